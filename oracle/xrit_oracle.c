@@ -1,0 +1,606 @@
+/*
+ * xrit_oracle.c -- CPU restatement of the xritdemod demodulation chain.
+ *
+ * TEST INFRASTRUCTURE ONLY (see xrit_oracle.h).  PARITY UNPINNED: the reference
+ * delegates every per-sample loop to libSatHelper, which is not vendored
+ * (/root/reference/Makefile:52-55) and has no tests (/root/reference/Makefile:91-92).
+ * Each function below cites the reference call site it serves and names the
+ * published algorithm it restates.  All per-sample arithmetic is float32, plain
+ * IEEE multiply/add (build with -ffp-contract=off: the reference is built with
+ * -O3 only, demodulator/CMakeLists.txt:33-34, i.e. no FMA contraction on x86-64).
+ */
+#define _GNU_SOURCE
+#include "xrit_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Tap designers                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* Filters::lowPass(1, Fs, Fs_circ/2, 100e3, HAMMING, 6.76), demodulator.cpp:444.
+ * GNU Radio firdes::low_pass: length = int(A*Fs/(22*tw)) forced odd with
+ * A = 53 dB for Hamming (beta is ignored for Hamming); windowed sinc; taps
+ * scaled so that the DC gain equals `gain`. */
+int xo_lowpass_ntaps(double fs, double transition_width)
+{
+    int ntaps = (int)(53.0 * fs / (22.0 * transition_width));
+    if ((ntaps & 1) == 0) ntaps++;
+    return ntaps;
+}
+
+int xo_lowpass_taps(double gain, double fs, double cutoff, double transition_width,
+                    float *taps, int cap)
+{
+    int ntaps = xo_lowpass_ntaps(fs, transition_width);
+    if (ntaps > cap) return -ntaps;
+    int M = (ntaps - 1) / 2;
+    double fwT0 = 2.0 * M_PI * cutoff / fs;
+    for (int n = -M; n <= M; n++) {
+        /* Hamming window, stored as float like the upstream window vector */
+        float w = (float)(0.54 - 0.46 * cos((2.0 * M_PI * (n + M)) / (ntaps - 1)));
+        if (n == 0)
+            taps[n + M] = (float)(fwT0 / M_PI * w);
+        else
+            taps[n + M] = (float)(sin(n * fwT0) / (n * M_PI) * w);
+    }
+    double fmax = taps[M];
+    for (int n = 1; n <= M; n++) fmax += 2.0 * taps[n + M];
+    gain /= fmax;
+    for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain);
+    return ntaps;
+}
+
+/* Filters::RRC(1, Fs_circ, symbolRate, alpha, 63), demodulator.cpp:443.
+ * GNU Radio firdes::root_raised_cosine. */
+int xo_rrc_taps(double gain, double fs, double symbol_rate, double alpha, int ntaps,
+                float *taps, int cap)
+{
+    ntaps |= 1;
+    if (ntaps > cap) return -ntaps;
+    double spb = fs / symbol_rate;
+    double scale = 0;
+    for (int i = 0; i < ntaps; i++) {
+        double x1, x2, x3, num, den;
+        double xindx = i - ntaps / 2;
+        x1 = M_PI * xindx / spb;
+        x2 = 4 * alpha * xindx / spb;
+        x3 = x2 * x2 - 1;
+        if (fabs(x3) >= 0.000001) {
+            if (i != ntaps / 2)
+                num = cos((1 + alpha) * x1) + sin((1 - alpha) * x1) / (4 * alpha * xindx / spb);
+            else
+                num = cos((1 + alpha) * x1) + (1 - alpha) * M_PI / (4 * alpha);
+            den = x3 * M_PI;
+        } else {
+            if (alpha == 1) {
+                taps[i] = -1;
+                scale += taps[i];
+                continue;
+            }
+            x3 = (1 - alpha) * x1;
+            x2 = (1 + alpha) * x1;
+            num = (sin(x2) * (1 + alpha) * M_PI
+                   - cos(x3) * ((1 - alpha) * M_PI * spb) / (4 * alpha * xindx)
+                   + sin(x3) * spb * spb / (4 * alpha * xindx * xindx));
+            den = -32 * M_PI * alpha * alpha * xindx / spb;
+        }
+        taps[i] = (float)(4 * alpha * num / den);
+        scale += taps[i];
+    }
+    for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain / scale);
+    return ntaps;
+}
+
+/* MMSE interpolator table used by ClockRecovery (demodulator.cpp:449).
+ * GNU Radio ships a generated table (interpolator_taps.h, 8 taps x 128 steps)
+ * that minimises the mean squared error of a fractional delay for signals
+ * band-limited to |f| <= B = 0.25 cycles/sample.  The generated file is not
+ * available here; this solves the same least-squares problem in closed form:
+ *     R h = p,  R[a][b] = 2B sinc(2B (a-b)),  p[a] = 2B sinc(2B (mu + j_a))
+ * where column a carries the label j_a = a-4 ("-4 ... 3" in the upstream header)
+ * and multiplies the sample at time -j_a; the target instant is mu in [0,1].
+ * Row 0 is the unit tap on column 4, row 128 the unit tap on column 3.
+ * Spot check against rows recalled from the upstream header (unverifiable
+ * here): row 1 = {-1.54700e-04, 8.53777e-04, -2.76968e-03, 7.89295e-03,
+ * 9.98534e-01, -5.41054e-03, 1.24642e-03, -1.98993e-04} and row 64 =
+ * {-6.77751e-03, 3.94578e-02, -1.42658e-01, 6.09836e-01, ...mirror} agree with
+ * this solution in every printed digit (tests/test_oracle_kat.py).
+ */
+static double xo_sinc(double x)
+{
+    if (fabs(x) < 1e-12) return 1.0;
+    return sin(M_PI * x) / (M_PI * x);
+}
+
+static void xo_solve8(double A[8][8], double b[8], double x[8])
+{
+    int n = 8;
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (piv != c) {
+            for (int k = 0; k < n; k++) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+            double t = b[c]; b[c] = b[piv]; b[piv] = t;
+        }
+        for (int r = c + 1; r < n; r++) {
+            double f = A[r][c] / A[c][c];
+            for (int k = c; k < n; k++) A[r][k] -= f * A[c][k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < n; k++) s -= A[r][k] * x[k];
+        x[r] = s / A[r][r];
+    }
+}
+
+void xo_mmse_table(float *table)
+{
+    const double B = 0.25;
+    for (int s = 0; s <= XO_MM_NSTEPS; s++) {
+        double mu = (double)s / XO_MM_NSTEPS;
+        double A[8][8], p[8], h[8];
+        for (int a = 0; a < 8; a++) {
+            for (int b = 0; b < 8; b++) A[a][b] = 2 * B * xo_sinc(2 * B * (a - b));
+            p[a] = 2 * B * xo_sinc(2 * B * (mu + (a - 4)));
+        }
+        xo_solve8(A, p, h);
+        for (int a = 0; a < 8; a++) {
+            /* upstream stores the table as "%.5e" literals: round the same way */
+            char txt[32];
+            snprintf(txt, sizeof txt, "%.5e", h[a]);
+            table[s * 8 + a] = strtof(txt, NULL);
+        }
+    }
+    /* exact end rows, as in the upstream table */
+    for (int a = 0; a < 8; a++) {
+        table[a] = (a == 4) ? 1.0f : 0.0f;
+        table[XO_MM_NSTEPS * 8 + a] = (a == 3) ? 1.0f : 0.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* FirFilter                                                                 */
+/* ------------------------------------------------------------------------- */
+
+struct xo_fir {
+    unsigned D;
+    int      T;
+    float   *rtaps;  /* reversed taps: rtaps[i] = h[T-1-i] */
+    xo_cf   *buf;    /* [T-1 history | new samples] */
+    size_t   cap;
+};
+
+xo_fir *xo_fir_create(unsigned decimation, const float *taps, int ntaps)
+{
+    xo_fir *f = (xo_fir *)calloc(1, sizeof(*f));
+    f->D = decimation ? decimation : 1;
+    f->T = ntaps;
+    f->rtaps = (float *)malloc(sizeof(float) * ntaps);
+    for (int i = 0; i < ntaps; i++) f->rtaps[i] = taps[ntaps - 1 - i];
+    f->cap = 0;
+    f->buf = NULL;
+    return f;
+}
+
+void xo_fir_destroy(xo_fir *f)
+{
+    if (!f) return;
+    free(f->rtaps);
+    free(f->buf);
+    free(f);
+}
+
+/* FirFilter::Work(in, out, nOut), demodulator.cpp:138,148.  GNU Radio
+ * fir_filter_ccf semantics: T-1 samples of zero-initialised history persist
+ * across calls; output m of a call is sum_k h[k] x[m*D - k] with x[0] the first
+ * new sample.  The summation order of the upstream dot product (VOLK SIMD) is
+ * unspecified; this restatement accumulates in float32 in four interleaved
+ * partial sums (lane = tap index mod 4 over the time-ordered window), then
+ * (s0+s1)+(s2+s3) -- the shape of a 4-wide SIMD dot product. */
+void xo_fir_work(xo_fir *f, const xo_cf *in, xo_cf *out, int n_out)
+{
+    int T = f->T;
+    size_t n_in = (size_t)n_out * f->D;
+    size_t need = (size_t)(T - 1) + n_in;
+    if (need > f->cap) {
+        xo_cf *nb = (xo_cf *)calloc(need + 64, sizeof(xo_cf));
+        if (f->buf) memcpy(nb, f->buf, sizeof(xo_cf) * (size_t)(T - 1));
+        free(f->buf);
+        f->buf = nb;
+        f->cap = need + 64;
+    }
+    memcpy(f->buf + (T - 1), in, sizeof(xo_cf) * n_in);
+    const float *rt = f->rtaps;
+    for (int m = 0; m < n_out; m++) {
+        const xo_cf *w = f->buf + (size_t)m * f->D; /* w[i] = x[m*D - (T-1) + i] */
+        float sr[4] = {0, 0, 0, 0}, si[4] = {0, 0, 0, 0};
+        int i = 0;
+        for (; i + 4 <= T; i += 4) {
+            for (int j = 0; j < 4; j++) {
+                sr[j] += rt[i + j] * w[i + j].re;
+                si[j] += rt[i + j] * w[i + j].im;
+            }
+        }
+        for (int j = 0; i < T; i++, j++) {
+            sr[j] += rt[i] * w[i].re;
+            si[j] += rt[i] * w[i].im;
+        }
+        out[m].re = (sr[0] + sr[1]) + (sr[2] + sr[3]);
+        out[m].im = (si[0] + si[1]) + (si[2] + si[3]);
+    }
+    /* keep the last T-1 consumed samples as history */
+    if (n_in > 0) memmove(f->buf, f->buf + n_in, sizeof(xo_cf) * (size_t)(T - 1));
+}
+
+/* ------------------------------------------------------------------------- */
+/* AGC                                                                       */
+/* ------------------------------------------------------------------------- */
+
+void xo_agc_init(xo_agc *a, float rate, float reference, float gain, float max_gain)
+{
+    a->rate = rate;
+    a->reference = reference;
+    a->gain = gain;
+    a->max_gain = max_gain;
+}
+
+/* AGC::Work, demodulator.cpp:143 with AGC(0.01, 0.5, 1, 4000) (:447).
+ * GNU Radio analog::agc_cc::scale + set_max_gain. */
+void xo_agc_work(xo_agc *a, const xo_cf *in, xo_cf *out, int n)
+{
+    float g = a->gain;
+    for (int i = 0; i < n; i++) {
+        float yr = in[i].re * g;
+        float yi = in[i].im * g;
+        out[i].re = yr;
+        out[i].im = yi;
+        g += a->rate * (a->reference - sqrtf(yr * yr + yi * yi));
+        if (a->max_gain > 0.0f && g > a->max_gain) g = a->max_gain;
+    }
+    a->gain = g;
+}
+
+/* ------------------------------------------------------------------------- */
+/* CostasLoop                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* CostasLoop(pllAlpha, LOOP_ORDER=2), demodulator.cpp:448; loop bandwidth
+ * defaults to CLOCK_ALPHA=0.0037 (demodulator.cpp:220).  GNU Radio
+ * blocks::control_loop(bw, +1, -1): damping sqrt(2)/2. */
+void xo_costas_init(xo_costas *c, float loop_bw)
+{
+    float damping = sqrtf(2.0f) / 2.0f;
+    float denom = (1.0f + 2.0f * damping * loop_bw + loop_bw * loop_bw);
+    c->alpha = (4 * damping * loop_bw) / denom;
+    c->beta = (4 * loop_bw * loop_bw) / denom;
+    c->phase = 0;
+    c->freq = 0;
+    c->max_freq = 1.0f;
+    c->min_freq = -1.0f;
+}
+
+static inline float xo_clip(float x, float clip)
+{
+    /* branchless_clip: 0.5*(|x+clip| - |x-clip|) */
+    float x1 = fabsf(x + clip);
+    float x2 = fabsf(x - clip);
+    x1 -= x2;
+    return 0.5f * x1;
+}
+
+/* CostasLoop::Work, demodulator.cpp:152.  GNU Radio digital::costas_loop_cc,
+ * order 2, no SNR weighting: out = in * exp(-j phase); error = re*im clipped to
+ * +-1; freq += beta*err; phase += freq + alpha*err; wrap to +-2pi; limit freq. */
+void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n)
+{
+    const float twopi = (float)(2.0 * M_PI);
+    float phase = c->phase, freq = c->freq;
+    for (int i = 0; i < n; i++) {
+        float s, co;
+        sincosf(-phase, &s, &co);
+        float yr = in[i].re * co - in[i].im * s;
+        float yi = in[i].re * s + in[i].im * co;
+        out[i].re = yr;
+        out[i].im = yi;
+        float err = yr * yi;
+        err = xo_clip(err, 1.0f);
+        freq = freq + c->beta * err;
+        phase = phase + freq + c->alpha * err;
+        while (phase > twopi) phase -= twopi;
+        while (phase < -twopi) phase += twopi;
+        if (freq > c->max_freq) freq = c->max_freq;
+        else if (freq < c->min_freq) freq = c->min_freq;
+    }
+    c->phase = phase;
+    c->freq = freq;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ClockRecovery (Mueller & Mueller, complex)                                */
+/* ------------------------------------------------------------------------- */
+
+struct xo_mm {
+    float mu, omega, omega_mid, omega_lim, gain_omega, gain_mu;
+    xo_cf p_2t, p_1t, p_0t, c_2t, c_1t, c_0t;
+    float table[(XO_MM_NSTEPS + 1) * XO_MM_NTAPS];
+    xo_cf *buf;   /* [carry | new] */
+    size_t cap;
+    int    carry;
+};
+
+xo_mm *xo_mm_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit)
+{
+    xo_mm *m = (xo_mm *)calloc(1, sizeof(*m));
+    m->mu = mu;
+    m->omega = omega;
+    m->omega_mid = omega;
+    m->omega_lim = omega * omega_rel_limit;
+    m->gain_omega = gain_omega;
+    m->gain_mu = gain_mu;
+    xo_mmse_table(m->table);
+    return m;
+}
+
+void xo_mm_destroy(xo_mm *m)
+{
+    if (!m) return;
+    free(m->buf);
+    free(m);
+}
+
+void xo_mm_get_state(const xo_mm *m, xo_mm_state *s)
+{
+    s->mu = m->mu; s->omega = m->omega; s->omega_mid = m->omega_mid; s->omega_lim = m->omega_lim;
+    s->gain_omega = m->gain_omega; s->gain_mu = m->gain_mu;
+    s->p_2t = m->p_2t; s->p_1t = m->p_1t; s->p_0t = m->p_0t;
+    s->c_2t = m->c_2t; s->c_1t = m->c_1t; s->c_0t = m->c_0t;
+    s->carry = m->carry;
+}
+
+/* ClockRecovery::Work(in, out, n) -> symbols, demodulator.cpp:156.  GNU Radio
+ * digital::clock_recovery_mm_cc::general_work.  A symbol is produced while the
+ * read index ii satisfies ii < available - NTAPS - FUDGE (the upstream `ni`);
+ * samples not yet consumed are carried to the next call, which makes the
+ * symbol sequence independent of how the stream is chunked (GNU Radio's
+ * scheduler gives the same guarantee through consume_each(ii)). */
+int xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, float *mu_trace)
+{
+    size_t total = (size_t)m->carry + (size_t)n;
+    if (total > m->cap) {
+        xo_cf *nb = (xo_cf *)malloc(sizeof(xo_cf) * (total + 64));
+        if (m->carry) memcpy(nb, m->buf, sizeof(xo_cf) * (size_t)m->carry);
+        free(m->buf);
+        m->buf = nb;
+        m->cap = total + 64;
+    }
+    memcpy(m->buf + m->carry, in, sizeof(xo_cf) * (size_t)n);
+    const xo_cf *x = m->buf;
+    long ni = (long)total - XO_MM_NTAPS - XO_MM_FUDGE;
+    long ii = 0;
+    int oo = 0;
+    float mu = m->mu, omega = m->omega;
+    while (ii < ni) {
+        m->p_2t = m->p_1t;
+        m->p_1t = m->p_0t;
+        /* mmse_fir_interpolator_cc::interpolate */
+        int imu = (int)rint(mu * XO_MM_NSTEPS);
+        const float *row = m->table + imu * XO_MM_NTAPS;
+        float ar = 0, ai = 0;
+        for (int k = 0; k < XO_MM_NTAPS; k++) {
+            ar += row[XO_MM_NTAPS - 1 - k] * x[ii + k].re;
+            ai += row[XO_MM_NTAPS - 1 - k] * x[ii + k].im;
+        }
+        m->p_0t.re = ar;
+        m->p_0t.im = ai;
+
+        m->c_2t = m->c_1t;
+        m->c_1t = m->c_0t;
+        /* slicer_0deg */
+        m->c_0t.re = m->p_0t.re > 0 ? 1.0f : 0.0f;
+        m->c_0t.im = m->p_0t.im > 0 ? 1.0f : 0.0f;
+
+        /* x = (c0 - c2) * conj(p1); y = (p0 - p2) * conj(c1); mm = Re(y - x) */
+        float dcr = m->c_0t.re - m->c_2t.re, dci = m->c_0t.im - m->c_2t.im;
+        float xr = dcr * m->p_1t.re + dci * m->p_1t.im;
+        float dpr = m->p_0t.re - m->p_2t.re, dpi = m->p_0t.im - m->p_2t.im;
+        float yr = dpr * m->c_1t.re + dpi * m->c_1t.im;
+        float mm_val = yr - xr;
+        if (arm) arm[oo] = imu;
+        if (mu_trace) mu_trace[oo] = mu;
+        out[oo++] = m->p_0t;
+
+        mm_val = xo_clip(mm_val, 1.0f);
+        omega = omega + m->gain_omega * mm_val;
+        omega = m->omega_mid + xo_clip(omega - m->omega_mid, m->omega_lim);
+        mu = mu + omega + m->gain_mu * mm_val;
+        float fl = floorf(mu);
+        ii += (long)fl;
+        mu -= fl;
+    }
+    m->mu = mu;
+    m->omega = omega;
+    if (ii > (long)total) ii = (long)total;
+    m->carry = (int)((long)total - ii);
+    memmove(m->buf, m->buf + ii, sizeof(xo_cf) * (size_t)m->carry);
+    return oo;
+}
+
+int xo_mm_work(xo_mm *m, const xo_cf *in, int n, xo_cf *out)
+{
+    return xo_mm_work_trace(m, in, n, out, NULL, NULL);
+}
+
+/* ------------------------------------------------------------------------- */
+/* The chain                                                                 */
+/* ------------------------------------------------------------------------- */
+
+static void xo_config_common(xo_config *c, float sample_rate, uint32_t decimation)
+{
+    c->sample_rate = sample_rate;
+    c->decimation = decimation;
+    c->rrc_taps = 63;                                   /* RRC_TAPS */
+    c->agc_rate = 0.01f;                                /* AGC_RATE */
+    c->agc_reference = 0.5f;                            /* AGC_REFERENCE */
+    c->agc_gain = 1.f;                                  /* AGC_GAIN */
+    c->agc_max_gain = 4000;                             /* AGC_MAX_GAIN */
+    c->pll_alpha = 0.0037f;                             /* (float)CLOCK_ALPHA, demodulator.cpp:220 */
+    c->clock_mu = 0.5f;                                 /* CLOCK_MU */
+    c->clock_alpha = 0.0037f;                           /* CLOCK_ALPHA */
+    c->clock_gain_omega = (0.0037f * 0.0037f) / 4.0f;   /* CLOCK_GAIN_OMEGA */
+    c->clock_omega_limit = 0.005f;                      /* CLOCK_OMEGA_LIMIT */
+}
+
+void xo_config_lrit(xo_config *c, float sample_rate, uint32_t decimation)
+{
+    xo_config_common(c, sample_rate, decimation);
+    c->symbol_rate = 293883;
+    c->rrc_alpha = 0.5f;
+}
+
+void xo_config_hrit(xo_config *c, float sample_rate, uint32_t decimation)
+{
+    xo_config_common(c, sample_rate, decimation);
+    c->symbol_rate = 927000;
+    c->rrc_alpha = 0.3f;
+}
+
+struct xo_demod {
+    xo_config cfg;
+    float     sps;
+    int       dec_ntaps;
+    float    *dec_taps;
+    float     rrc_taps[256];
+    xo_fir   *decimator;
+    xo_fir   *rrc;
+    xo_agc    agc;
+    xo_costas costas;
+    xo_mm    *mm;
+    xo_cf    *stage[6];  /* 0 converted input .. 5 clock recovery */
+    int       stage_n[6];
+    size_t    cap;
+};
+
+/* main(), demodulator.cpp:436-450 */
+xo_demod *xo_demod_create(const xo_config *cfg)
+{
+    xo_demod *d = (xo_demod *)calloc(1, sizeof(*d));
+    d->cfg = *cfg;
+    float circuit_rate = cfg->sample_rate / ((float)cfg->decimation);  /* :436 */
+    float sps = circuit_rate / ((float)cfg->symbol_rate);              /* :437 */
+    d->sps = sps;
+    xo_rrc_taps(1, circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps, d->rrc_taps, 256);
+    d->dec_ntaps = xo_lowpass_ntaps(cfg->sample_rate, 100e3);
+    d->dec_taps = (float *)malloc(sizeof(float) * (size_t)d->dec_ntaps);
+    xo_lowpass_taps(1, cfg->sample_rate, circuit_rate / 2, 100e3, d->dec_taps, d->dec_ntaps);
+    d->decimator = xo_fir_create(cfg->decimation, d->dec_taps, d->dec_ntaps);
+    xo_agc_init(&d->agc, cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain);
+    xo_costas_init(&d->costas, cfg->pll_alpha);
+    d->mm = xo_mm_create(sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha,
+                         cfg->clock_omega_limit);
+    d->rrc = xo_fir_create(1, d->rrc_taps, cfg->rrc_taps | 1);
+    return d;
+}
+
+void xo_demod_destroy(xo_demod *d)
+{
+    if (!d) return;
+    xo_fir_destroy(d->decimator);
+    xo_fir_destroy(d->rrc);
+    xo_mm_destroy(d->mm);
+    free(d->dec_taps);
+    for (int i = 0; i < 6; i++) free(d->stage[i]);
+    free(d);
+}
+
+/* onSamplesAvailable, demodulator.cpp:54-74 (+ the FIFO -> complex
+ * deinterleave of :124-128, which is the identity on an interleaved buffer) */
+void xo_convert_samples(const void *in, int sample_type, xo_cf *out, size_t n)
+{
+    if (sample_type == XO_SAMPLE_FLOATIQ) {
+        memcpy(out, in, n * sizeof(xo_cf));
+    } else if (sample_type == XO_SAMPLE_S16IQ) {
+        const int16_t *d = (const int16_t *)in;
+        for (size_t i = 0; i < n; i++) {
+            out[i].re = d[2 * i] / 32768.f;
+            out[i].im = d[2 * i + 1] / 32768.f;
+        }
+    } else if (sample_type == XO_SAMPLE_S8IQ) {
+        const int8_t *d = (const int8_t *)in;
+        for (size_t i = 0; i < n; i++) {
+            out[i].re = d[2 * i] / 128.f;
+            out[i].im = d[2 * i + 1] / 128.f;
+        }
+    }
+}
+
+/* processSamples(), demodulator.cpp:100-168 */
+int xo_demod_process(xo_demod *d, const void *samples, int n, int sample_type,
+                     float *soft_out, int cap_out)
+{
+    if (n <= 0) return 0;
+    if ((size_t)n > d->cap) {
+        for (int i = 0; i < 6; i++) {
+            free(d->stage[i]);
+            d->stage[i] = (xo_cf *)malloc(sizeof(xo_cf) * ((size_t)n + 64));
+        }
+        d->cap = (size_t)n;
+    }
+    int length = n;
+    xo_convert_samples(samples, sample_type, d->stage[0], (size_t)n);
+    const xo_cf *cur = d->stage[0];
+    d->stage_n[0] = n;
+    if (d->cfg.decimation > 1) {                       /* :136-140 */
+        length /= (int)d->cfg.decimation;              /* remainder samples are dropped */
+        xo_fir_work(d->decimator, cur, d->stage[1], length);
+        cur = d->stage[1];
+    } else {
+        memcpy(d->stage[1], cur, sizeof(xo_cf) * (size_t)length);
+    }
+    d->stage_n[1] = length;
+    xo_agc_work(&d->agc, cur, d->stage[2], length);    /* :143 */
+    d->stage_n[2] = length;
+    xo_fir_work(d->rrc, d->stage[2], d->stage[3], length);      /* :148 */
+    d->stage_n[3] = length;
+    xo_costas_work(&d->costas, d->stage[3], d->stage[4], length); /* :152 */
+    d->stage_n[4] = length;
+    /* the M&M output never exceeds the input length for sps >= 1 */
+    int symbols = xo_mm_work(d->mm, d->stage[4], length, d->stage[5]); /* :156 */
+    d->stage_n[5] = symbols;
+    if (symbols > cap_out) return -symbols;
+    for (int i = 0; i < symbols; i++) soft_out[i] = d->stage[5][i].re; /* SymbolManager.cpp:104 */
+    return symbols;
+}
+
+const xo_cf *xo_demod_stage(const xo_demod *d, int stage, int *n)
+{
+    if (stage < 0 || stage > 4) return NULL;
+    if (n) *n = d->stage_n[stage + 1];
+    return d->stage[stage + 1];
+}
+
+int xo_demod_decimator_ntaps(const xo_demod *d) { return d->dec_ntaps; }
+const float *xo_demod_decimator_taps(const xo_demod *d) { return d->dec_taps; }
+const float *xo_demod_rrc_taps(const xo_demod *d) { return d->rrc_taps; }
+float xo_demod_sps(const xo_demod *d) { return d->sps; }
+
+/* SymbolManager::process, SymbolManager.cpp:43-46 */
+void xo_quantize_i8(const float *in, int8_t *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        float f = in[i] * 127;
+        f = f > 127 ? 127 : f;
+        f = f < -128 ? -128 : f;
+        out[i] = (int8_t)(char)(f);
+    }
+}

@@ -1,0 +1,126 @@
+/*
+ * xrit_oracle.h -- CPU restatement of the xritdemod BPSK demodulation chain.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path lives in the third-party library
+ * libSatHelper (github.com/opensatelliteproject/libsathelper, fetched un-pinned by
+ * /root/reference/Makefile:52-55, absent from /root/reference and from this
+ * image), and the reference ships no tests or golden vectors (Makefile:91-92).
+ * This file restates the published algorithms those classes implement (the GNU
+ * Radio 3.7 blocks the in-repo flowgraph demod_tcp_qt.py:95-96,261-266,275-276
+ * wires with the same parameter lists) and anchors on the reference's own call
+ * sites: demodulator/src/demodulator.cpp:54-74 (ingest), :100-168 (stage
+ * order), :436-450 (construction), Parameters.h:16-37 (constants),
+ * SymbolManager.cpp:43-46,104 (soft-symbol selection and int8 quantiser).
+ */
+#ifndef XRIT_ORACLE_H_
+#define XRIT_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } xo_cf;
+
+/* Sample types, FrontendDevice.h:11-13 */
+#define XO_SAMPLE_FLOATIQ 0
+#define XO_SAMPLE_S16IQ   1
+#define XO_SAMPLE_S8IQ    2
+
+#define XO_MM_NTAPS  8
+#define XO_MM_NSTEPS 128
+#define XO_MM_FUDGE  16
+
+/* ---- tap designers (run once at start-up, demodulator.cpp:443-444) ---- */
+/* Filters::lowPass(gain, Fs, cutoff, transitionWidth, HAMMING, beta): returns
+ * the tap count (GNU Radio firdes length rule); writes at most cap taps. */
+int  xo_lowpass_ntaps(double fs, double transition_width);
+int  xo_lowpass_taps(double gain, double fs, double cutoff, double transition_width,
+                     float *taps, int cap);
+/* Filters::RRC(gain, Fs, symbolRate, alpha, ntaps): ntaps is forced odd; returns it. */
+int  xo_rrc_taps(double gain, double fs, double symbol_rate, double alpha, int ntaps,
+                 float *taps, int cap);
+/* 8-tap, 128-step MMSE fractional interpolator table (129 rows x 8), one-sided
+ * design bandwidth 0.25 cycles/sample.  Row layout follows GNU Radio's
+ * interpolator_taps.h: column c multiplies the sample 3-(7-c) ... see .c file. */
+void xo_mmse_table(float *table /* [129*8] */);
+
+/* ---- FirFilter(decimation, taps): y[m] = sum_k h[k] x[m*D - k] ---- */
+typedef struct xo_fir xo_fir;
+xo_fir *xo_fir_create(unsigned decimation, const float *taps, int ntaps);
+void    xo_fir_destroy(xo_fir *f);
+/* Work(in, out, nOut): consumes nOut*D input samples (demodulator.cpp:137-138) */
+void    xo_fir_work(xo_fir *f, const xo_cf *in, xo_cf *out, int n_out);
+
+/* ---- AGC(rate, reference, gain, maxGain) ---- */
+typedef struct { float rate, reference, gain, max_gain; } xo_agc;
+void xo_agc_init(xo_agc *a, float rate, float reference, float gain, float max_gain);
+void xo_agc_work(xo_agc *a, const xo_cf *in, xo_cf *out, int n);
+
+/* ---- CostasLoop(loopBw, order=2) ---- */
+typedef struct { float phase, freq, alpha, beta, max_freq, min_freq; } xo_costas;
+void xo_costas_init(xo_costas *c, float loop_bw);
+void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n);
+
+/* ---- ClockRecovery(omega, gainOmega, mu, gainMu, omegaRelativeLimit) ---- */
+typedef struct xo_mm xo_mm;
+typedef struct {
+    float mu, omega, omega_mid, omega_lim, gain_omega, gain_mu;
+    xo_cf p_2t, p_1t, p_0t, c_2t, c_1t, c_0t;
+    int   carry; /* unread samples held for the next call */
+} xo_mm_state;
+xo_mm *xo_mm_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit);
+void   xo_mm_destroy(xo_mm *m);
+/* returns symbols written; out must hold at least n/ (omega*(1-lim)) + 2 */
+int    xo_mm_work(xo_mm *m, const xo_cf *in, int n, xo_cf *out);
+void   xo_mm_get_state(const xo_mm *m, xo_mm_state *s);
+/* per-symbol trace for diagnostics (tests only): arm index of the last call */
+int    xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, float *mu_trace);
+
+/* ---- the chain, demodulator.cpp:100-168 ---- */
+typedef struct {
+    float    sample_rate;      /* device->GetSampleRate() */
+    uint32_t decimation;       /* baseDecimation, cfg "decimation" */
+    uint32_t symbol_rate;      /* LRIT 293883 / HRIT 927000, Parameters.h:18,23 */
+    float    rrc_alpha;        /* Parameters.h:19,24 */
+    int      rrc_taps;         /* RRC_TAPS 63 */
+    float    agc_rate, agc_reference, agc_gain, agc_max_gain; /* Parameters.h:34-37 */
+    float    pll_alpha;        /* = CLOCK_ALPHA, demodulator.cpp:220 */
+    float    clock_mu, clock_alpha, clock_gain_omega, clock_omega_limit; /* Parameters.h:30-33 */
+} xo_config;
+
+void xo_config_lrit(xo_config *c, float sample_rate, uint32_t decimation);
+void xo_config_hrit(xo_config *c, float sample_rate, uint32_t decimation);
+
+typedef struct xo_demod xo_demod;
+xo_demod *xo_demod_create(const xo_config *cfg);
+void      xo_demod_destroy(xo_demod *d);
+/* One processSamples() pass over n complex samples of the given type.
+ * soft_out receives the real parts of the recovered symbols
+ * (SymbolManager.cpp:104); returns the symbol count.  cap_out is checked. */
+int       xo_demod_process(xo_demod *d, const void *samples, int n, int sample_type,
+                           float *soft_out, int cap_out);
+/* Stage taps for tests / the staged-parity checks.  stage: 0 decimator out,
+ * 1 agc out, 2 rrc out, 3 costas out, 4 clock-recovery out (complex).
+ * Valid until the next process() call. */
+const xo_cf *xo_demod_stage(const xo_demod *d, int stage, int *n);
+int       xo_demod_decimator_ntaps(const xo_demod *d);
+const float *xo_demod_decimator_taps(const xo_demod *d);
+const float *xo_demod_rrc_taps(const xo_demod *d);
+float     xo_demod_sps(const xo_demod *d);
+
+/* SymbolManager::process quantiser, SymbolManager.cpp:43-46 */
+void xo_quantize_i8(const float *in, int8_t *out, size_t n);
+/* ingest conversion, demodulator.cpp:54-74 */
+void xo_convert_samples(const void *in, int sample_type, xo_cf *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRIT_ORACLE_H_ */
