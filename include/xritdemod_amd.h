@@ -1,0 +1,194 @@
+/*
+ * xritdemod_amd.h -- C ABI of the MI355X-native xRIT BPSK demodulation chain.
+ *
+ * The reference (opensatelliteproject/xritdemod) has no FFI for this path; the
+ * seam is the libSatHelper C++ class API as used by
+ * demodulator/src/demodulator.cpp.  Every entry point below names the
+ * reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers and sizes; no exceptions cross the ABI.
+ *   - return value: 0 (XRIT_OK) or a negative XRIT_E_* code; xrit_last_error()
+ *     gives the text of the last failure on the calling thread.
+ *   - complex samples are interleaved (re, im) float32 = std::complex<float>.
+ *   - "host" entry points take host pointers and do the H2D/D2H copies;
+ *     "_device" entry points take device pointers (HBM-resident data) and a
+ *     hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - a handle is single-consumer (the reference calls Work() from one thread,
+ *     demodulator.cpp:170-175,475); distinct handles may be used concurrently.
+ *   - the compute path is HIP only: if no HIP device is usable, create fails
+ *     with XRIT_E_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef XRITDEMOD_AMD_H_
+#define XRITDEMOD_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XRIT_OK            0
+#define XRIT_E_INVALID    -1   /* bad argument */
+#define XRIT_E_NO_DEVICE  -2   /* no usable HIP device */
+#define XRIT_E_HIP        -3   /* HIP runtime error (text in xrit_last_error) */
+#define XRIT_E_NOMEM      -4
+#define XRIT_E_CAPACITY   -5   /* output buffer too small */
+#define XRIT_E_NOT_CONVERGED -6 /* strict mode only: hand-off passes exhausted */
+
+/* FrontendDevice.h:11-13 */
+#define XRIT_SAMPLE_FLOATIQ 0
+#define XRIT_SAMPLE_S16IQ   1
+#define XRIT_SAMPLE_S8IQ    2
+
+const char *xrit_last_error(void);
+const char *xrit_version(void);
+/* number of visible HIP devices (0 when none / runtime unusable) */
+int xrit_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Tap designers -- SatHelper::Filters (demodulator.cpp:443-444), host only.
+ * ------------------------------------------------------------------------ */
+/* Filters::lowPass(gain, sampleRate, cutFreq, transitionWidth, HAMMING, beta)
+ * -> number of taps written, or the negative required count if cap is short */
+int xrit_lowpass_taps(double gain, double sample_rate, double cutoff, double transition_width,
+                      float *taps, int cap);
+/* Filters::RRC(gain, sampleRate, symbolRate, alpha, nTaps) -> taps written */
+int xrit_rrc_taps(double gain, double sample_rate, double symbol_rate, double alpha, int ntaps,
+                  float *taps, int cap);
+/* the 129 x 8 MMSE interpolator table used by ClockRecovery */
+void xrit_mmse_table(float *table /* [129*8] */);
+
+/* ------------------------------------------------------------------------
+ * The chain -- processSamples(), demodulator.cpp:100-168, with the objects
+ * main() builds at demodulator.cpp:436-450.
+ * ------------------------------------------------------------------------ */
+typedef struct xrit_demod xrit_demod;
+
+typedef struct xrit_demod_config {
+    /* reference parameters */
+    float    sample_rate;       /* device->GetSampleRate(), demodulator.cpp:436 */
+    uint32_t decimation;        /* baseDecimation, cfg "decimation" (:300-301) */
+    uint32_t symbol_rate;       /* cfg "symbolRate"; LRIT 293883 / HRIT 927000 */
+    float    rrc_alpha;         /* cfg "rrcAlpha"; 0.5 / 0.3 */
+    int32_t  rrc_taps;          /* RRC_TAPS = 63, Parameters.h:28 */
+    float    agc_rate, agc_reference, agc_gain, agc_max_gain;   /* Parameters.h:34-37 */
+    float    pll_alpha;         /* Costas loop bandwidth = CLOCK_ALPHA (demodulator.cpp:220) */
+    float    clock_mu, clock_alpha, clock_gain_omega, clock_omega_limit; /* Parameters.h:30-33 */
+    /* placement */
+    int32_t  device;            /* HIP device ordinal */
+    /* time-slice tiling of the feedback loops (0 = library default) */
+    int32_t  costas_chain_len;  /* samples per Costas chain */
+    int32_t  clock_chain_syms;  /* symbols per clock-recovery chain */
+    int32_t  max_passes;        /* hand-off passes before giving up (per loop) */
+    int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED instead of accepting the residual */
+    int32_t  reserved[8];
+} xrit_demod_config;
+
+/* setLRITMode / setHRITMode + Parameters.h defaults (demodulator.cpp:177-197) */
+void xrit_demod_config_lrit(xrit_demod_config *cfg, float sample_rate, uint32_t decimation);
+void xrit_demod_config_hrit(xrit_demod_config *cfg, float sample_rate, uint32_t decimation);
+
+int  xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out);
+void xrit_demod_destroy(xrit_demod *d);
+
+/* One processSamples() pass: onSamplesAvailable conversion (:54-74), decimator
+ * (:136-140, n/decimation outputs, remainder dropped), AGC (:143), RRC (:148),
+ * Costas (:152), clock recovery (:156); soft_out receives Re(symbol)
+ * (SymbolManager.cpp:104).  State persists across calls like the SatHelper
+ * objects.  n_out may exceed nothing: cap must be >= n/(decimation*sps*0.99)+64.
+ * Host buffers. */
+int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int sample_type,
+                       float *soft_out, size_t cap, size_t *n_out);
+/* Same with device-resident input and output (no PCIe in the call). */
+int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type,
+                              float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* symbols per sample as the reference computes it (demodulator.cpp:437) */
+float xrit_demod_sps(const xrit_demod *d);
+int   xrit_demod_decimator_ntaps(const xrit_demod *d);
+
+/* Diagnostics: enable=1 makes every later process call keep a copy of each
+ * stage's output (costs D2D copies; off by default). */
+int xrit_demod_keep_stages(xrit_demod *d, int enable);
+/* Copies a stage's output of the LAST process call to host (tests/diagnostics):
+ * 0 decimator, 1 agc, 2 rrc, 3 costas, 4 clock recovery (complex symbols).
+ * Returns the element count through n; out may be NULL to query the count. */
+int xrit_demod_read_stage(xrit_demod *d, int stage, float *out_interleaved, size_t cap, size_t *n);
+
+typedef struct xrit_demod_stats {
+    uint64_t samples_in;          /* last call */
+    uint64_t circuit_samples;
+    uint64_t symbols_out;
+    int32_t  costas_passes;       /* hand-off passes run, last call */
+    int32_t  clock_passes;
+    uint32_t costas_unconverged;  /* chain boundaries left above tolerance */
+    uint32_t clock_unconverged;
+    float    costas_max_residual; /* rad */
+    float    clock_max_residual;  /* samples */
+    int32_t  agc_serial_fallback; /* 1 if the affine scan guard tripped (|x|*rate > 1) */
+    int32_t  reserved[5];
+} xrit_demod_stats;
+int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s);
+
+/* Per-kernel timing with HIP events on the stream the kernels are launched on.
+ * enable=1 brackets every launch of the following process calls. */
+int xrit_demod_profile(xrit_demod *d, int enable);
+/* name/ms arrays are filled with up to cap entries (accumulated since enable);
+ * launches[] = number of launches per kernel.  Returns entries written. */
+int xrit_demod_profile_read(xrit_demod *d, const char **names, float *total_ms, int *launches, int cap);
+
+/* SymbolManager::process quantiser (SymbolManager.cpp:43-46): f=s*127, clamp
+ * [-128,127], C cast (truncation).  Device kernel on device pointers. */
+int xrit_quantize_i8_device(const float *d_soft, int8_t *d_out, size_t n, int device, void *stream);
+int xrit_quantize_i8(xrit_demod *d, const float *soft, int8_t *out, size_t n);
+
+/* ------------------------------------------------------------------------
+ * Stage objects -- the SatHelper classes one by one, for stage-level parity
+ * and for callers that keep the reference's five-Work() structure.
+ * in/out are HOST pointers unless the _device variant is used.
+ * ------------------------------------------------------------------------ */
+typedef struct xrit_fir     xrit_fir;      /* SatHelper::FirFilter      (demodulator.cpp:446,450) */
+typedef struct xrit_agc     xrit_agc;      /* SatHelper::AGC            (:447) */
+typedef struct xrit_costas  xrit_costas;   /* SatHelper::CostasLoop     (:448) */
+typedef struct xrit_clock   xrit_clock;    /* SatHelper::ClockRecovery  (:449) */
+
+int  xrit_fir_create(unsigned decimation, const float *taps, int ntaps, int device, xrit_fir **out);
+/* FirFilter::Work(in, out, nOut): consumes nOut*decimation samples */
+int  xrit_fir_work(xrit_fir *f, const float *in, float *out, size_t n_out);
+void xrit_fir_destroy(xrit_fir *f);
+
+int  xrit_agc_create(float rate, float reference, float gain, float max_gain, int device, xrit_agc **out);
+int  xrit_agc_work(xrit_agc *a, const float *in, float *out, size_t n);
+float xrit_agc_gain(xrit_agc *a);
+void xrit_agc_destroy(xrit_agc *a);
+
+int  xrit_costas_create(float loop_bw, int order, int device, xrit_costas **out);
+int  xrit_costas_work(xrit_costas *c, const float *in, float *out, size_t n);
+int  xrit_costas_state(xrit_costas *c, float *phase, float *freq);
+void xrit_costas_destroy(xrit_costas *c);
+
+int  xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit,
+                       int device, xrit_clock **out);
+/* ClockRecovery::Work(in, out, n) -> symbols through n_out */
+int  xrit_clock_work(xrit_clock *c, const float *in, size_t n, float *out, size_t cap, size_t *n_out);
+void xrit_clock_destroy(xrit_clock *c);
+
+/* ------------------------------------------------------------------------
+ * Synthetic burst generator -- stands in for the cf32 capture
+ * the reference reads through CFileFrontend (CFileFrontend.cpp:34-56).
+ * Writes n cf32 samples [start, start+n) into a device buffer.
+ * ------------------------------------------------------------------------ */
+typedef struct xrit_synth_params {
+    double   fs_in, symbol_rate, alpha, amplitude, carrier_hz, phase0, timing_offset, clock_ppm;
+    double   esn0_db;     /* < -900: no noise */
+    uint64_t seed;
+} xrit_synth_params;
+void xrit_synth_defaults(xrit_synth_params *p);
+int  xrit_synth_generate_device(const xrit_synth_params *p, uint64_t start, size_t n,
+                                float *d_out_interleaved, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRITDEMOD_AMD_H_ */

@@ -1,0 +1,366 @@
+"""ctypes binding of libxritdemod_amd.so (include/xritdemod_amd.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libxritdemod_amd.so")
+
+SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ = 0, 1, 2
+
+
+class XritError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"xritdemod_amd error {code}: {text}")
+        self.code = code
+
+
+class DemodConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_float), ("decimation", C.c_uint32), ("symbol_rate", C.c_uint32),
+                ("rrc_alpha", C.c_float), ("rrc_taps", C.c_int32),
+                ("agc_rate", C.c_float), ("agc_reference", C.c_float), ("agc_gain", C.c_float),
+                ("agc_max_gain", C.c_float), ("pll_alpha", C.c_float),
+                ("clock_mu", C.c_float), ("clock_alpha", C.c_float), ("clock_gain_omega", C.c_float),
+                ("clock_omega_limit", C.c_float),
+                ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
+                ("max_passes", C.c_int32), ("strict", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class DemodStats(C.Structure):
+    _fields_ = [("samples_in", C.c_uint64), ("circuit_samples", C.c_uint64), ("symbols_out", C.c_uint64),
+                ("costas_passes", C.c_int32), ("clock_passes", C.c_int32),
+                ("costas_unconverged", C.c_uint32), ("clock_unconverged", C.c_uint32),
+                ("costas_max_residual", C.c_float), ("clock_max_residual", C.c_float),
+                ("agc_serial_fallback", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("fs_in", C.c_double), ("symbol_rate", C.c_double), ("alpha", C.c_double),
+                ("amplitude", C.c_double), ("carrier_hz", C.c_double), ("phase0", C.c_double),
+                ("timing_offset", C.c_double), ("clock_ppm", C.c_double), ("esn0_db", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+# every symbol include/xritdemod_amd.h declares: (restype, argtypes)
+_vp, _sz = C.c_void_p, C.c_size_t
+_SIGNATURES = {
+    "xrit_last_error": (C.c_char_p, []),
+    "xrit_version": (C.c_char_p, []),
+    "xrit_device_count": (C.c_int, []),
+    "xrit_lowpass_taps": (C.c_int, [C.c_double] * 4 + [_vp, C.c_int]),
+    "xrit_rrc_taps": (C.c_int, [C.c_double] * 4 + [C.c_int, _vp, C.c_int]),
+    "xrit_mmse_table": (None, [_vp]),
+    "xrit_demod_config_lrit": (None, [C.POINTER(DemodConfig), C.c_float, C.c_uint32]),
+    "xrit_demod_config_hrit": (None, [C.POINTER(DemodConfig), C.c_float, C.c_uint32]),
+    "xrit_demod_create": (C.c_int, [C.POINTER(DemodConfig), C.POINTER(_vp)]),
+    "xrit_demod_destroy": (None, [_vp]),
+    "xrit_demod_process": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "xrit_demod_process_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),
+    "xrit_demod_sps": (C.c_float, [_vp]),
+    "xrit_demod_decimator_ntaps": (C.c_int, [_vp]),
+    "xrit_demod_keep_stages": (C.c_int, [_vp, C.c_int]),
+    "xrit_demod_read_stage": (C.c_int, [_vp, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "xrit_demod_get_stats": (C.c_int, [_vp, C.POINTER(DemodStats)]),
+    "xrit_demod_profile": (C.c_int, [_vp, C.c_int]),
+    "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "xrit_quantize_i8_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
+    "xrit_quantize_i8": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_fir_create": (C.c_int, [C.c_uint, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "xrit_fir_work": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_fir_destroy": (None, [_vp]),
+    "xrit_agc_create": (C.c_int, [C.c_float] * 4 + [C.c_int, C.POINTER(_vp)]),
+    "xrit_agc_work": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_agc_gain": (C.c_float, [_vp]),
+    "xrit_agc_destroy": (None, [_vp]),
+    "xrit_costas_create": (C.c_int, [C.c_float, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "xrit_costas_work": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_costas_state": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "xrit_costas_destroy": (None, [_vp]),
+    "xrit_clock_create": (C.c_int, [C.c_float] * 5 + [C.c_int, C.POINTER(_vp)]),
+    "xrit_clock_work": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "xrit_clock_destroy": (None, [_vp]),
+    "xrit_synth_defaults": (None, [C.POINTER(SynthParams)]),
+    "xrit_synth_generate_device": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, _sz, _vp, C.c_int, _vp]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False):
+    """Compile libxritdemod_amd.so for gfx950 with hipcc (csrc/Makefile)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+def lib():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise XritError(-2, f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the HIP extension is required; there is no CPU path)")
+        L = C.CDLL(_LIB)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise XritError(rc, lib().xrit_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().xrit_device_count()
+
+
+def version():
+    return lib().xrit_version().decode()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+class Filters:
+    """SatHelper::Filters (demodulator.cpp:443-444)."""
+
+    @staticmethod
+    def RRC(gain, sample_rate, symbol_rate, alpha, ntaps):
+        t = np.zeros(ntaps | 1, np.float32)
+        n = lib().xrit_rrc_taps(gain, sample_rate, symbol_rate, alpha, ntaps, _p(t), len(t))
+        assert n == len(t)
+        return t
+
+    @staticmethod
+    def lowPass(gain, sample_rate, cutoff, transition_width, window="HAMMING", beta=6.76):
+        if window != "HAMMING":
+            raise ValueError("the reference only uses FFTWindows::HAMMING (demodulator.cpp:444)")
+        n = -lib().xrit_lowpass_taps(gain, sample_rate, cutoff, transition_width, None, 0)
+        t = np.zeros(n, np.float32)
+        assert lib().xrit_lowpass_taps(gain, sample_rate, cutoff, transition_width, _p(t), n) == n
+        return t
+
+    @staticmethod
+    def mmse_table():
+        t = np.zeros((129, 8), np.float32)
+        lib().xrit_mmse_table(_p(t))
+        return t
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            getattr(lib(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FirFilter(_Handle):
+    """SatHelper::FirFilter(decimation, taps); Work(in, out, nOut)."""
+    _destroy = "xrit_fir_destroy"
+
+    def __init__(self, decimation, taps, device=0):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, np.float32)
+        self.D = int(decimation)
+        _check(lib().xrit_fir_create(self.D, _p(taps), len(taps), device, C.byref(self._h)))
+
+    def Work(self, x, n_out):
+        x = _c64(x)
+        assert len(x) >= n_out * self.D
+        out = np.zeros(n_out, np.complex64)
+        _check(lib().xrit_fir_work(self._h, _p(x), _p(out), n_out))
+        return out
+
+
+class AGC(_Handle):
+    """SatHelper::AGC(rate, reference, gain, maxGain); Work(in, out, n)."""
+    _destroy = "xrit_agc_destroy"
+
+    def __init__(self, rate, reference, gain, max_gain, device=0):
+        super().__init__()
+        _check(lib().xrit_agc_create(rate, reference, gain, max_gain, device, C.byref(self._h)))
+
+    def Work(self, x):
+        x = _c64(x)
+        out = np.zeros(len(x), np.complex64)
+        _check(lib().xrit_agc_work(self._h, _p(x), _p(out), len(x)))
+        return out
+
+    @property
+    def gain(self):
+        return lib().xrit_agc_gain(self._h)
+
+
+class CostasLoop(_Handle):
+    """SatHelper::CostasLoop(loopBw, order); Work(in, out, n)."""
+    _destroy = "xrit_costas_destroy"
+
+    def __init__(self, loop_bw, order=2, device=0):
+        super().__init__()
+        _check(lib().xrit_costas_create(loop_bw, order, device, C.byref(self._h)))
+
+    def Work(self, x):
+        x = _c64(x)
+        out = np.zeros(len(x), np.complex64)
+        _check(lib().xrit_costas_work(self._h, _p(x), _p(out), len(x)))
+        return out
+
+    def state(self):
+        ph, fr = C.c_float(), C.c_float()
+        _check(lib().xrit_costas_state(self._h, C.byref(ph), C.byref(fr)))
+        return ph.value, fr.value
+
+
+class ClockRecovery(_Handle):
+    """SatHelper::ClockRecovery(omega, gainOmega, mu, gainMu, omegaRelativeLimit); Work(in, out, n) -> symbols."""
+    _destroy = "xrit_clock_destroy"
+
+    def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit, device=0):
+        super().__init__()
+        _check(lib().xrit_clock_create(omega, gain_omega, mu, gain_mu, omega_rel_limit, device, C.byref(self._h)))
+
+    def Work(self, x):
+        x = _c64(x)
+        cap = len(x) + 64
+        out = np.zeros(cap, np.complex64)
+        n = C.c_size_t(0)
+        _check(lib().xrit_clock_work(self._h, _p(x), len(x), _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+
+class Demodulator(_Handle):
+    """The chain of processSamples() (demodulator.cpp:100-168) behind one handle."""
+    _destroy = "xrit_demod_destroy"
+    STAGES = ("decimator", "agc", "rrc", "costas", "clock")
+
+    @staticmethod
+    def config(mode="lrit", sample_rate=1.25e6, decimation=1, device=0, **over):
+        c = DemodConfig()
+        if mode == "lrit":
+            lib().xrit_demod_config_lrit(C.byref(c), sample_rate, decimation)
+        elif mode == "hrit":
+            lib().xrit_demod_config_hrit(C.byref(c), sample_rate, decimation)
+        else:
+            raise ValueError(mode)
+        c.device = device
+        for k, v in over.items():
+            setattr(c, k, v)
+        return c
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        _check(lib().xrit_demod_create(C.byref(cfg), C.byref(self._h)))
+
+    @property
+    def sps(self):
+        return lib().xrit_demod_sps(self._h)
+
+    @property
+    def decimator_ntaps(self):
+        return lib().xrit_demod_decimator_ntaps(self._h)
+
+    def keep_stages(self, enable=True):
+        _check(lib().xrit_demod_keep_stages(self._h, int(enable)))
+
+    def process(self, samples, sample_type=SAMPLE_FLOATIQ):
+        """Host buffers in, host soft symbols out."""
+        if sample_type == SAMPLE_FLOATIQ:
+            a = _c64(samples)
+            n = len(a)
+        elif sample_type == SAMPLE_S16IQ:
+            a = np.ascontiguousarray(samples, np.int16)
+            n = len(a) // 2
+        else:
+            a = np.ascontiguousarray(samples, np.int8)
+            n = len(a) // 2
+        cap = n + 64
+        out = np.zeros(cap, np.float32)
+        n_out = C.c_size_t(0)
+        _check(lib().xrit_demod_process(self._h, _p(a), n, sample_type, _p(out), cap, C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    def process_device(self, d_samples_ptr, n, d_soft_ptr, cap, sample_type=SAMPLE_FLOATIQ, stream=None):
+        """Device pointers (ints) in and out; returns the symbol count."""
+        n_out = C.c_size_t(0)
+        _check(lib().xrit_demod_process_device(self._h, C.c_void_p(d_samples_ptr), n, sample_type,
+                                               C.c_void_p(d_soft_ptr), cap, C.byref(n_out),
+                                               C.c_void_p(stream) if stream else None))
+        return n_out.value
+
+    def stage(self, name):
+        idx = self.STAGES.index(name)
+        n = C.c_size_t(0)
+        _check(lib().xrit_demod_read_stage(self._h, idx, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.complex64)
+        if n.value:
+            _check(lib().xrit_demod_read_stage(self._h, idx, _p(out), n.value, C.byref(n)))
+        return out
+
+    def stats(self):
+        s = DemodStats()
+        _check(lib().xrit_demod_get_stats(self._h, C.byref(s)))
+        return s
+
+    def profile(self, enable=True):
+        _check(lib().xrit_demod_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (C.c_int * cap)()
+        n = lib().xrit_demod_profile_read(self._h, names, ms, cnt, cap)
+        return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
+
+    def quantize_i8(self, soft):
+        soft = np.ascontiguousarray(soft, np.float32)
+        out = np.zeros(len(soft), np.int8)
+        _check(lib().xrit_quantize_i8(self._h, _p(soft), _p(out), len(soft)))
+        return out
+
+
+def synth_generate_device(params, start, n, d_out_ptr, device=0, stream=None):
+    _check(lib().xrit_synth_generate_device(C.byref(params), start, n, C.c_void_p(d_out_ptr), device,
+                                            C.c_void_p(stream) if stream else None))
+
+
+def synth_params(**over):
+    p = SynthParams()
+    lib().xrit_synth_defaults(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def quantize_i8_device(d_soft_ptr, d_out_ptr, n, device=0, stream=None):
+    _check(lib().xrit_quantize_i8_device(C.c_void_p(d_soft_ptr), C.c_void_p(d_out_ptr), n, device,
+                                         C.c_void_p(stream) if stream else None))

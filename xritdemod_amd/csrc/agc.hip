@@ -1,0 +1,136 @@
+// agc.hip -- automatic gain control as an exact parallel scan.
+// Replaces SatHelper::AGC::Work (/root/reference/demodulator/src/demodulator.cpp:143,
+// object built at :447 with Parameters.h:34-37): y = x*g; g += rate*(ref - |y|);
+// g = min(g, max).  For g > 0 one step is the map g -> min(a g + b, c) with
+// a = 1 - rate*|x| >= 0, and such maps compose associatively, so block-start
+// gains come from a prefix scan; inside its own 4-sample run every lane replays
+// the recurrence literally.  A sample with rate*|x| > 1 (a < 0) breaks
+// monotonicity: it raises a guard flag and a single-lane kernel redoes the call
+// serially (never seen with normalised SDR samples; kept for exactness).
+#include "kernels.h"
+#include "scan.h"
+
+namespace xrit {
+
+struct AgcScanF {
+    typedef AgcMap T;
+    const float2 *x;
+    float2 *y;
+    const float *state_in;   // [0] gain
+    float *state_out;        // [0] gain after the call, [1] guard flag
+    float rate, ref, maxg;
+    long long n;
+
+    __device__ T identity() const { return agc_identity(); }
+    __device__ T combine(const T &lo, const T &hi) const { return agc_compose(lo, hi); }
+    __device__ T reduce_run(long long i0, int cnt) const
+    {
+        T m = agc_identity();
+        bool bad = false;
+        for (int k = 0; k < cnt; ++k) {
+            float2 v = x[i0 + k];
+            T e = agc_sample_map(v.x, v.y, rate, ref, maxg);
+            bad |= !(e.a >= 0.0f);
+            m = agc_compose(m, e);
+        }
+        if (bad) state_out[1] = 1.0f;
+        return m;
+    }
+    __device__ void apply_run(long long i0, int cnt, const T &pre) const
+    {
+        float g = agc_apply(pre, state_in[0]);
+        for (int k = 0; k < cnt; ++k) {
+            float2 v = x[i0 + k];
+            float yr, yi;
+            agc_step(v.x, v.y, g, rate, ref, maxg, yr, yi);
+            y[i0 + k] = make_float2(yr, yi);
+        }
+        if (i0 + cnt == n) state_out[0] = g;
+    }
+};
+
+__global__ void agc_serial_kernel(const float2 *x, float2 *y, const float *state_in, float *state_out,
+                                  float rate, float ref, float maxg, long long n, int force)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (!force && state_out[1] == 0.0f) return;
+    float g = state_in[0];
+    for (long long i = 0; i < n; ++i) {
+        float2 v = x[i];
+        float yr, yi;
+        agc_step(v.x, v.y, g, rate, ref, maxg, yr, yi);
+        y[i] = make_float2(yr, yi);
+    }
+    state_out[0] = g;
+    state_out[1] = 2.0f;  // serial path taken
+}
+
+__global__ void agc_begin_kernel(float *state_out)
+{
+    state_out[1] = 0.0f;
+}
+
+int AgcStage::init(float rate_, float reference, float gain0, float max_gain)
+{
+    rate = rate_;
+    ref = reference;
+    maxg = max_gain;
+    XR_TRY(state.reserve(4 * sizeof(float)));
+    float h[4] = {gain0, 0.0f, gain0, 0.0f};   // two (gain, flag) slots, ping-pong
+    XR_HIP(hipMemcpy(state.p, h, sizeof h, hipMemcpyHostToDevice));
+    cur = 0;
+    return XRIT_OK;
+}
+
+void AgcStage::release()
+{
+    state.release();
+    aggs.release();
+    starts.release();
+}
+
+int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)
+{
+    if (n == 0) return XRIT_OK;
+    float *sin_ = state.as<float>() + 2 * cur;
+    float *sout = state.as<float>() + 2 * (cur ^ 1);
+    int nb = scan_blocks((long long)n);
+    XR_TRY(aggs.reserve((size_t)(nb + 1) * sizeof(AgcMap)));
+    AgcScanF f{in, out, sin_, sout, rate, ref, maxg, (long long)n};
+    {
+        ProfScope ps(prof, "agc_reduce", s);
+        hipLaunchKernelGGL(agc_begin_kernel, dim3(1), dim3(1), 0, s, sout);
+        hipLaunchKernelGGL(scan_reduce_kernel<AgcScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, (long long)n,
+                           aggs.as<AgcMap>());
+    }
+    {
+        ProfScope ps(prof, "agc_scan", s);
+        hipLaunchKernelGGL(scan_aggs_kernel<AgcScanF>, dim3(1), dim3(SCAN_BLOCK), 0, s, f, aggs.as<AgcMap>(), nb);
+    }
+    {
+        ProfScope ps(prof, "agc_apply", s);
+        hipLaunchKernelGGL(scan_apply_kernel<AgcScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, (long long)n,
+                           aggs.as<AgcMap>());
+        hipLaunchKernelGGL(agc_serial_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg,
+                           (long long)n, 0);
+    }
+    XR_HIP(hipGetLastError());
+    cur ^= 1;
+    return XRIT_OK;
+}
+
+int AgcStage::gain(float *g, hipStream_t s)
+{
+    XR_HIP(hipMemcpyAsync(g, state.as<float>() + 2 * cur, sizeof(float), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    return XRIT_OK;
+}
+
+int AgcStage::fallback_flag(float *flag, hipStream_t s)
+{
+    XR_HIP(hipMemcpyAsync(flag, state.as<float>() + 2 * cur + 1, sizeof(float), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    return XRIT_OK;
+}
+
+}  // namespace xrit

@@ -1,0 +1,552 @@
+// clock.hip -- Mueller & Mueller symbol-timing recovery over symbol-count chains.
+// Replaces SatHelper::ClockRecovery::Work (/root/reference/demodulator/src/
+// demodulator.cpp:156; object built at :449 with Parameters.h:30-33).  The
+// recurrence carries (read index ii, mu, omega) plus two symbols of history and
+// advances ii by floor(mu) each symbol, so the output rate is data dependent.
+//
+// Tiling: chain k produces symbols [k*NS, (k+1)*NS) -- a fixed symbol count, so
+// every chain knows where its output goes and the map "start state -> end
+// state" is smooth apart from the 1/128 interpolator-arm quantisation.  Start
+// positions are guessed from an Oerder & Meyr timing estimate (|x|^2 line at the
+// symbol rate, unwrapped over the call), then corrected by Newton steps on the
+// multiple-shooting system; the Jacobian of each chain comes from two extra
+// lanes that run the chain from (t+h_t, omega) and (t, omega+h_w).  A residual of
+// m whole symbols at a boundary is carried as a symbol slip that shifts all later
+// chains, not "corrected".  The arm quantisation makes the recurrence chaotic at
+// the 1e-5 level in mu, so the passes stop at a fixed
+// budget rather than at bitwise closure.
+#include "kernels.h"
+#include "scan.h"
+
+namespace xrit {
+
+constexpr int CLK_OM_BLOCK = 256;     // samples per timing-estimate block
+constexpr float CLK_H_T = 0.0625f;    // finite-difference steps
+constexpr float CLK_H_W = 1e-3f;
+
+struct ClockResult {
+    unsigned long long n_symbols;
+    long long ii_final;
+    int terminal_chain;
+    int ok;
+};
+
+// --------------------------------------------------------- timing estimate
+__global__ void __launch_bounds__(256) clock_om_kernel(const float2 *__restrict__ x, double2 *__restrict__ X,
+                                                       long long N, int nb, double inv_sps)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + wave;
+    if (b >= nb) return;
+    float sr = 0.f, si = 0.f;
+    for (int i = lane; i < CLK_OM_BLOCK; i += 64) {
+        long long j = b * CLK_OM_BLOCK + i;
+        if (j < N) {
+            float2 v = x[j];
+            float p = v.x * v.x + v.y * v.y;
+            double ph = (double)j * inv_sps;
+            ph -= floor(ph);
+            float sn, cs;
+            sincosf(-6.28318530717958647692f * (float)ph, &sn, &cs);
+            sr += p * cs;
+            si += p * sn;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        si += __shfl_down(si, off, 64);
+    }
+    if (lane == 0) X[b] = make_double2((double)sr, (double)si);
+}
+
+__device__ __forceinline__ double clk_wrap(double x) { return x - 2.0 * XR_PI_D * rint(x / (2.0 * XR_PI_D)); }
+
+struct ClkUnwrapF {
+    typedef double T;
+    const double2 *X;
+    double *cnt;      // out: symbol count (continuous) at block centres
+    int nb;
+    double sps;
+    __device__ T identity() const { return 0.0; }
+    __device__ T combine(const T &lo, const T &hi) const { return lo + hi; }
+    __device__ double ang(long long b) const
+    {
+        double sr = 0, si = 0;
+        for (long long q = b - 2; q <= b + 2; ++q)
+            if (q >= 0 && q < nb) { sr += X[q].x; si += X[q].y; }
+        return atan2(si, sr);
+    }
+    __device__ double diff(long long b) const
+    {
+        double cur = ang(b);
+        if (b == 0) return cur;
+        return clk_wrap(cur - ang(b - 1));
+    }
+    __device__ T reduce_run(long long i0, int n) const
+    {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s += diff(i0 + k);
+        return s;
+    }
+    __device__ void apply_run(long long i0, int n, const T &pre) const
+    {
+        double s = pre;
+        for (int k = 0; k < n; ++k) {
+            s += diff(i0 + k);
+            double cb = ((double)(i0 + k) + 0.5) * CLK_OM_BLOCK;
+            cnt[i0 + k] = (cb + s / (2.0 * XR_PI_D) * sps) / sps;
+        }
+    }
+};
+
+__device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double sps, double t)
+{
+    double fb = t / CLK_OM_BLOCK - 0.5;
+    int b = (int)floor(fb);
+    b = max(0, min(nb - 2, b));
+    if (nb < 2) return cnt[0] + (t - 0.5 * CLK_OM_BLOCK) / sps;
+    double c0 = cnt[b], c1 = cnt[b + 1];
+    return c0 + (c1 - c0) * (fb - b);
+}
+
+// start state of every chain from the unwrapped symbol-count curve
+__global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, double sps, ClockState *__restrict__ S,
+                                   const ClockState *__restrict__ carried, int K, int NS, float omega0)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    ClockState s0 = carried[0];
+    if (k == 0) { S[0] = s0; return; }
+    double t0 = (double)s0.ii + (double)s0.mu;
+    // the M&M read position t = ii+mu sits 3 samples before the interpolation instant
+    double ca = clk_count_at(cnt, nb, sps, t0) + 3.0 / sps;
+    double target = rint(ca) + (double)k * NS;
+    // invert the piecewise-linear count curve around the nominal position
+    double t = (target - cnt[0]) * sps + 0.5 * CLK_OM_BLOCK;
+    for (int it = 0; it < 4; ++it) {
+        double c = clk_count_at(cnt, nb, sps, t);
+        t += (target - c) * sps;
+    }
+    t -= 3.0;
+    if (t < 0) t = 0;
+    ClockState s;
+    s.ii = (long long)floor(t);
+    s.mu = (float)(t - floor(t));
+    s.omega = omega0;
+    s.p0 = cf32{0.f, 0.f}; s.p1 = cf32{0.f, 0.f};
+    s.c0 = cf32{0.f, 0.f}; s.c1 = cf32{0.f, 0.f};
+    S[k] = s;
+}
+
+// --------------------------------------------------------------------- pass
+// 192 threads: wave 0 = base trajectories of 64 chains, wave 1 = start shifted by
+// h_t, wave 2 = omega shifted by h_w.
+__global__ void __launch_bounds__(192) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+                                                         const ClockState *__restrict__ S, ClockState *__restrict__ E,
+                                                         float4 *__restrict__ J, int *__restrict__ dirty,
+                                                         int *__restrict__ nrun, long long ni, int K, int NS,
+                                                         ClockPar par)
+{
+    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
+    __shared__ float2 endv[2][64];
+    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) table[i] = table_g[i];
+    const int variant = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 64 + lane;
+    bool run = k < K;
+    if (run) run = dirty[k] != 0;
+    __syncthreads();
+    ClockState s{};
+    ClockState base{};
+    int produced = 0;
+    if (run) {
+        s = S[k];
+        if (variant == 1) clock_shift(s, CLK_H_T);
+        if (variant == 2) s.omega += CLK_H_W;
+        const cf32 *xp = reinterpret_cast<const cf32 *>(x);
+        for (int i = 0; i < NS; ++i) {
+            if (s.ii >= ni || s.ii < 0) break;
+            clock_step(xp, table, s, par);
+            ++produced;
+        }
+    }
+    if (variant == 0) base = s;
+    // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
+    __shared__ long long ref_ii[64];
+    if (variant == 0) ref_ii[lane] = s.ii;
+    __syncthreads();
+    if (variant > 0) endv[variant - 1][lane] = make_float2((float)(s.ii - ref_ii[lane]) + s.mu, s.omega);
+    __syncthreads();
+    if (variant == 0 && run) {
+        float2 et = endv[0][lane], ew = endv[1][lane];
+        float tb = base.mu;
+        float4 j;
+        j.x = (et.x - tb) / CLK_H_T;           // dt/dt0
+        j.y = (ew.x - tb) / CLK_H_W;           // dt/dw0
+        j.z = (et.y - base.omega) / CLK_H_T;   // dw/dt0
+        j.w = (ew.y - base.omega) / CLK_H_W;   // dw/dw0
+        E[k] = base;
+        J[k] = j;
+        nrun[k] = produced;
+        dirty[k] = 0;
+    }
+}
+
+// output pass: base trajectories only, symbols written at k*NS + i
+__global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+                                                          const ClockState *__restrict__ S, ClockState *__restrict__ E,
+                                                          int *__restrict__ counts, float *__restrict__ soft,
+                                                          float2 *__restrict__ sym, unsigned long long cap, long long ni,
+                                                          int K, int NS, ClockPar par, int *__restrict__ terminal)
+{
+    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
+    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) table[i] = table_g[i];
+    __syncthreads();
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    ClockState s = S[k];
+    const cf32 *xp = reinterpret_cast<const cf32 *>(x);
+    const unsigned long long o0 = (unsigned long long)k * NS;
+    int i = 0;
+    for (; i < NS; ++i) {
+        if (s.ii >= ni || s.ii < 0) break;
+        cf32 p = clock_step(xp, table, s, par);
+        unsigned long long o = o0 + i;
+        if (o < cap) {
+            if (soft) soft[o] = p.x;
+            if (sym) sym[o] = make_float2(p.x, p.y);
+        }
+    }
+    E[k] = s;
+    counts[k] = i;
+    if (i < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
+}
+
+// result of the call + the state and the unread tail carried to the next call
+__global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *__restrict__ E,
+                                                              const int *__restrict__ counts,
+                                                              const int *__restrict__ terminal,
+                                                              const ClockState *__restrict__ carried_in,
+                                                              ClockState *__restrict__ carried_out,
+                                                              ClockResult *__restrict__ res, float2 *__restrict__ x,
+                                                              long long N, int K, int NS)
+{
+    __shared__ long long s_ii;
+    if (threadIdx.x == 0) {
+        int k = *terminal;
+        ClockState s;
+        if (k < 0 || k >= K) {
+            // no chain reached the end of the input: the chain budget was too small
+            res->ok = 0;
+            res->n_symbols = 0;
+            res->terminal_chain = -1;
+            s = carried_in[0];
+        } else {
+            res->ok = 1;
+            res->terminal_chain = k;
+            res->n_symbols = (unsigned long long)k * NS + (unsigned long long)counts[k];
+            s = E[k];
+        }
+        long long ii = s.ii;
+        if (ii > N) ii = N;
+        if (ii < 0) ii = 0;
+        res->ii_final = ii;
+        s_ii = ii;
+        s.ii = 0;           // the carried tail starts at the read index
+        carried_out[0] = s;
+    }
+    __syncthreads();
+    const long long ii = s_ii;
+    const long long carry = N - ii;
+    float2 v = make_float2(0.f, 0.f);
+    if (threadIdx.x < carry) v = x[ii + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < carry) x[threadIdx.x] = v;
+}
+
+// ------------------------------------------------------------ hand-off solve
+struct ClockMap { float a11, a12, a21, a22, b1, b2; int slip; };
+
+struct ClockNewtonF {
+    typedef ClockMap T;
+    ClockState *S;
+    const ClockState *E;
+    const float4 *J;
+    float2 *dlin;
+    int *dirty;
+    const int *nrun;      // symbols chain k produced when it last ran
+    unsigned *counters;   // [0] changed, [1] not frozen, [2] max |r_t| bits
+    long long ni;
+    float trust_t, trust_w, tol_t, tol_w;
+    int phase;
+
+    __device__ T identity() const { return T{1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0}; }
+    __device__ T combine(const T &lo, const T &hi) const
+    {
+        T r;
+        r.a11 = hi.a11 * lo.a11 + hi.a12 * lo.a21;
+        r.a12 = hi.a11 * lo.a12 + hi.a12 * lo.a22;
+        r.a21 = hi.a21 * lo.a11 + hi.a22 * lo.a21;
+        r.a22 = hi.a21 * lo.a12 + hi.a22 * lo.a22;
+        r.b1 = hi.a11 * lo.b1 + hi.a12 * lo.b2 + hi.b1;
+        r.b2 = hi.a21 * lo.b1 + hi.a22 * lo.b2 + hi.b2;
+        r.slip = lo.slip + hi.slip;
+        return r;
+    }
+    __device__ bool active(long long k) const { return nrun[k] > 0; }
+    __device__ T element(long long k) const
+    {
+        T t = identity();
+        if (!active(k)) { t.a11 = t.a22 = 0.f; return t; }   // nothing to hand over past the end of the input
+        ClockState e = E[k], s = S[k + 1];
+        float rt = clock_tdiff(e, s);
+        float rw = e.omega - s.omega;
+        float m = rintf(rt / e.omega);
+        rt -= m * e.omega;
+        bool cut = false;
+        if (phase == 1) {
+            float2 d = dlin[k];
+            cut = !(fabsf(d.x) <= trust_t) || !(fabsf(d.y) <= trust_w);
+        }
+        float4 j = J[k];
+        if (cut || !(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 4.f * 4096.f)) { t.a11 = t.a12 = t.a21 = t.a22 = 0.f; }
+        else { t.a11 = j.x; t.a12 = j.y; t.a21 = j.z; t.a22 = j.w; }
+        t.b1 = rt; t.b2 = rw;
+        t.slip = (int)m;
+        return t;
+    }
+    __device__ T reduce_run(long long i0, int cnt) const
+    {
+        T m = identity();
+        for (int k = 0; k < cnt; ++k) m = combine(m, element(i0 + k));
+        return m;
+    }
+    __device__ void apply_run(long long i0, int cnt, const T &pre) const
+    {
+        float dt = pre.b1, dw = pre.b2;
+        int slip = pre.slip;
+        for (int q = 0; q < cnt; ++q) {
+            long long k = i0 + q;
+            T e = element(k);
+            float jt = e.a11 * dt + e.a12 * dw;
+            float jw = e.a21 * dt + e.a22 * dw;
+            float ndt = e.b1 + jt, ndw = e.b2 + jw;
+            if (phase == 0) {
+                dlin[k + 1] = make_float2(ndt, ndw);
+                if (k == 0) dlin[0] = make_float2(0.f, 0.f);
+            } else {
+                ClockState ek = E[k], old = S[k + 1];
+                bool act = active(k);
+                bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
+                                 ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
+                                 ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
+                bool frozen = act && fabsf(ndt) <= tol_t && fabsf(ndw) <= tol_w && slip == 0 && e.slip == 0 && hist_same;
+                if (!act) {
+                    // chain k produced nothing: its successor starts where it stands
+                    bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
+                    if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; atomicAdd(&counters[0], 1u); }
+                } else if (!frozen) {
+                    ClockState nw = ek;
+                    clock_shift(nw, (float)slip * ek.omega + jt);
+                    nw.omega = ek.omega + jw;
+                    if (nw.ii < 0) { nw.ii = 0; nw.mu = 0.f; }
+                    atomicAdd(&counters[1], 1u);
+                    atomicMax(&counters[2], __float_as_uint(fabsf(e.b1)));
+                    bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
+                    if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; atomicAdd(&counters[0], 1u); }
+                }
+            }
+            dt = ndt; dw = ndw;
+            slip += e.slip;
+        }
+    }
+};
+
+__global__ void clk_fill_int_kernel(int *p, int v, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
+                     int max_passes_)
+{
+    sps = omega;
+    par.omega_mid = omega;
+    par.omega_lim = omega * omega_rel_limit;
+    par.gain_omega = gain_omega;
+    par.gain_mu = gain_mu;
+    mu0 = mu;
+    NS = chain_syms > 0 ? chain_syms : 64;
+    max_passes = max_passes_ > 0 ? max_passes_ : 8;
+    std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
+    design_mmse_table(tb.data());
+    XR_TRY(table.reserve(tb.size() * sizeof(float)));
+    XR_HIP(hipMemcpy(table.p, tb.data(), tb.size() * sizeof(float), hipMemcpyHostToDevice));
+    XR_TRY(st.reserve(2 * sizeof(ClockState)));
+    ClockState s0{};
+    s0.ii = 0; s0.mu = mu; s0.omega = omega;
+    ClockState both[2] = {s0, s0};
+    XR_HIP(hipMemcpy(st.p, both, sizeof both, hipMemcpyHostToDevice));
+    XR_TRY(counters.reserve(16 * sizeof(unsigned)));
+    XR_HIP(hipHostMalloc((void **)&h_res, 64));
+    XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
+    cur = 0;
+    carry = 0;
+    return XRIT_OK;
+}
+
+void ClockStage::release()
+{
+    table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
+    work.release(); counters.release(); sym.release(); dlin.release(); flags.release();
+    if (h_res) (void)hipHostFree(h_res);
+    if (h_counters) (void)hipHostFree(h_counters);
+    h_res = nullptr;
+    h_counters = nullptr;
+}
+
+int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
+{
+    size_t need = (carry + n + 64) * sizeof(float2);
+    if (need > xbuf.bytes) {
+        DevBuf nb;
+        XR_TRY(nb.reserve(need));
+        if (carry && xbuf.p) {
+            XR_HIP(hipMemcpyAsync(nb.p, xbuf.p, carry * sizeof(float2), hipMemcpyDeviceToDevice, s));
+            XR_HIP(hipStreamSynchronize(s));
+        }
+        xbuf.release();
+        xbuf = nb;
+    }
+    *slot = xbuf.as<float2>() + carry;
+    return XRIT_OK;
+}
+
+int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s,
+                    Profiler *prof)
+{
+    passes = 0;
+    unconverged = 0;
+    max_residual = 0;
+    const long long N = (long long)(carry + n);
+    const long long ni = N - XR_MM_NTAPS - XR_MM_FUDGE;
+    const ClockState *st_in = st.as<ClockState>() + cur;
+    ClockState *st_out = st.as<ClockState>() + (cur ^ 1);
+    float2 *x = xbuf.as<float2>();
+    *n_out = 0;
+    if (ni <= 0) {
+        // not enough samples for a single symbol: everything is carried
+        carry = (size_t)N;
+        last_symbols = 0;
+        return XRIT_OK;
+    }
+    // chain budget: the slowest admissible symbol clock plus slack
+    const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
+    const int K = (int)((double)N / (min_omega * NS)) + 3;
+    const int nb = (int)((N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
+    XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
+    XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
+    XR_TRY(J.reserve((size_t)K * sizeof(float4)));
+    XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
+    XR_TRY(flags.reserve((size_t)(3 * K + 4) * sizeof(int)));
+    XR_TRY(om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))));
+    const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
+    const int nbmax = nbK > nbB ? nbK : nbB;
+    XR_TRY(work.reserve((size_t)(nbmax + 2) * sizeof(ClockMap)));
+    int *dirty = flags.as<int>();
+    int *counts = flags.as<int>() + K;
+    int *nrun = flags.as<int>() + 2 * K;
+    int *terminal = flags.as<int>() + 3 * K;
+    double2 *X = om.as<double2>();
+    double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
+    ClockResult *d_res = reinterpret_cast<ClockResult *>(counters.as<unsigned>() + 8);
+    const unsigned gridK = div_up((size_t)K, 64);
+
+    if (K > 1) {
+        {
+            ProfScope ps(prof, "clock_guess", s);
+            hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, N, nb,
+                               1.0 / (double)sps);
+            ClkUnwrapF uf{X, cnt, nb, (double)sps};
+            hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
+                               work.as<double>());
+            hipLaunchKernelGGL(scan_aggs_kernel<ClkUnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbB);
+            hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
+                               work.as<double>());
+            hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
+                               S.as<ClockState>(), st_in, K, NS, par.omega_mid);
+            hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, dirty, 1, K);
+        }
+        ClockNewtonF nf{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dlin.as<float2>(), dirty, nrun,
+                        counters.as<unsigned>(), ni, 0.75f, 0.01f, tol_t, tol_w, 0};
+        const long long nel = K - 1;
+        const int nbE = scan_blocks(nel);
+        for (int p = 0; p < max_passes; ++p) {
+            {
+                ProfScope ps(prof, "clock_pass", s);
+                hipLaunchKernelGGL(clock_pass_kernel, dim3(gridK), dim3(192), 0, s, x, table.as<float>(),
+                                   S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, ni, K, NS, par);
+            }
+            {
+                ProfScope ps(prof, "clock_solve", s);
+                XR_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned), s));
+                nf.phase = 0;
+                hipLaunchKernelGGL(scan_reduce_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
+                                   work.as<ClockMap>());
+                hipLaunchKernelGGL(scan_aggs_kernel<ClockNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
+                                   work.as<ClockMap>(), nbE);
+                hipLaunchKernelGGL(scan_apply_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
+                                   work.as<ClockMap>());
+                nf.phase = 1;
+                hipLaunchKernelGGL(scan_reduce_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
+                                   work.as<ClockMap>());
+                hipLaunchKernelGGL(scan_aggs_kernel<ClockNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
+                                   work.as<ClockMap>(), nbE);
+                hipLaunchKernelGGL(scan_apply_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
+                                   work.as<ClockMap>());
+            }
+            XR_HIP(hipMemcpyAsync(h_counters, counters.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
+            ++passes;
+            unconverged = h_counters[1];
+            uint32_t bits = h_counters[2];
+            memcpy(&max_residual, &bits, sizeof(float));
+            if (h_counters[0] == 0) { unconverged = 0; break; }
+        }
+    } else {
+        XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
+    }
+    {
+        ProfScope ps(prof, "clock_output", s);
+        hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, terminal, 0x7fffffff, 1);
+        hipLaunchKernelGGL(clock_output_kernel, dim3(gridK), dim3(64), 0, s, x, table.as<float>(), S.as<ClockState>(),
+                           E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, ni, K, NS, par,
+                           terminal);
+        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), counts, terminal,
+                           st_in, st_out, d_res, x, N, K, NS);
+    }
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(h_res, d_res, sizeof(ClockResult), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    ClockResult r;
+    memcpy(&r, h_res, sizeof r);
+    cur ^= 1;
+    if (!r.ok) {
+        set_error("clock recovery: chain budget exhausted before the end of the input");
+        return XRIT_E_INVALID;
+    }
+    carry = (size_t)(N - r.ii_final);
+    if (carry > 1024) {
+        set_error("clock recovery: carry of %zu samples exceeds the hand-over buffer", carry);
+        return XRIT_E_INVALID;
+    }
+    last_symbols = (size_t)r.n_symbols;
+    *n_out = last_symbols;
+    if (last_symbols > cap) {
+        set_error("clock recovery produced %zu symbols, capacity %zu", last_symbols, cap);
+        return XRIT_E_CAPACITY;
+    }
+    return XRIT_OK;
+}
+
+}  // namespace xrit

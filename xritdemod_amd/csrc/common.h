@@ -1,0 +1,126 @@
+// common.h -- shared host-side plumbing of libxritdemod_amd (HIP runtime helpers,
+// error text, grow-only device buffers, per-kernel HIP-event profiler).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/xritdemod_amd.h"
+
+namespace xrit {
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define XR_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ::xrit::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                    \
+            return XRIT_E_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define XR_TRY(expr)               \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != XRIT_OK) return _r; \
+    } while (0)
+
+// Grow-only device allocation, like the reference's checkAndResizeBuffers
+// (demodulator.cpp:76-92): no allocation in process() once warmed up.
+struct DevBuf {
+    void  *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return XRIT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return XRIT_E_NOMEM;
+        }
+        bytes = want;
+        return XRIT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Brackets kernel launches with HIP events on the launch stream.
+struct Profiler {
+    bool enabled = false;
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    std::map<std::string, std::pair<double, int>> acc;
+    std::vector<std::string> order;
+
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(const char *name, hipStream_t s)
+    {
+        if (!enabled) return;
+        Rec r{name, get(), get()};
+        (void)hipEventRecord(r.a, s);
+        pending.push_back(r);
+    }
+    void end(hipStream_t s)
+    {
+        if (!enabled) return;
+        (void)hipEventRecord(pending.back().b, s);
+    }
+    // call after the stream has been synchronised
+    void collect()
+    {
+        for (auto &r : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                auto it = acc.find(r.name);
+                if (it == acc.end()) { acc[r.name] = {ms, 1}; order.push_back(r.name); }
+                else { it->second.first += ms; it->second.second += 1; }
+            }
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    void reset() { acc.clear(); order.clear(); }
+    ~Profiler()
+    {
+        for (auto &r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+struct ProfScope {
+    Profiler *p; hipStream_t s;
+    ProfScope(Profiler *p_, const char *name, hipStream_t s_) : p(p_), s(s_) { if (p) p->begin(name, s); }
+    ~ProfScope() { if (p) p->end(s); }
+};
+
+static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace xrit

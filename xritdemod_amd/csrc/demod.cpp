@@ -1,0 +1,517 @@
+// demod.cpp -- the chain object and the C ABI (include/xritdemod_amd.h).
+// Stage order, buffer hand-over and parameter defaults follow
+// /root/reference/demodulator/src/demodulator.cpp:100-168 (processSamples) and
+// :436-450 (construction); constants from Parameters.h:16-37.
+#include "kernels.h"
+
+#include <cmath>
+#include <new>
+
+namespace xrit {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+static int select_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no usable HIP device (%s); this library has no CPU path",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return XRIT_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (0..%d)", device, count - 1);
+        return XRIT_E_INVALID;
+    }
+    XR_HIP(hipSetDevice(device));
+    return XRIT_OK;
+}
+
+}  // namespace xrit
+
+using namespace xrit;
+
+struct xrit_demod {
+    xrit_demod_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float sps = 0, circuit_rate = 0;
+    int dec_ntaps = 0;
+    FirStage dec, rrc;
+    AgcStage agc;
+    CostasStage costas;
+    ClockStage clock;
+    DevBuf bufA, bufB, in_dev, soft_dev, q_in, q_out;
+    bool keep_stages = false;
+    DevBuf stage_buf[5];
+    size_t stage_n[5] = {0, 0, 0, 0, 0};
+    Profiler prof;
+    xrit_demod_stats stats{};
+    std::vector<std::string> prof_names;
+};
+
+struct xrit_fir { int device; hipStream_t stream; FirStage st; DevBuf in, out; };
+struct xrit_agc { int device; hipStream_t stream; AgcStage st; DevBuf in, out; };
+struct xrit_costas { int device; hipStream_t stream; CostasStage st; DevBuf in, out; };
+struct xrit_clock { int device; hipStream_t stream; ClockStage st; DevBuf in, out; };
+
+template <typename H> static int stage_open(H *h, int device)
+{
+    XR_TRY(select_device(device));
+    h->device = device;
+    XR_HIP(hipStreamCreate(&h->stream));
+    return XRIT_OK;
+}
+template <typename H> static void stage_close(H *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); }
+    h->st.release();
+    h->in.release();
+    h->out.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+
+extern "C" {
+
+const char *xrit_last_error(void) { return get_error(); }
+const char *xrit_version(void) { return "xritdemod_amd 0.1 (gfx950)"; }
+
+int xrit_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int xrit_lowpass_taps(double gain, double sample_rate, double cutoff, double transition_width, float *taps, int cap)
+{
+    std::vector<float> h = design_lowpass(gain, sample_rate, cutoff, transition_width);
+    if ((int)h.size() > cap || !taps) return -(int)h.size();
+    memcpy(taps, h.data(), h.size() * sizeof(float));
+    return (int)h.size();
+}
+
+int xrit_rrc_taps(double gain, double sample_rate, double symbol_rate, double alpha, int ntaps, float *taps, int cap)
+{
+    std::vector<float> h = design_rrc(gain, sample_rate, symbol_rate, alpha, ntaps);
+    if ((int)h.size() > cap || !taps) return -(int)h.size();
+    memcpy(taps, h.data(), h.size() * sizeof(float));
+    return (int)h.size();
+}
+
+void xrit_mmse_table(float *table) { design_mmse_table(table); }
+
+static void config_common(xrit_demod_config *c, float sample_rate, uint32_t decimation)
+{
+    memset(c, 0, sizeof *c);
+    c->sample_rate = sample_rate;
+    c->decimation = decimation ? decimation : 1;
+    c->rrc_taps = 63;                                  // RRC_TAPS
+    c->agc_rate = 0.01f;                               // AGC_RATE
+    c->agc_reference = 0.5f;                           // AGC_REFERENCE
+    c->agc_gain = 1.f;                                 // AGC_GAIN
+    c->agc_max_gain = 4000;                            // AGC_MAX_GAIN
+    c->pll_alpha = 0.0037f;                            // (float)CLOCK_ALPHA, demodulator.cpp:220
+    c->clock_mu = 0.5f;                                // CLOCK_MU
+    c->clock_alpha = 0.0037f;                          // CLOCK_ALPHA
+    c->clock_gain_omega = (0.0037f * 0.0037f) / 4.0f;  // CLOCK_GAIN_OMEGA
+    c->clock_omega_limit = 0.005f;                     // CLOCK_OMEGA_LIMIT
+}
+
+void xrit_demod_config_lrit(xrit_demod_config *c, float sample_rate, uint32_t decimation)
+{
+    config_common(c, sample_rate, decimation);
+    c->symbol_rate = 293883;   // LRIT_SYMBOL_RATE
+    c->rrc_alpha = 0.5f;       // LRIT_RRC_ALPHA
+}
+
+void xrit_demod_config_hrit(xrit_demod_config *c, float sample_rate, uint32_t decimation)
+{
+    config_common(c, sample_rate, decimation);
+    c->symbol_rate = 927000;   // HRIT_SYMBOL_RATE
+    c->rrc_alpha = 0.3f;       // HRIT_RRC_ALPHA
+}
+
+int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
+{
+    if (!cfg || !out) { set_error("null argument"); return XRIT_E_INVALID; }
+    *out = nullptr;
+    if (cfg->decimation < 1 || cfg->symbol_rate == 0 || !(cfg->sample_rate > 0) || cfg->rrc_taps < 1) {
+        set_error("invalid configuration");
+        return XRIT_E_INVALID;
+    }
+    XR_TRY(select_device(cfg->device));
+    xrit_demod *d = new (std::nothrow) xrit_demod();
+    if (!d) return XRIT_E_NOMEM;
+    d->cfg = *cfg;
+    d->device = cfg->device;
+    // demodulator.cpp:436-437 (float arithmetic as written there)
+    d->circuit_rate = cfg->sample_rate / ((float)cfg->decimation);
+    d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
+    int rc = XRIT_OK;
+    do {
+        if (hipStreamCreate(&d->stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+        std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
+        std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
+        d->dec_ntaps = (int)lp.size();
+        if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
+        if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
+        if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
+        if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
+                                cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
+        if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
+    } while (0);
+    if (rc != XRIT_OK) { xrit_demod_destroy(d); return rc; }
+    *out = d;
+    return XRIT_OK;
+}
+
+void xrit_demod_destroy(xrit_demod *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
+    d->bufA.release(); d->bufB.release(); d->in_dev.release(); d->soft_dev.release();
+    d->q_in.release(); d->q_out.release();
+    for (auto &b : d->stage_buf) b.release();
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+float xrit_demod_sps(const xrit_demod *d) { return d ? d->sps : 0.f; }
+int xrit_demod_decimator_ntaps(const xrit_demod *d) { return d ? d->dec_ntaps : 0; }
+
+static int keep_stage(xrit_demod *d, int idx, const void *src, size_t n, hipStream_t s)
+{
+    if (!d->keep_stages) return XRIT_OK;
+    XR_TRY(d->stage_buf[idx].reserve((n + 1) * sizeof(float2)));
+    if (n) XR_HIP(hipMemcpyAsync(d->stage_buf[idx].p, src, n * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    d->stage_n[idx] = n;
+    return XRIT_OK;
+}
+
+int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, int type, float *d_soft, size_t cap,
+                              size_t *n_out, void *stream)
+{
+    if (!d || !n_out || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    *n_out = 0;
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    const unsigned D = d->cfg.decimation;
+    size_t length = n;
+    const float2 *cur = nullptr;
+    if (D > 1) length = n / D;   // demodulator.cpp:137 -- the remainder of the chunk is dropped
+    XR_TRY(d->bufA.reserve((length + 8) * sizeof(float2)));
+    XR_TRY(d->bufB.reserve((length + 8) * sizeof(float2)));
+    float2 *A = d->bufA.as<float2>(), *B = d->bufB.as<float2>();
+    if (D > 1) {
+        XR_TRY(d->dec.run(d_samples, type, A, length, s, prof));   // :138
+        cur = A;
+    } else if (type != XRIT_SAMPLE_FLOATIQ) {
+        ProfScope ps(prof, "convert", s);
+        XR_TRY(launch_convert(d_samples, type, A, length, s));     // :57-70
+        cur = A;
+    } else {
+        cur = reinterpret_cast<const float2 *>(d_samples);
+    }
+    XR_TRY(keep_stage(d, 0, cur, length, s));
+    XR_TRY(d->agc.run(cur, B, length, s, prof));                   // :143
+    XR_TRY(keep_stage(d, 1, B, length, s));
+    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof)); // :148
+    XR_TRY(keep_stage(d, 2, A, length, s));
+    float2 *slot = nullptr;
+    XR_TRY(d->clock.input_slot(length, &slot, s));
+    XR_TRY(d->costas.run(A, slot, length, s, prof));               // :152
+    XR_TRY(keep_stage(d, 3, slot, length, s));
+    float2 *sym = nullptr;
+    if (d->keep_stages) {
+        XR_TRY(d->stage_buf[4].reserve((cap + 1) * sizeof(float2)));
+        sym = d->stage_buf[4].as<float2>();
+    }
+    size_t nsym = 0;
+    int rc = d->clock.run(length, d_soft, sym, cap, &nsym, s, prof);  // :156, SymbolManager.cpp:104
+    if (prof) d->prof.collect();
+    d->stage_n[4] = nsym;
+    d->stats.samples_in = n;
+    d->stats.circuit_samples = length;
+    d->stats.symbols_out = nsym;
+    d->stats.costas_passes = d->costas.passes;
+    d->stats.clock_passes = d->clock.passes;
+    d->stats.costas_unconverged = d->costas.unconverged;
+    d->stats.clock_unconverged = d->clock.unconverged;
+    d->stats.costas_max_residual = d->costas.max_residual;
+    d->stats.clock_max_residual = d->clock.max_residual;
+    *n_out = nsym;
+    if (rc != XRIT_OK) return rc;
+    if (d->cfg.strict && d->costas.unconverged) {
+        set_error("Costas hand-off did not close: %u boundaries above tolerance", d->costas.unconverged);
+        return XRIT_E_NOT_CONVERGED;
+    }
+    return XRIT_OK;
+}
+
+int xrit_demod_process(xrit_demod *d, const void *samples, size_t n, int type, float *soft_out, size_t cap,
+                       size_t *n_out)
+{
+    if (!d || !n_out || (n && !samples) || (cap && !soft_out)) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    const size_t esz = type == XRIT_SAMPLE_FLOATIQ ? 8 : (type == XRIT_SAMPLE_S16IQ ? 4 : 2);
+    XR_TRY(d->in_dev.reserve(n * esz + 16));
+    XR_TRY(d->soft_dev.reserve((cap + 1) * sizeof(float)));
+    if (n) XR_HIP(hipMemcpyAsync(d->in_dev.p, samples, n * esz, hipMemcpyHostToDevice, d->stream));
+    int rc = xrit_demod_process_device(d, d->in_dev.p, n, type, d->soft_dev.as<float>(), cap, n_out, d->stream);
+    if (rc != XRIT_OK) return rc;
+    if (*n_out)
+        XR_HIP(hipMemcpyAsync(soft_out, d->soft_dev.p, *n_out * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    XR_HIP(hipStreamSynchronize(d->stream));
+    return XRIT_OK;
+}
+
+int xrit_demod_read_stage(xrit_demod *d, int stage, float *out, size_t cap, size_t *n)
+{
+    if (!d || stage < 0 || stage > 4 || !n) { set_error("bad argument"); return XRIT_E_INVALID; }
+    if (!d->keep_stages) { set_error("stage copies are off: call xrit_demod_keep_stages(d, 1) first"); return XRIT_E_INVALID; }
+    *n = d->stage_n[stage];
+    if (!out) return XRIT_OK;
+    if (*n > cap) { set_error("stage %d holds %zu elements, capacity %zu", stage, *n, cap); return XRIT_E_CAPACITY; }
+    XR_HIP(hipSetDevice(d->device));
+    XR_HIP(hipStreamSynchronize(d->stream));
+    if (*n) XR_HIP(hipMemcpy(out, d->stage_buf[stage].p, *n * sizeof(float2), hipMemcpyDeviceToHost));
+    return XRIT_OK;
+}
+
+int xrit_demod_keep_stages(xrit_demod *d, int enable)
+{
+    if (!d) return XRIT_E_INVALID;
+    d->keep_stages = enable != 0;
+    return XRIT_OK;
+}
+
+int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s)
+{
+    if (!d || !s) return XRIT_E_INVALID;
+    *s = d->stats;
+    return XRIT_OK;
+}
+
+int xrit_demod_profile(xrit_demod *d, int enable)
+{
+    if (!d) return XRIT_E_INVALID;
+    d->prof.enabled = enable != 0;
+    d->prof.reset();
+    return XRIT_OK;
+}
+
+int xrit_demod_profile_read(xrit_demod *d, const char **names, float *total_ms, int *launches, int cap)
+{
+    if (!d) return XRIT_E_INVALID;
+    d->prof_names = d->prof.order;
+    int n = 0;
+    for (auto &nm : d->prof_names) {
+        if (n >= cap) break;
+        auto &v = d->prof.acc[nm];
+        if (names) names[n] = nm.c_str();
+        if (total_ms) total_ms[n] = (float)v.first;
+        if (launches) launches[n] = v.second;
+        ++n;
+    }
+    return n;
+}
+
+int xrit_quantize_i8_device(const float *d_soft, int8_t *d_out, size_t n, int device, void *stream)
+{
+    XR_TRY(select_device(device));
+    return launch_quantize_i8(d_soft, d_out, n, (hipStream_t)stream);
+}
+
+int xrit_quantize_i8(xrit_demod *d, const float *soft, int8_t *out, size_t n)
+{
+    if (!d || (n && (!soft || !out))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    XR_TRY(d->q_in.reserve(n * sizeof(float) + 16));
+    XR_TRY(d->q_out.reserve(n + 16));
+    if (!n) return XRIT_OK;
+    XR_HIP(hipMemcpyAsync(d->q_in.p, soft, n * sizeof(float), hipMemcpyHostToDevice, d->stream));
+    XR_TRY(launch_quantize_i8(d->q_in.as<float>(), d->q_out.as<int8_t>(), n, d->stream));
+    XR_HIP(hipMemcpyAsync(out, d->q_out.p, n, hipMemcpyDeviceToHost, d->stream));
+    XR_HIP(hipStreamSynchronize(d->stream));
+    return XRIT_OK;
+}
+
+// ---------------------------------------------------------------- stage objects
+int xrit_fir_create(unsigned decimation, const float *taps, int ntaps, int device, xrit_fir **out)
+{
+    if (!taps || ntaps < 1 || !out) { set_error("bad argument"); return XRIT_E_INVALID; }
+    xrit_fir *f = new (std::nothrow) xrit_fir();
+    if (!f) return XRIT_E_NOMEM;
+    f->stream = nullptr;
+    int rc = stage_open(f, device);
+    if (rc == XRIT_OK) rc = f->st.init(taps, ntaps, (int)decimation);
+    if (rc != XRIT_OK) { stage_close(f); return rc; }
+    *out = f;
+    return XRIT_OK;
+}
+
+int xrit_fir_work(xrit_fir *f, const float *in, float *out, size_t n_out)
+{
+    if (!f || (n_out && (!in || !out))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(f->device));
+    size_t n_in = n_out * (size_t)f->st.D;
+    XR_TRY(f->in.reserve((n_in + 8) * sizeof(float2)));
+    XR_TRY(f->out.reserve((n_out + 8) * sizeof(float2)));
+    if (n_in) XR_HIP(hipMemcpyAsync(f->in.p, in, n_in * sizeof(float2), hipMemcpyHostToDevice, f->stream));
+    XR_TRY(f->st.run(f->in.p, XRIT_SAMPLE_FLOATIQ, f->out.as<float2>(), n_out, f->stream, nullptr));
+    if (n_out) XR_HIP(hipMemcpyAsync(out, f->out.p, n_out * sizeof(float2), hipMemcpyDeviceToHost, f->stream));
+    XR_HIP(hipStreamSynchronize(f->stream));
+    return XRIT_OK;
+}
+
+void xrit_fir_destroy(xrit_fir *f) { stage_close(f); }
+
+int xrit_agc_create(float rate, float reference, float gain, float max_gain, int device, xrit_agc **out)
+{
+    if (!out) return XRIT_E_INVALID;
+    xrit_agc *a = new (std::nothrow) xrit_agc();
+    if (!a) return XRIT_E_NOMEM;
+    a->stream = nullptr;
+    int rc = stage_open(a, device);
+    if (rc == XRIT_OK) rc = a->st.init(rate, reference, gain, max_gain);
+    if (rc != XRIT_OK) { stage_close(a); return rc; }
+    *out = a;
+    return XRIT_OK;
+}
+
+int xrit_agc_work(xrit_agc *a, const float *in, float *out, size_t n)
+{
+    if (!a || (n && (!in || !out))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(a->device));
+    XR_TRY(a->in.reserve((n + 8) * sizeof(float2)));
+    XR_TRY(a->out.reserve((n + 8) * sizeof(float2)));
+    if (n) XR_HIP(hipMemcpyAsync(a->in.p, in, n * sizeof(float2), hipMemcpyHostToDevice, a->stream));
+    XR_TRY(a->st.run(a->in.as<float2>(), a->out.as<float2>(), n, a->stream, nullptr));
+    if (n) XR_HIP(hipMemcpyAsync(out, a->out.p, n * sizeof(float2), hipMemcpyDeviceToHost, a->stream));
+    XR_HIP(hipStreamSynchronize(a->stream));
+    return XRIT_OK;
+}
+
+float xrit_agc_gain(xrit_agc *a)
+{
+    float g = NAN;
+    if (!a) return g;
+    (void)hipSetDevice(a->device);
+    (void)a->st.gain(&g, a->stream);
+    return g;
+}
+
+void xrit_agc_destroy(xrit_agc *a) { stage_close(a); }
+
+int xrit_costas_create(float loop_bw, int order, int device, xrit_costas **out)
+{
+    if (!out) return XRIT_E_INVALID;
+    if (order != 2) { set_error("only the 2nd-order (BPSK) loop is implemented, as the reference uses (LOOP_ORDER 2)"); return XRIT_E_INVALID; }
+    xrit_costas *c = new (std::nothrow) xrit_costas();
+    if (!c) return XRIT_E_NOMEM;
+    c->stream = nullptr;
+    int rc = stage_open(c, device);
+    if (rc == XRIT_OK) rc = c->st.init(loop_bw, 0, 0);
+    if (rc != XRIT_OK) { stage_close(c); return rc; }
+    *out = c;
+    return XRIT_OK;
+}
+
+int xrit_costas_work(xrit_costas *c, const float *in, float *out, size_t n)
+{
+    if (!c || (n && (!in || !out))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(c->device));
+    XR_TRY(c->in.reserve((n + 8) * sizeof(float2)));
+    XR_TRY(c->out.reserve((n + 8) * sizeof(float2)));
+    if (n) XR_HIP(hipMemcpyAsync(c->in.p, in, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    XR_TRY(c->st.run(c->in.as<float2>(), c->out.as<float2>(), n, c->stream, nullptr));
+    if (n) XR_HIP(hipMemcpyAsync(out, c->out.p, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRIT_OK;
+}
+
+int xrit_costas_state(xrit_costas *c, float *phase, float *freq)
+{
+    if (!c || !phase || !freq) return XRIT_E_INVALID;
+    XR_HIP(hipSetDevice(c->device));
+    return c->st.get_state(phase, freq, c->stream);
+}
+
+void xrit_costas_destroy(xrit_costas *c) { stage_close(c); }
+
+int xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int device,
+                      xrit_clock **out)
+{
+    if (!out || !(omega >= 1.0f)) { set_error("bad argument"); return XRIT_E_INVALID; }
+    xrit_clock *c = new (std::nothrow) xrit_clock();
+    if (!c) return XRIT_E_NOMEM;
+    c->stream = nullptr;
+    int rc = stage_open(c, device);
+    if (rc == XRIT_OK) rc = c->st.init(omega, gain_omega, mu, gain_mu, omega_rel_limit, 0, 0);
+    if (rc != XRIT_OK) { stage_close(c); return rc; }
+    *out = c;
+    return XRIT_OK;
+}
+
+int xrit_clock_work(xrit_clock *c, const float *in, size_t n, float *out, size_t cap, size_t *n_out)
+{
+    if (!c || !n_out || (n && !in)) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(c->device));
+    float2 *slot = nullptr;
+    XR_TRY(c->st.input_slot(n, &slot, c->stream));
+    if (n) XR_HIP(hipMemcpyAsync(slot, in, n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    XR_TRY(c->out.reserve((cap + 8) * sizeof(float2)));
+    XR_TRY(c->st.run(n, nullptr, c->out.as<float2>(), cap, n_out, c->stream, nullptr));
+    if (*n_out && out)
+        XR_HIP(hipMemcpyAsync(out, c->out.p, *n_out * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRIT_OK;
+}
+
+void xrit_clock_destroy(xrit_clock *c) { stage_close(c); }
+
+// ---------------------------------------------------------------- synth
+void xrit_synth_defaults(xrit_synth_params *p)
+{
+    if (!p) return;
+    p->fs_in = 1.25e6;
+    p->symbol_rate = 293883.0;
+    p->alpha = 0.5;
+    p->amplitude = 0.1;
+    p->carrier_hz = 500.0;
+    p->phase0 = 0.7;
+    p->timing_offset = 0.3;
+    p->clock_ppm = 20.0;
+    p->esn0_db = 12.0;
+    p->seed = 0x58524954ull;
+}
+
+int xrit_synth_generate_device(const xrit_synth_params *p, uint64_t start, size_t n, float *d_out, int device,
+                               void *stream)
+{
+    if (!p || (n && !d_out)) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    return launch_synth(*p, start, n, reinterpret_cast<float2 *>(d_out), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// fir.hip -- decimating FIR, complex samples x real taps.
+// Replaces SatHelper::FirFilter::Work as called at
+// /root/reference/demodulator/src/demodulator.cpp:138 (decimating low-pass) and
+// :148 (63-tap RRC, decimation 1):  y[m] = sum_k h[k] x[m*D - k], T-1 samples of
+// history kept across calls.  The ingest conversion of demodulator.cpp:54-74
+// (s16 -> /32768.f, s8 -> /128.f) is fused into the tile load.
+//
+// Layout: one workgroup stages a contiguous window of the input in LDS (coalesced
+// 8-byte loads); every lane then produces RC consecutive outputs, walking its
+// window once and feeding each sample to RC accumulators, so an LDS read is
+// amortised over RC complex MACs.  The taps a lane needs at step i are the same
+// for all lanes (wave-uniform), so they come through the scalar cache as SGPR
+// operands.  RC*D odd gives a conflict-free ds_read_b64 lane stride; for even
+// strides the LDS image is skewed by one sample per D (PAD).
+#include "kernels.h"
+
+namespace xrit {
+
+template <int TYPE> struct SampleLoad;
+template <> struct SampleLoad<XRIT_SAMPLE_FLOATIQ> {
+    static __device__ __forceinline__ float2 at(const void *p, size_t j) { return reinterpret_cast<const float2 *>(p)[j]; }
+};
+template <> struct SampleLoad<XRIT_SAMPLE_S16IQ> {
+    static __device__ __forceinline__ float2 at(const void *p, size_t j)
+    {
+        short2 v = reinterpret_cast<const short2 *>(p)[j];
+        return make_float2(v.x / 32768.f, v.y / 32768.f);
+    }
+};
+template <> struct SampleLoad<XRIT_SAMPLE_S8IQ> {
+    static __device__ __forceinline__ float2 at(const void *p, size_t j)
+    {
+        char2 v = reinterpret_cast<const char2 *>(p)[j];
+        return make_float2(v.x / 128.f, v.y / 128.f);
+    }
+};
+
+// g: RC rows of Wpad taps, g[c][i] = h[T-1 + c*D - i] (0 outside), i.e. the tap
+// that sample i of a lane's window contributes to the lane's c-th output.
+template <int RC, bool PAD, int TYPE>
+__global__ void __launch_bounds__(256)
+fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
+                 const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
+                 int tile_len)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(smem_raw);
+    const int nthr = blockDim.x;
+    const int tid = threadIdx.x;
+    const long long OB = (long long)nthr * RC;
+    const long long out_base = (long long)blockIdx.x * OB;
+    const long long tile_start = out_base * D - (T - 1);
+
+    for (int idx = tid; idx < tile_len; idx += nthr) {
+        long long j = tile_start + idx;
+        float2 v = make_float2(0.f, 0.f);
+        if (j < 0) {
+            long long hj = (T - 1) + j;
+            if (hj >= 0) v = hist[hj];
+        } else if (j < n_in) {
+            v = SampleLoad<TYPE>::at(in, (size_t)j);
+        }
+        int pos = PAD ? idx + idx / D : idx;
+        tile[pos] = v;
+    }
+    __syncthreads();
+
+    float2 acc[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) acc[c] = make_float2(0.f, 0.f);
+
+    const int lane_base = PAD ? tid * RC * (D + 1) : tid * RC * D;
+    const float2 *w = tile + lane_base;
+    // PAD: window index i sits at i + i/D; walk it D samples at a time
+    if (PAD) {
+        int i = 0, off = 0;
+        while (i < Wpad) {
+            int run = min(D, Wpad - i);
+            for (int k = 0; k < run; ++k) {
+                float2 x = w[off + k];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    float tp = g[c * Wpad + i + k];
+                    acc[c].x = fmaf(tp, x.x, acc[c].x);
+                    acc[c].y = fmaf(tp, x.y, acc[c].y);
+                }
+            }
+            i += run;
+            off += D + 1;
+        }
+    } else {
+        for (int i = 0; i < Wpad; i += 4) {
+            float2 x0 = w[i], x1 = w[i + 1], x2 = w[i + 2], x3 = w[i + 3];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const float *gc = g + c * Wpad + i;
+                float t0 = gc[0], t1 = gc[1], t2 = gc[2], t3 = gc[3];
+                acc[c].x = fmaf(t0, x0.x, acc[c].x);
+                acc[c].y = fmaf(t0, x0.y, acc[c].y);
+                acc[c].x = fmaf(t1, x1.x, acc[c].x);
+                acc[c].y = fmaf(t1, x1.y, acc[c].y);
+                acc[c].x = fmaf(t2, x2.x, acc[c].x);
+                acc[c].y = fmaf(t2, x2.y, acc[c].y);
+                acc[c].x = fmaf(t3, x3.x, acc[c].x);
+                acc[c].y = fmaf(t3, x3.y, acc[c].y);
+            }
+        }
+    }
+    const long long m0 = out_base + (long long)tid * RC;
+#pragma unroll
+    for (int c = 0; c < RC; ++c)
+        if (m0 + c < n_out) out[m0 + c] = acc[c];
+}
+
+// new history = last T-1 samples of (hist | in[0..n_in)), converted to float
+template <int TYPE>
+__global__ void fir_hist_kernel(const void *__restrict__ in, const float2 *__restrict__ hist_old,
+                                float2 *__restrict__ hist_new, int T, long long n_in)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T - 1) return;
+    long long j = n_in - (T - 1) + i;  // index into in, negative -> old history
+    float2 v;
+    if (j >= 0) v = SampleLoad<TYPE>::at(in, (size_t)j);
+    else {
+        long long hj = (T - 1) + j;
+        v = hj >= 0 ? hist_old[hj] : make_float2(0.f, 0.f);
+    }
+    hist_new[i] = v;
+}
+
+int FirStage::init(const float *taps, int ntaps, int decim)
+{
+    T = ntaps;
+    D = decim < 1 ? 1 : decim;
+    if (D == 1) RC = 5;
+    else RC = 3;
+    pad = ((RC * D) % 2) == 0;
+    W = T + (RC - 1) * D;
+    Wpad = (W + 3) & ~3;
+    std::vector<float> rows((size_t)RC * Wpad, 0.0f);
+    for (int c = 0; c < RC; ++c)
+        for (int i = 0; i < W; ++i) {
+            int k = T - 1 + c * D - i;
+            if (k >= 0 && k < T) rows[(size_t)c * Wpad + i] = taps[k];
+        }
+    XR_TRY(g.reserve(rows.size() * sizeof(float)));
+    XR_HIP(hipMemcpy(g.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    // block size: keep the LDS window under 64 KiB
+    threads = 256;
+    for (;;) {
+        long long ob = (long long)threads * RC;
+        long long tl = (ob - 1) * D + T + (Wpad - W) + 8;
+        long long padded = pad ? tl + tl / D + 8 : tl;
+        if (padded * 8 <= 64 * 1024 || threads == 64) {
+            tile_len = (int)tl;
+            lds_bytes = (size_t)padded * 8;
+            break;
+        }
+        threads /= 2;
+    }
+    if (lds_bytes > 160 * 1024) {
+        set_error("FIR window of %d taps x decimation %d does not fit LDS", T, D);
+        return XRIT_E_INVALID;
+    }
+    XR_TRY(hist[0].reserve((size_t)(T > 1 ? T - 1 : 1) * sizeof(float2)));
+    XR_TRY(hist[1].reserve((size_t)(T > 1 ? T - 1 : 1) * sizeof(float2)));
+    XR_HIP(hipMemset(hist[0].p, 0, hist[0].bytes));
+    XR_HIP(hipMemset(hist[1].p, 0, hist[1].bytes));
+    cur = 0;
+    return XRIT_OK;
+}
+
+void FirStage::release()
+{
+    g.release();
+    hist[0].release();
+    hist[1].release();
+}
+
+template <int RC, bool PAD>
+static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out, size_t n_out, size_t n_in,
+                        hipStream_t s)
+{
+    unsigned blocks = div_up(n_out, (size_t)f.threads * RC);
+    const float2 *h = f.hist[f.cur].as<float2>();
+    const float *g = f.g.as<float>();
+#define XR_FIR_GO(TY)                                                                                          \
+    hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len)
+    if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
+    else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
+    else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
+#undef XR_FIR_GO
+    XR_HIP(hipGetLastError());
+    return XRIT_OK;
+}
+
+int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof)
+{
+    size_t n_in = n_out * (size_t)D;
+    if (n_out > 0) {
+        ProfScope ps(prof, D > 1 ? "fir_decim" : "fir_rrc", s);
+        if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s)));
+        else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s)));
+        else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s)));
+    }
+    if (T > 1 && n_in > 0) {
+        ProfScope ps(prof, "fir_hist", s);
+        int nb = div_up((size_t)T - 1, 256);
+        float2 *hn = hist[cur ^ 1].as<float2>();
+        const float2 *ho = hist[cur].as<float2>();
+        if (type == XRIT_SAMPLE_FLOATIQ)
+            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_FLOATIQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
+        else if (type == XRIT_SAMPLE_S16IQ)
+            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_S16IQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
+        else
+            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_S8IQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
+        XR_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    return XRIT_OK;
+}
+
+}  // namespace xrit

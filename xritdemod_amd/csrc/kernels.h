@@ -1,0 +1,89 @@
+// kernels.h -- stage objects of the chain (device state + launch plans).
+#pragma once
+
+#include "common.h"
+#include "loop_core.h"
+#include "taps.h"
+
+namespace xrit {
+
+// ---- FirFilter (demodulator.cpp:446,450; Work at :138,:148) ---------------
+struct FirStage {
+    int T = 0, D = 1, RC = 3, W = 0, Wpad = 0, threads = 256, tile_len = 0, cur = 0;
+    bool pad = false;
+    size_t lds_bytes = 0;
+    DevBuf g;        // RC x Wpad window taps
+    DevBuf hist[2];  // T-1 samples of history (ping-pong)
+    int init(const float *taps, int ntaps, int decim);
+    void release();
+    // consumes n_out*D samples of `in` (sample_type as in FrontendDevice.h:11-13)
+    int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof);
+};
+
+// ---- AGC (demodulator.cpp:447; Work at :143) ------------------------------
+struct AgcStage {
+    float rate = 0, ref = 0, maxg = 0;
+    DevBuf state;    // two (gain, guard flag) slots, ping-pong across calls
+    DevBuf aggs;     // per-block composed maps
+    DevBuf starts;
+    int cur = 0;
+    int init(float rate, float reference, float gain, float max_gain);
+    void release();
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    int gain(float *g, hipStream_t s);
+    int fallback_flag(float *flag, hipStream_t s);
+};
+
+// ---- CostasLoop (demodulator.cpp:448; Work at :152) -----------------------
+struct CostasStage {
+    CostasGains gains{};
+    int L = 256;            // samples per chain
+    int max_passes = 32;
+    float trust = 1.0f, tol_phase = 1e-6f, tol_freq = 3e-9f;
+    DevBuf state;           // float2 (phase, freq) carried across calls
+    DevBuf S, E, J, stat, dlin, work, flags, counters;
+    unsigned *h_counters = nullptr;   // pinned
+    int cur = 0;
+    int passes = 0;
+    unsigned unconverged = 0;
+    float max_residual = 0;
+    int init(float loop_bw, int chain_len, int max_passes);
+    void release();
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    int get_state(float *phase, float *freq, hipStream_t s);
+};
+
+// ---- ClockRecovery (demodulator.cpp:449; Work at :156) --------------------
+struct ClockStage {
+    ClockPar par{};
+    float sps = 0, mu0 = 0.5f;
+    int NS = 64;            // symbols per chain
+    int max_passes = 8;
+    DevBuf table;           // 129 x 8 MMSE taps
+    DevBuf xbuf;            // [carry | new] input samples of the call
+    DevBuf st;              // carried ClockState + carry count
+    DevBuf S, E, J, om, work, counters, sym, dlin, flags;
+    void *h_res = nullptr;            // pinned
+    unsigned *h_counters = nullptr;   // pinned
+    float tol_t = 2e-6f, tol_w = 2e-7f;
+    int cur = 0;
+    size_t carry = 0;       // samples held over from the previous call
+    int passes = 0;
+    unsigned unconverged = 0;
+    float max_residual = 0;
+    size_t last_symbols = 0;
+    int init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
+             int max_passes);
+    void release();
+    // where the producer must write the n new samples of this call
+    int input_slot(size_t n, float2 **slot, hipStream_t s);
+    // soft (real parts) and/or complex symbols; either may be null
+    int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
+};
+
+// ---- helpers ---------------------------------------------------------------
+int launch_quantize_i8(const float *in, int8_t *out, size_t n, hipStream_t s);
+int launch_convert(const void *in, int type, float2 *out, size_t n, hipStream_t s);
+int launch_synth(const xrit_synth_params &p, uint64_t start, size_t n, float2 *out, hipStream_t s);
+
+}  // namespace xrit

@@ -1,0 +1,197 @@
+// loop_core.h -- per-sample / per-symbol arithmetic of the three feedback loops,
+// written once and used by every kernel lane.  The statement order follows the
+// algorithms SatHelper's AGC / CostasLoop / ClockRecovery implement (call sites
+// /root/reference/demodulator/src/demodulator.cpp:143,152,156; parameters
+// Parameters.h:27-37).  Build with -ffp-contract=off: these recurrences use
+// separate multiplies and adds, like the reference's x86-64 -O3 build, so that a
+// lane's trajectory tracks the CPU one as closely as float32 allows.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define XR_HD __host__ __device__ __forceinline__
+#else
+#define XR_HD inline
+#endif
+
+namespace xrit {
+
+struct cf32 { float x, y; };
+
+#define XR_TWOPI_F 6.28318530717958647692f
+#define XR_PI_D    3.14159265358979323846
+
+// 0.5*(|x+c| - |x-c|): the "branchless clip" of the upstream loops.  Its float
+// roundings are part of the recurrence (it quantises small x to ulp(c)), so it
+// must not be replaced by fmin/fmax.
+XR_HD float bclip(float x, float c)
+{
+    float a = fabsf(x + c);
+    float b = fabsf(x - c);
+    a -= b;
+    return 0.5f * a;
+}
+
+// ------------------------------------------------------------------ AGC ----
+// g' = min(a*g + b, c) maps; composition is associative for a >= 0.
+struct AgcMap { float a, b, c; };
+
+XR_HD AgcMap agc_identity() { return AgcMap{1.0f, 0.0f, INFINITY}; }
+
+// first `lo`, then `hi`
+XR_HD AgcMap agc_compose(const AgcMap &lo, const AgcMap &hi)
+{
+    AgcMap r;
+    r.a = hi.a * lo.a;
+    r.b = hi.a * lo.b + hi.b;
+    r.c = fminf(hi.a * lo.c + hi.b, hi.c);
+    return r;
+}
+
+XR_HD float agc_apply(const AgcMap &m, float g) { return fminf(m.a * g + m.b, m.c); }
+
+// map of one sample: g += rate*(ref - |x| g); clamp to max (max<=0: no clamp)
+XR_HD AgcMap agc_sample_map(float xr, float xi, float rate, float ref, float maxg)
+{
+    float mag = sqrtf(xr * xr + xi * xi);
+    AgcMap m;
+    m.a = 1.0f - rate * mag;
+    m.b = rate * ref;
+    m.c = maxg > 0.0f ? maxg : INFINITY;
+    return m;
+}
+
+// exact serial step, same statement order as the CPU chain
+XR_HD void agc_step(float xr, float xi, float &g, float rate, float ref, float maxg, float &yr, float &yi)
+{
+    yr = xr * g;
+    yi = xi * g;
+    g += rate * (ref - sqrtf(yr * yr + yi * yi));
+    if (maxg > 0.0f && g > maxg) g = maxg;
+}
+
+// --------------------------------------------------------------- Costas ----
+struct CostasGains { float alpha, beta; };
+
+XR_HD CostasGains costas_gains(float loop_bw)
+{
+    float damping = sqrtf(2.0f) / 2.0f;
+    float denom = (1.0f + 2.0f * damping * loop_bw + loop_bw * loop_bw);
+    CostasGains g;
+    g.alpha = (4 * damping * loop_bw) / denom;
+    g.beta = (4 * loop_bw * loop_bw) / denom;
+    return g;
+}
+
+// tangent of (phase, freq) w.r.t. the chain's start (phase0, freq0)
+struct CostasTan { float pp, pf, fp, ff; };
+
+template <bool TANGENT>
+XR_HD void costas_step(float zr, float zi, float &phase, float &freq, const CostasGains &g,
+                       float &yr, float &yi, CostasTan &t)
+{
+    float s, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(-phase, &s, &c);
+#else
+    ::sincosf(-phase, &s, &c);
+#endif
+    yr = zr * c - zi * s;
+    yi = zr * s + zi * c;
+    float err = yr * yi;
+    float ed = 0.0f;
+    if (TANGENT) ed = (fabsf(err) < 1.0f) ? (yi * yi - yr * yr) : 0.0f;
+    err = bclip(err, 1.0f);
+    freq = freq + g.beta * err;
+    phase = phase + freq + g.alpha * err;
+    if (TANGENT) {
+        float be = g.beta * ed, ae = g.alpha * ed;
+        t.fp = t.fp + be * t.pp;
+        t.ff = t.ff + be * t.pf;
+        float npp = t.pp + t.fp + ae * t.pp;
+        float npf = t.pf + t.ff + ae * t.pf;
+        t.pp = npp;
+        t.pf = npf;
+    }
+    while (phase > XR_TWOPI_F) phase -= XR_TWOPI_F;
+    while (phase < -XR_TWOPI_F) phase += XR_TWOPI_F;
+    if (freq > 1.0f) {
+        freq = 1.0f;
+        if (TANGENT) { t.fp = 0.0f; t.ff = 0.0f; }
+    } else if (freq < -1.0f) {
+        freq = -1.0f;
+        if (TANGENT) { t.fp = 0.0f; t.ff = 0.0f; }
+    }
+}
+
+// ---------------------------------------------------- Mueller & Mueller ----
+#define XR_MM_NTAPS  8
+#define XR_MM_NSTEPS 128
+#define XR_MM_FUDGE  16
+
+struct ClockPar { float omega_mid, omega_lim, gain_omega, gain_mu; };
+
+// state between symbols.  ii is the absolute read index into the call's
+// [carry | new] sample buffer.
+struct ClockState {
+    int64_t ii;
+    float mu, omega;
+    cf32 p0, p1;   // last two interpolated outputs (p_0T, p_1T after the step)
+    cf32 c0, c1;   // their 0/1 slicer decisions
+};
+
+// One symbol.  x points at the sample buffer base, table at the 129x8 MMSE taps.
+template <typename TableT>
+XR_HD cf32 clock_step(const cf32 *x, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
+{
+    cf32 p2 = s.p1, p1 = s.p0;
+    cf32 c2 = s.c1, c1 = s.c0;
+    int imu = (int)rintf(s.mu * (float)XR_MM_NSTEPS);
+    if (arm_out) *arm_out = imu;
+    const TableT *row = table + imu * XR_MM_NTAPS;
+    const cf32 *w = x + s.ii;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int k = 0; k < XR_MM_NTAPS; ++k) {
+        float tp = (float)row[XR_MM_NTAPS - 1 - k];
+        cf32 v = w[k];
+        ar += tp * v.x;
+        ai += tp * v.y;
+    }
+    cf32 p0{ar, ai};
+    cf32 c0{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
+    float dcr = c0.x - c2.x, dci = c0.y - c2.y;
+    float xr = dcr * p1.x + dci * p1.y;
+    float dpr = p0.x - p2.x, dpi = p0.y - p2.y;
+    float yr = dpr * c1.x + dpi * c1.y;
+    float mm = yr - xr;
+    mm = bclip(mm, 1.0f);
+    float omega = s.omega + par.gain_omega * mm;
+    omega = par.omega_mid + bclip(omega - par.omega_mid, par.omega_lim);
+    float mu = s.mu + omega + par.gain_mu * mm;
+    float fl = floorf(mu);
+    s.ii += (int64_t)fl;
+    s.mu = mu - fl;
+    s.omega = omega;
+    s.p1 = p1; s.p0 = p0;
+    s.c1 = c1; s.c0 = c0;
+    return p0;
+}
+
+// t += dt on the (ii, mu) pair
+XR_HD void clock_shift(ClockState &s, float dt)
+{
+    float m = s.mu + dt;
+    float fl = floorf(m);
+    s.ii += (int64_t)fl;
+    s.mu = m - fl;
+}
+
+XR_HD float clock_tdiff(const ClockState &a, const ClockState &b)
+{
+    return (float)(a.ii - b.ii) + (a.mu - b.mu);
+}
+
+}  // namespace xrit
