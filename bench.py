@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the xRIT BPSK demodulation chain on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): LRIT BPSK at 293 883 sym/s, synthetic
+complex-float IQ, 256 Mi samples per burst at an input rate of 6.25 Msps,
+decimation 5 (151-tap Hamming low-pass) -> AGC -> 63-tap RRC (alpha 0.5) -> Costas
+-> Mueller & Mueller.  One "step" = one pass of the chain over one burst that is
+already resident in HBM; consecutive steps are consecutive bursts of one
+continuous stream (loop and filter state carried from step to step, exactly as
+the reference's processSamples() carries it from chunk to chunk,
+/root/reference/demodulator/src/demodulator.cpp:100-168).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank
+demodulates its own independent capture segment (distinct seed) -- the path
+shards by time slice / segment with no data-path collective, so scaling is weak
+and the only collectives are the timing barrier and the max-over-ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--burst-log2", type=int, default=28, help="log2 of samples per burst (28 = 256 Mi)")
+    ap.add_argument("--decimation", type=int, default=5)
+    ap.add_argument("--cpu-sample-log2", type=int, default=27, help="log2 of samples timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import xritdemod_amd as xa
+    from xritdemod_amd import _capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the chain has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    n_burst = 1 << args.burst_log2
+    D = args.decimation
+    fs_in = 1.25e6 * D
+    K, W = args.steps, args.warmup
+    nb = K + W
+
+    # ---- synthetic stream: nb consecutive bursts of this rank's capture segment
+    sp = _capi.synth_params(fs_in=fs_in, seed=0x58524954 + 2 * rank)
+    bursts = torch.empty((nb, n_burst, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for b in range(nb):
+        _capi.synth_generate_device(sp, b * n_burst, n_burst, bursts[b].data_ptr(), device=local_rank,
+                                    stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+
+    cfg = xa.Demodulator.config("lrit", fs_in, D, device=local_rank)
+    dem = xa.Demodulator(cfg)
+    sps = dem.sps
+    cap = int(n_burst / (D * sps * 0.99)) + 64
+    soft = torch.empty((cap,), dtype=torch.float32, device=dev)
+    soft0 = None
+
+    def step(b):
+        return dem.process_device(bursts[b].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
+
+    for b in range(W):
+        ns = step(b)
+        if b == 0:
+            soft0 = soft[:ns].clone()
+    if W == 0:
+        soft0 = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if not args.no_profile:
+        dem.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    nsym_total = 0
+    for b in range(W, W + K):
+        nsym_total += step(b)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    st = dem.stats()
+    prof = dem.profile_read() if not args.no_profile else []
+    dem.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([float(nsym_total)], dtype=torch.float64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        nsym_all = float(s.item())
+    else:
+        nsym_all = float(nsym_total)
+
+    total_samples = float(n_burst) * K * world
+    value = total_samples / elapsed / 1e6
+    b_alg = 8.0 + 4.0 / (D * sps)          # read cf32 once + one f32 soft symbol per symbol
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream)
+    roofline = None
+    kernels = {}
+    if prof:
+        for name, ms, cnt in prof:
+            kernels[name] = {"total_ms": round(ms, 4), "launches": cnt}
+        dom = max(prof, key=lambda r: r[1])
+        launches_per_step = dom[2] / K
+        avg_ms = dom[1] / dom[2]
+        # one launch of the dominant kernel covers the whole burst when it is launched once per step;
+        # kernels launched several times per step (hand-off passes) are priced per launch on the burst they sweep
+        bytes_per_launch = b_alg * n_burst
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "chain_achieved": round(b_alg * n_burst * K / (elapsed) / 1e9, 1),
+                    "chain_frac": round(b_alg * n_burst * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+        tpath = os.path.join(HERE, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if dom[0] in tj and tj[dom[0]].get("burst_log2") == args.burst_log2:
+                    roofline["traffic"] = tj[dom[0]]["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = tj[dom[0]].get("source")
+            except Exception:
+                pass
+
+    out = {
+        "metric": "Msamples/s in -> soft-symbols/s out (LRIT 293 ksym/s chain); % HBM roofline",
+        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: LRIT BPSK chain (decimating LPF 151 taps d=%d -> AGC -> RRC 63 a=0.5 -> Costas -> M&M), "
+                               "%d Mi-sample cf32 burst per step per GPU, consecutive bursts of one stream" % (D, n_burst >> 20),
+                   "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
+                   "segments": world, "costas_chain_len": 256, "clock_chain_syms": 64},
+        "soft_symbols_per_s": round(nsym_all / elapsed, 1),
+        "algorithmic_bytes_per_sample": round(b_alg, 4),
+        "loop_passes": {"costas": st.costas_passes, "clock": st.clock_passes,
+                        "costas_unconverged": st.costas_unconverged, "clock_unconverged": st.clock_unconverged},
+    }
+    if roofline:
+        out["roofline"] = roofline
+        out["kernels"] = kernels
+
+    # ---- CPU baseline: the oracle (a CPU restatement; the reference binary cannot be built here) on a
+    # bounded sample of the same workload, one thread like the reference's DSP thread.
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle
+        n_cpu = min(n_burst, 1 << args.cpu_sample_log2)
+        host = bursts[0, :n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
+        od = oracle.Demod(oracle.config("lrit", fs_in, D))
+        c0 = time.perf_counter()
+        so = od.process(host)
+        c1 = time.perf_counter()
+        out["cpu_baseline"] = {"value": round(n_cpu / (c1 - c0) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                               "kind": "port",
+                               "sample": "first %d Mi samples of burst 0, oracle/xrit_oracle.c single thread "
+                                         "(gcc -O3 -mavx2 -ffp-contract=off)" % (n_cpu >> 20),
+                               "seconds": round(c1 - c0, 3)}
+        if soft0 is not None:
+            g = soft0[:len(so)].cpu().numpy()
+            n = min(len(g), len(so))
+            e = np.abs(g[:n] - so[:n])
+            big = np.abs(so[:n]) > 1e-3
+            out["parity_vs_oracle"] = {"symbols": int(n), "rms": float(np.sqrt(np.mean(e ** 2))), "max": float(e.max()),
+                                       "sign_mismatches": int((np.sign(g[:n])[big] != np.sign(so[:n])[big]).sum())}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

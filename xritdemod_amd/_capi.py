@@ -25,7 +25,8 @@ class DemodConfig(C.Structure):
                 ("clock_mu", C.c_float), ("clock_alpha", C.c_float), ("clock_gain_omega", C.c_float),
                 ("clock_omega_limit", C.c_float),
                 ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
-                ("max_passes", C.c_int32), ("strict", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("max_passes", C.c_int32), ("strict", C.c_int32), ("clock_min_passes", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class DemodStats(C.Structure):

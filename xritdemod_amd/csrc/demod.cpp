@@ -173,6 +173,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
+        if (cfg->clock_min_passes > 0)
+            d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
         if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
     } while (0);
     if (rc != XRIT_OK) { xrit_demod_destroy(d); return rc; }
@@ -258,6 +260,10 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.clock_unconverged = d->clock.unconverged;
     d->stats.costas_max_residual = d->costas.max_residual;
     d->stats.clock_max_residual = d->clock.max_residual;
+    {
+        float flag = 0.f;   // the stream is idle here: clock.run() ended with a synchronise
+        if (length && d->agc.fallback_flag(&flag, s) == XRIT_OK) d->stats.agc_serial_fallback = flag == 2.0f;
+    }
     *n_out = nsym;
     if (rc != XRIT_OK) return rc;
     if (d->cfg.strict && d->costas.unconverged) {

@@ -39,7 +39,7 @@ struct CostasStage {
     CostasGains gains{};
     int L = 256;            // samples per chain
     int max_passes = 32;
-    float trust = 1.0f, tol_phase = 1e-6f, tol_freq = 3e-9f;
+    float trust = 1.0f, tol_phase = 1e-5f, tol_freq = 3e-8f;
     DevBuf state;           // float2 (phase, freq) carried across calls
     DevBuf S, E, J, stat, dlin, work, flags, counters;
     unsigned *h_counters = nullptr;   // pinned
@@ -58,7 +58,7 @@ struct ClockStage {
     ClockPar par{};
     float sps = 0, mu0 = 0.5f;
     int NS = 64;            // symbols per chain
-    int max_passes = 8;
+    int max_passes = 48, min_passes = 5;
     DevBuf table;           // 129 x 8 MMSE taps
     DevBuf xbuf;            // [carry | new] input samples of the call
     DevBuf st;              // carried ClockState + carry count
