@@ -16,7 +16,10 @@
 // the 1e-5 level in mu, so the passes stop at a fixed
 // budget rather than at bitwise closure.
 #include "kernels.h"
+
+#include <cstdlib>
 #include "scan.h"
+#include "newton.h"
 
 namespace xrit {
 
@@ -111,7 +114,8 @@ __device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double
 
 // start state of every chain from the unwrapped symbol-count curve
 __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, double sps, ClockState *__restrict__ S,
-                                   const ClockState *__restrict__ carried, int K, int NS, float omega0)
+                                   const ClockState *__restrict__ carried, int K, int NS, float omega0,
+                                   const float2 *__restrict__ x, const float *__restrict__ table, long long ni)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -135,90 +139,248 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
     s.omega = omega0;
     s.p0 = cf32{0.f, 0.f}; s.p1 = cf32{0.f, 0.f};
     s.c0 = cf32{0.f, 0.f}; s.c1 = cf32{0.f, 0.f};
+    // history: the two symbols before the chain, interpolated one and two nominal periods earlier
+    for (int back = 2; back >= 1; --back) {
+        double tb = t - back * (double)omega0;
+        if (tb < 0) continue;
+        long long ib = (long long)floor(tb);
+        if (ib >= ni) continue;
+        float mub = (float)(tb - floor(tb));
+        int imu = (int)rintf(mub * (float)XR_MM_NSTEPS);
+        const float *row = table + imu * XR_MM_NTAPS;
+        float ar = 0.f, ai = 0.f;
+        for (int q = 0; q < XR_MM_NTAPS; ++q) {
+            float2 v = x[ib + q];
+            ar += row[XR_MM_NTAPS - 1 - q] * v.x;
+            ai += row[XR_MM_NTAPS - 1 - q] * v.y;
+        }
+        s.p1 = s.p0; s.c1 = s.c0;
+        s.p0 = cf32{ar, ai};
+        s.c0 = cf32{ar > 0.f ? 1.f : 0.f, ai > 0.f ? 1.f : 0.f};
+    }
     S[k] = s;
 }
 
 // --------------------------------------------------------------------- pass
-// 192 threads: wave 0 = base trajectories of 64 chains, wave 1 = start shifted by
-// h_t, wave 2 = omega shifted by h_w.
-__global__ void __launch_bounds__(192) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
-                                                         const ClockState *__restrict__ S, ClockState *__restrict__ E,
-                                                         float4 *__restrict__ J, int *__restrict__ dirty,
-                                                         int *__restrict__ nrun, long long ni, int K, int NS,
-                                                         ClockPar par)
+// Sample access.  A lane advances through its chain at its own, data dependent
+// pace, reading an 8-sample window per symbol; done straight from global memory
+// every wave instruction touches 64 different cache lines.  Instead the block
+// stages, for every chain, the window it will need during the next SS symbols
+// (W samples from the base lane's read index - 1) with coalesced loads: a row of W
+// samples is one contiguous run, WP lanes per row.  Rows are WS = W|1 float2 apart
+// so that the per-lane ds_read_b64 stay spread over the banks.  A lane whose read
+// index leaves its staged window (possible only for perturbed or wildly wrong
+// states) reads global memory for that symbol.
+struct ClockTile {
+    float *table;          // 129 x 8
+    long long *wb;         // window base per chain (-1: row unused)
+    float2 *tile;          // 64 x WS
+};
+
+__device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
 {
-    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    __shared__ float2 endv[2][64];
-    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) table[i] = table_g[i];
+    ClockTile t;
+    t.table = reinterpret_cast<float *>(smem);
+    t.wb = reinterpret_cast<long long *>(smem + 4160);
+    t.tile = reinterpret_cast<float2 *>(smem + 4160 + 512);
+    return t;
+}
+
+static inline size_t clock_tile_bytes(int WS) { return 4160 + 512 + (size_t)64 * WS * sizeof(float2); }
+
+// All threads of the block (NV waves).  WP lanes cover one row, 64/WP rows per wave
+// instruction.  Fully unrolled in three phases -- window bases, then every global
+// load, then the LDS stores -- so that all loads of a fill are in flight together.
+template <int NV, int WP>
+__device__ __forceinline__ void clock_tile_fill(const ClockTile &t, const float2 *__restrict__ x, long long N, int W,
+                                                int WS)
+{
+    constexpr int RPI = 64 / WP;                       // rows per wave instruction
+    constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / WP, col = lane - sub * WP;
+    long long base[ITER];
+    float2 v[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = (it * NV + wave) * RPI + sub;
+        base[it] = (row < 64 && col < W) ? t.wb[row] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        v[it] = make_float2(0.f, 0.f);
+        const long long j = base[it] + col;
+        if (base[it] >= 0 && j < N) v[it] = x[j];
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int row = (it * NV + wave) * RPI + sub;
+        if (base[it] >= 0) t.tile[row * WS + col] = v[it];
+    }
+}
+
+__device__ __forceinline__ cf32 clock_step_tiled(const ClockTile &t, int lane, const float2 *__restrict__ x, int W,
+                                                 int WS, ClockState &s, const ClockPar &par)
+{
+    const long long off = s.ii - t.wb[lane];
+    if (off >= 0 && off + XR_MM_NTAPS <= W)
+        return clock_step_w(reinterpret_cast<const cf32 *>(t.tile + lane * WS + off), t.table, s, par);
+    return clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
+}
+
+// NV == 3 (192 threads): wave 0 = base trajectories of 64 chains, wave 1 = start
+// shifted by h_t, wave 2 = omega shifted by h_w; the base lane forms the
+// finite-difference Jacobian.  NV == 1 (64 threads): base trajectories only, the
+// Jacobian of an earlier pass is kept (quasi-Newton).
+template <int NV, int WP>
+__global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+                                                             const ClockState *__restrict__ S, ClockState *__restrict__ E,
+                                                             float4 *__restrict__ J, int *__restrict__ dirty,
+                                                             int *__restrict__ nrun, long long N, long long ni, int K,
+                                                             int NS, ClockPar par, int SS, int W, int WS)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float2 endv[NV > 1 ? 2 : 1][64];
+    __shared__ long long ref_ii[64];
+    __shared__ int any_run;
+    const ClockTile t = clock_tile_carve(smem);
     const int variant = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 64 + lane;
     bool run = k < K;
     if (run) run = dirty[k] != 0;
+    if (threadIdx.x == 0) any_run = 0;
     __syncthreads();
+    if (run && variant == 0) any_run = 1;
+    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) t.table[i] = table_g[i];
+    __syncthreads();
+    if (!any_run) return;
     ClockState s{};
-    ClockState base{};
     int produced = 0;
+    bool alive = run;
     if (run) {
         s = S[k];
-        if (variant == 1) clock_shift(s, CLK_H_T);
-        if (variant == 2) s.omega += CLK_H_W;
-        const cf32 *xp = reinterpret_cast<const cf32 *>(x);
-        for (int i = 0; i < NS; ++i) {
-            if (s.ii >= ni || s.ii < 0) break;
-            clock_step(xp, table, s, par);
-            ++produced;
-        }
+        if (NV > 1 && variant == 1) clock_shift(s, CLK_H_T);
+        if (NV > 1 && variant == 2) s.omega += CLK_H_W;
     }
-    if (variant == 0) base = s;
-    // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
-    __shared__ long long ref_ii[64];
-    if (variant == 0) ref_ii[lane] = s.ii;
-    __syncthreads();
-    if (variant > 0) endv[variant - 1][lane] = make_float2((float)(s.ii - ref_ii[lane]) + s.mu, s.omega);
-    __syncthreads();
+    for (int s0 = 0; s0 < NS; s0 += SS) {
+        if (variant == 0) t.wb[lane] = alive ? (s.ii > 0 ? s.ii - 1 : 0) : -1;
+        __syncthreads();
+        clock_tile_fill<NV, WP>(t, x, N, W, WS);
+        __syncthreads();
+        const int lim = min(SS, NS - s0);
+        for (int i = 0; i < lim; ++i) {
+            if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
+            if (alive) {
+                clock_step_tiled(t, lane, x, W, WS, s, par);
+                ++produced;
+            }
+        }
+        __syncthreads();
+    }
+    if (NV > 1) {
+        // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
+        if (variant == 0) ref_ii[lane] = s.ii;
+        __syncthreads();
+        if (variant > 0) endv[variant - 1][lane] = make_float2((float)(s.ii - ref_ii[lane]) + s.mu, s.omega);
+        __syncthreads();
+    }
     if (variant == 0 && run) {
-        float2 et = endv[0][lane], ew = endv[1][lane];
-        float tb = base.mu;
-        float4 j;
-        j.x = (et.x - tb) / CLK_H_T;           // dt/dt0
-        j.y = (ew.x - tb) / CLK_H_W;           // dt/dw0
-        j.z = (et.y - base.omega) / CLK_H_T;   // dw/dt0
-        j.w = (ew.y - base.omega) / CLK_H_W;   // dw/dw0
-        E[k] = base;
-        J[k] = j;
+        if (NV > 1) {
+            float2 et = endv[0][lane], ew = endv[1][lane];
+            float tb = s.mu;
+            float4 j;
+            j.x = (et.x - tb) / CLK_H_T;        // dt/dt0
+            j.y = (ew.x - tb) / CLK_H_W;        // dt/dw0
+            j.z = (et.y - s.omega) / CLK_H_T;   // dw/dt0
+            j.w = (ew.y - s.omega) / CLK_H_W;   // dw/dw0
+            J[k] = j;
+        }
+        E[k] = s;
         nrun[k] = produced;
         dirty[k] = 0;
     }
 }
 
-// output pass: base trajectories only, symbols written at k*NS + i
+// output pass: base trajectories only; symbol i of chain k goes to k*NS + i.  A lane
+// produces its symbols one after the other, so they are collected in an LDS tile of
+// CLK_OT symbols per chain and written out row-wise (4 lanes x 16 B per chain row).
+constexpr int CLK_OT = 16;
+
+template <int WP>
 __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
-                                                          float2 *__restrict__ sym, unsigned long long cap, long long ni,
-                                                          int K, int NS, ClockPar par, int *__restrict__ terminal)
+                                                          float2 *__restrict__ sym, unsigned long long cap, long long N,
+                                                          long long ni, int K, int NS, ClockPar par,
+                                                          int *__restrict__ terminal, int SS, int W, int WS)
 {
-    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) table[i] = table_g[i];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float2 otile[64][CLK_OT + 1];
+    __shared__ int made[64];
+    const ClockTile t = clock_tile_carve(smem);
+    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) t.table[i] = table_g[i];
     __syncthreads();
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    ClockState s = S[k];
-    const cf32 *xp = reinterpret_cast<const cf32 *>(x);
-    const unsigned long long o0 = (unsigned long long)k * NS;
-    int i = 0;
-    for (; i < NS; ++i) {
-        if (s.ii >= ni || s.ii < 0) break;
-        cf32 p = clock_step(xp, table, s, par);
-        unsigned long long o = o0 + i;
-        if (o < cap) {
-            if (soft) soft[o] = p.x;
-            if (sym) sym[o] = make_float2(p.x, p.y);
+    const int lane = threadIdx.x;
+    const int kbase = blockIdx.x * 64;
+    const int k = kbase + lane;
+    const bool mine = k < K;
+    ClockState s{};
+    if (mine) s = S[k];
+    int produced = 0;
+    bool alive = mine;
+    for (int i0 = 0; i0 < NS; i0 += CLK_OT) {
+        const int olim = min(CLK_OT, NS - i0);
+        for (int s0 = 0; s0 < olim; s0 += SS) {
+            t.wb[lane] = alive ? (s.ii > 0 ? s.ii - 1 : 0) : -1;
+            __syncthreads();
+            clock_tile_fill<1, WP>(t, x, N, W, WS);
+            __syncthreads();
+            const int lim = min(SS, olim - s0);
+            for (int i = 0; i < lim; ++i) {
+                if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
+                if (alive) {
+                    cf32 p = clock_step_tiled(t, lane, x, W, WS, s, par);
+                    otile[lane][s0 + i] = make_float2(p.x, p.y);
+                    ++produced;
+                }
+            }
+            __syncthreads();
         }
+        made[lane] = produced - i0;          // symbols of this tile that exist (may be <= 0)
+        __syncthreads();
+        // row-wise write: lane l handles chain (it*16 + l/4), symbols (l%4)*4 .. +3
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 16 + (lane >> 2);
+            const int q0 = (lane & 3) * 4;
+            const int have = made[c];
+            const unsigned long long o = (unsigned long long)(kbase + c) * NS + i0 + q0;
+            if (kbase + c < K && q0 < have && q0 < olim) {
+                float2 v0 = otile[c][q0], v1 = otile[c][q0 + 1], v2 = otile[c][q0 + 2], v3 = otile[c][q0 + 3];
+                const int nv = min(min(have, olim) - q0, 4);
+                if (nv == 4 && o + 3 < cap && (NS & 3) == 0) {
+                    if (soft) *reinterpret_cast<float4 *>(soft + o) = make_float4(v0.x, v1.x, v2.x, v3.x);
+                    if (sym) {
+                        *reinterpret_cast<float4 *>(sym + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                        *reinterpret_cast<float4 *>(sym + o + 2) = make_float4(v2.x, v2.y, v3.x, v3.y);
+                    }
+                } else {
+#define XR_PUT(Q, V)                                   \
+    if (Q < nv && o + Q < cap) {                       \
+        if (soft) soft[o + Q] = V.x;                   \
+        if (sym) sym[o + Q] = V;                       \
     }
+                    XR_PUT(0, v0) XR_PUT(1, v1) XR_PUT(2, v2) XR_PUT(3, v3)
+#undef XR_PUT
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!mine) return;
     E[k] = s;
-    counts[k] = i;
-    if (i < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
+    counts[k] = produced;
+    if (produced < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
 }
 
 // result of the call + the state and the unread tail carried to the next call
@@ -264,102 +426,63 @@ __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *
 }
 
 // ------------------------------------------------------------ hand-off solve
-struct ClockMap { float a11, a12, a21, a22, b1, b2; int slip; };
-
-struct ClockNewtonF {
-    typedef ClockMap T;
+// Policy for newton.h.  State components: (t = ii + mu, omega).  A residual of m
+// whole symbol periods is carried as a slip count (aux) that shifts all later chains.
+struct ClockPolicy {
     ClockState *S;
     const ClockState *E;
     const float4 *J;
-    float2 *dlin;
     int *dirty;
     const int *nrun;      // symbols chain k produced when it last ran
-    unsigned *counters;   // [0] changed, [1] not frozen, [2] max |r_t| bits
-    long long ni;
+    unsigned *cnt;        // [0] changed, [1] not frozen, [2] max |r_t| bits, [3] large, [4] sum r_t^2 (float)
     float trust_t, trust_w, tol_t, tol_w;
-    int phase;
 
-    __device__ T identity() const { return T{1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0}; }
-    __device__ T combine(const T &lo, const T &hi) const
-    {
-        T r;
-        r.a11 = hi.a11 * lo.a11 + hi.a12 * lo.a21;
-        r.a12 = hi.a11 * lo.a12 + hi.a12 * lo.a22;
-        r.a21 = hi.a21 * lo.a11 + hi.a22 * lo.a21;
-        r.a22 = hi.a21 * lo.a12 + hi.a22 * lo.a22;
-        r.b1 = hi.a11 * lo.b1 + hi.a12 * lo.b2 + hi.b1;
-        r.b2 = hi.a21 * lo.b1 + hi.a22 * lo.b2 + hi.b2;
-        r.slip = lo.slip + hi.slip;
-        return r;
-    }
     __device__ bool active(long long k) const { return nrun[k] > 0; }
-    __device__ T element(long long k) const
+    __device__ void residual(long long k, float &r1, float &r2, int &aux) const
     {
-        T t = identity();
-        if (!active(k)) { t.a11 = t.a22 = 0.f; return t; }   // nothing to hand over past the end of the input
         ClockState e = E[k], s = S[k + 1];
         float rt = clock_tdiff(e, s);
-        float rw = e.omega - s.omega;
         float m = rintf(rt / e.omega);
-        rt -= m * e.omega;
-        bool cut = false;
-        if (phase == 1) {
-            float2 d = dlin[k];
-            cut = !(fabsf(d.x) <= trust_t) || !(fabsf(d.y) <= trust_w);
-        }
+        r1 = rt - m * e.omega;
+        r2 = e.omega - s.omega;
+        aux = (int)m;
+    }
+    __device__ float4 jac(long long k) const
+    {
         float4 j = J[k];
-        if (cut || !(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 4.f * 4096.f)) { t.a11 = t.a12 = t.a21 = t.a22 = 0.f; }
-        else { t.a11 = j.x; t.a12 = j.y; t.a21 = j.z; t.a22 = j.w; }
-        t.b1 = rt; t.b2 = rw;
-        t.slip = (int)m;
-        return t;
+        if (!(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 16384.f) || !(fabsf(j.z) < 1.f) || !(fabsf(j.w) < 4.f))
+            j = make_float4(0.f, 0.f, 0.f, 0.f);
+        return j;
     }
-    __device__ T reduce_run(long long i0, int cnt) const
+    __device__ bool outside_trust(float d1, float d2) const
     {
-        T m = identity();
-        for (int k = 0; k < cnt; ++k) m = combine(m, element(i0 + k));
-        return m;
+        return !(fabsf(d1) <= trust_t) || !(fabsf(d2) <= trust_w);
     }
-    __device__ void apply_run(long long i0, int cnt, const T &pre) const
+    __device__ void update(long long k, float j1, float j2, float n1, float n2, int slip, int slip_k, float r1,
+                           NewtonStat &st) const
     {
-        float dt = pre.b1, dw = pre.b2;
-        int slip = pre.slip;
-        for (int q = 0; q < cnt; ++q) {
-            long long k = i0 + q;
-            T e = element(k);
-            float jt = e.a11 * dt + e.a12 * dw;
-            float jw = e.a21 * dt + e.a22 * dw;
-            float ndt = e.b1 + jt, ndw = e.b2 + jw;
-            if (phase == 0) {
-                dlin[k + 1] = make_float2(ndt, ndw);
-                if (k == 0) dlin[0] = make_float2(0.f, 0.f);
-            } else {
-                ClockState ek = E[k], old = S[k + 1];
-                bool act = active(k);
-                bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
-                                 ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
-                                 ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
-                bool frozen = act && fabsf(ndt) <= tol_t && fabsf(ndw) <= tol_w && slip == 0 && e.slip == 0 && hist_same;
-                if (!act) {
-                    // chain k produced nothing: its successor starts where it stands
-                    bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
-                    if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; atomicAdd(&counters[0], 1u); }
-                } else if (!frozen) {
-                    ClockState nw = ek;
-                    clock_shift(nw, (float)slip * ek.omega + jt);
-                    nw.omega = ek.omega + jw;
-                    if (nw.ii < 0) { nw.ii = 0; nw.mu = 0.f; }
-                    atomicAdd(&counters[1], 1u);
-                    atomicMax(&counters[2], __float_as_uint(fabsf(e.b1)));
-                    if (fabsf(e.b1) > 0.02f || e.slip != 0) atomicAdd(&counters[3], 1u);
-                    atomicAdd(reinterpret_cast<float *>(&counters[4]), fminf(e.b1 * e.b1, 1.0f));
-                    bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
-                    if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; atomicAdd(&counters[0], 1u); }
-                }
-            }
-            dt = ndt; dw = ndw;
-            slip += e.slip;
+        ClockState ek = E[k], old = S[k + 1];
+        const bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
+                               ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
+                               ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
+        if (!active(k)) {
+            // chain k produced nothing: its successor starts where it stands
+            const bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
+            if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; st.changed += 1; }
+            return;
         }
+        const bool frozen = fabsf(n1) <= tol_t && fabsf(n2) <= tol_w && slip == 0 && slip_k == 0 && hist_same;
+        if (frozen) return;
+        ClockState nw = ek;
+        clock_shift(nw, (float)slip * ek.omega + j1);
+        nw.omega = ek.omega + j2;
+        if (nw.ii < 0) { nw.ii = 0; nw.mu = 0.f; }
+        st.open_ += 1;
+        st.max_r = fmaxf(st.max_r, fabsf(r1));
+        if (fabsf(r1) > 0.02f || slip_k != 0) st.large += 1;
+        st.sum_sq += fminf(r1 * r1, 1.0f);
+        const bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
+        if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; st.changed += 1; }
     }
 };
 
@@ -380,7 +503,10 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     mu0 = mu;
     NS = chain_syms > 0 ? chain_syms : 64;
     max_passes = max_passes_ > 0 ? max_passes_ : 48;
-    min_passes = max_passes < 5 ? max_passes : 5;
+    min_passes = max_passes < 4 ? max_passes : 4;
+    if (const char *e = getenv("XRIT_CLOCK_JAC_PASSES")) jac_passes = atoi(e);   // experiment knobs
+    if (const char *e = getenv("XRIT_CLOCK_NS")) NS = atoi(e);
+    if (const char *e = getenv("XRIT_CLOCK_SS")) ss_override = atoi(e);
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
     design_mmse_table(tb.data());
     XR_TRY(table.reserve(tb.size() * sizeof(float)));
@@ -390,7 +516,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     s0.ii = 0; s0.mu = mu; s0.omega = omega;
     ClockState both[2] = {s0, s0};
     XR_HIP(hipMemcpy(st.p, both, sizeof both, hipMemcpyHostToDevice));
-    XR_TRY(counters.reserve(16 * sizeof(unsigned)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 4) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_res, 64));
     XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
     cur = 0;
@@ -455,7 +581,7 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     XR_TRY(om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))));
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;
-    XR_TRY(work.reserve((size_t)(nbmax + 2) * sizeof(ClockMap)));
+    XR_TRY(work.reserve((size_t)(2 * nbmax + 6) * sizeof(AffMap)));
     int *dirty = flags.as<int>();
     int *counts = flags.as<int>() + K;
     int *nrun = flags.as<int>() + 2 * K;
@@ -464,6 +590,15 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     ClockResult *d_res = reinterpret_cast<ClockResult *>(counters.as<unsigned>() + 8);
     const unsigned gridK = div_up((size_t)K, 64);
+    // staged window: SS symbols ahead, at the fastest admissible symbol clock
+    const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
+    int SS = ss_override > 0 ? ss_override : 4;
+    while (SS > 1 && (int)ceil(SS * max_adv) + 2 + XR_MM_NTAPS > 32) --SS;
+    int W = (int)ceil(SS * max_adv) + 1 + XR_MM_NTAPS + 1;
+    if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
+    const int WS = W | 1;
+    const bool wide = W > 32;
+    const size_t tile_bytes = clock_tile_bytes(WS);
 
     if (K > 1) {
         {
@@ -477,56 +612,67 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
             hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
-                               S.as<ClockState>(), st_in, K, NS, par.omega_mid);
+                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), ni);
             hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, dirty, 1, K);
         }
-        ClockNewtonF nf{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dlin.as<float2>(), dirty, nrun,
-                        counters.as<unsigned>(), ni, 0.75f, 0.01f, tol_t, tol_w, 0};
         const long long nel = K - 1;
-        const int nbE = scan_blocks(nel);
+        AffMap *aggs = work.as<AffMap>();
+        unsigned *cnt_all = counters.as<unsigned>() + 16;
+        XR_HIP(hipMemsetAsync(cnt_all, 0, (size_t)(max_passes + 1) * 8 * sizeof(unsigned), s));
+        ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, cnt_all,
+                        0.75f, 0.01f, tol_t, tol_w};
         float q_prev = INFINITY;
+        const int blind = min_passes < max_passes ? min_passes : max_passes;
         for (int p = 0; p < max_passes; ++p) {
             {
-                ProfScope ps(prof, "clock_pass", s);
-                hipLaunchKernelGGL(clock_pass_kernel, dim3(gridK), dim3(192), 0, s, x, table.as<float>(),
-                                   S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, ni, K, NS, par);
+                ProfScope ps(prof, p < jac_passes ? "clock_pass_jac" : "clock_pass", s);
+#define XR_CLK_PASS(NV, WPV)                                                                                      \
+    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), tile_bytes, s, x, table.as<float>(),  \
+                       S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, N, ni, K, NS, par, SS, W, WS)
+                if (p < jac_passes) { if (wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
+                else { if (wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
+#undef XR_CLK_PASS
             }
             {
                 ProfScope ps(prof, "clock_solve", s);
-                XR_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned), s));
-                nf.phase = 0;
-                hipLaunchKernelGGL(scan_reduce_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<ClockMap>());
-                hipLaunchKernelGGL(scan_aggs_kernel<ClockNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
-                                   work.as<ClockMap>(), nbE);
-                hipLaunchKernelGGL(scan_apply_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<ClockMap>());
-                nf.phase = 1;
-                hipLaunchKernelGGL(scan_reduce_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<ClockMap>());
-                hipLaunchKernelGGL(scan_aggs_kernel<ClockNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
-                                   work.as<ClockMap>(), nbE);
-                hipLaunchKernelGGL(scan_apply_kernel<ClockNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<ClockMap>());
+                pol.cnt = cnt_all + (size_t)p * 8;
+                if (newton_solve(pol, nel, aggs, dlin.as<float2>(), s) != 0) {
+                    set_error("clock hand-off: %d chains exceed the solver's block budget", K);
+                    return XRIT_E_INVALID;
+                }
             }
-            XR_HIP(hipMemcpyAsync(h_counters, counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
             ++passes;
+            if (p + 1 < blind) continue;
+            XR_HIP(hipMemcpyAsync(h_counters, pol.cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
             unconverged = h_counters[1];
             uint32_t bits = h_counters[2];
             memcpy(&max_residual, &bits, sizeof(float));
             if (h_counters[0] == 0) { unconverged = 0; break; }
             // The recurrence is chaotic at the 1e-5 level (interpolator-arm quantisation), so boundaries keep
             // moving by that much for ever; what must close are the LARGE residuals (acquisition at the head of a
-            // cold-started call, symbol slips).  Stop once those are down to the decision-flip background.
-            // (decision flips kick mu by up to ~2e-3; acquisition and slips leave residuals >> 0.02 samples)
-            // After that, keep going only while the summed squared residual still falls by > 15 % per pass.
+            // cold-started call, symbol slips: decision flips kick mu by up to ~2e-3, acquisition and slips leave
+            // residuals >> 0.02 samples).  After that, keep going only while the summed squared residual still
+            // falls by > 40 % per pass.
             unsigned large = h_counters[3];
             float q;
             memcpy(&q, &h_counters[4], sizeof(float));
-            bool stalled = q > 0.85f * q_prev;
+            bool stalled = q > 0.6f * q_prev;
             q_prev = q;
             if (passes >= min_passes && large == 0 && stalled) break;
+        }
+        if (getenv("XRIT_TRACE")) {
+            std::vector<unsigned> hc((size_t)passes * 8);
+            XR_HIP(hipMemcpyAsync(hc.data(), cnt_all, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
+            for (int p = 0; p < passes; ++p) {
+                float mr, q;
+                memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
+                memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+                fprintf(stderr, "[xrit] %s pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", "clock", p, K,
+                        hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
+                        hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
+            }
         }
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
@@ -534,9 +680,14 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     {
         ProfScope ps(prof, "clock_output", s);
         hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, terminal, 0x7fffffff, 1);
-        hipLaunchKernelGGL(clock_output_kernel, dim3(gridK), dim3(64), 0, s, x, table.as<float>(), S.as<ClockState>(),
-                           E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, ni, K, NS, par,
-                           terminal);
+        if (wide)
+            hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), tile_bytes, s, x, table.as<float>(),
+                               S.as<ClockState>(), E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, N,
+                               ni, K, NS, par, terminal, SS, W, WS);
+        else
+            hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), tile_bytes, s, x, table.as<float>(),
+                               S.as<ClockState>(), E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, N,
+                               ni, K, NS, par, terminal, SS, W, WS);
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), counts, terminal,
                            st_in, st_out, d_res, x, N, K, NS);
     }

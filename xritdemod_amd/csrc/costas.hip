@@ -14,7 +14,10 @@
 // detector is Re*Im): a residual of m*pi at a boundary is carried as a parity
 // that shifts every later start by pi instead of being "corrected".
 #include "kernels.h"
+
+#include <cstdlib>
 #include "scan.h"
+#include "newton.h"
 
 namespace xrit {
 
@@ -117,7 +120,14 @@ __global__ void costas_head_kernel(const float2 *__restrict__ stat, float2 *__re
 }
 
 // --------------------------------------------------------------------- pass
-// One lane = one chain.  FINAL: write the de-rotated samples, no tangent.
+// One wave = 64 chains, one lane per chain.  Samples move through LDS tiles of
+// COSTAS_CT samples per chain so that HBM sees coalesced 16-byte accesses
+// (4 lanes cover one chain's 64-byte row, 16 chains per wave instruction) while
+// each lane walks its own chain: row stride COSTAS_CT+1 float2 = 18 dwords keeps the
+// per-lane ds_read_b64 conflict free.  FINAL: write the de-rotated samples (through
+// the same kind of tile), no tangent.
+constexpr int COSTAS_CT = 8;
+
 template <bool FINAL>
 __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restrict__ z, float2 *__restrict__ y,
                                                          const float2 *__restrict__ S, float2 *__restrict__ E,
@@ -125,128 +135,132 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          float2 *__restrict__ state_out, long long n, int L, int K,
                                                          CostasGains g)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    if (!FINAL) {
-        if (!dirty[k]) return;
-        dirty[k] = 0;
-    }
+    __shared__ float2 tin[2][64][COSTAS_CT + 1];
+    __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_CT + 1];
+    const int lane = threadIdx.x;
+    const int kbase = blockIdx.x * 64;
+    const int k = kbase + lane;
+    bool mine = k < K;
+    if (!FINAL && mine) mine = dirty[k] != 0;
+    if (!__any(mine)) return;
     const long long base = (long long)k * L;
-    const int cnt = (int)min((long long)L, n - base);
-    float2 s = S[k];
-    float phase = s.x, freq = s.y;
+    int cnt = 0;
+    float phase = 0.f, freq = 0.f;
+    if (mine) {
+        cnt = (int)min((long long)L, n - base);
+        float2 s = S[k];
+        phase = s.x;
+        freq = s.y;
+    }
     CostasTan t{1.f, 0.f, 0.f, 1.f};
-    const float2 *zp = z + base;
-    float2 *yp = y + base;
-    int i = 0;
-    for (; i + 2 <= cnt; i += 2) {
-        float4 v = *reinterpret_cast<const float4 *>(zp + i);
-        float y0r, y0i, y1r, y1i;
-        costas_step<!FINAL>(v.x, v.y, phase, freq, g, y0r, y0i, t);
-        costas_step<!FINAL>(v.z, v.w, phase, freq, g, y1r, y1i, t);
-        if (FINAL) *reinterpret_cast<float4 *>(yp + i) = make_float4(y0r, y0i, y1r, y1i);
+    const int nt = L / COSTAS_CT;
+    const int lrow = lane >> 2, lcol = (lane & 3) * 2;
+    float4 pre[4];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 16 + lrow;
+            const long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kbase + c < K) {
+                if (j + 1 < n) v = *reinterpret_cast<const float4 *>(z + j);
+                else if (j < n) { float2 u = z[j]; v.x = u.x; v.y = u.y; }
+            }
+            pre[it] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 16 + lrow;
+            tin[buf][c][lcol] = make_float2(pre[it].x, pre[it].y);
+            tin[buf][c][lcol + 1] = make_float2(pre[it].z, pre[it].w);
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int tile = 0; tile < nt; ++tile) {
+        const int cur = tile & 1;
+        if (tile + 1 < nt) fetch(tile + 1);
+        const int i0 = tile * COSTAS_CT;
+#pragma unroll
+        for (int i = 0; i < COSTAS_CT; ++i) {
+            float yr = 0.f, yi = 0.f;
+            if (i0 + i < cnt) {
+                float2 v = tin[cur][lane][i];
+                costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
+            }
+            if (FINAL) tout[lane][i] = make_float2(yr, yi);
+        }
+        if (FINAL) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = it * 16 + lrow;
+                const long long j = (long long)(kbase + c) * L + (long long)i0 + lcol;
+                if (kbase + c < K) {
+                    float2 a = tout[c][lcol], b = tout[c][lcol + 1];
+                    if (j + 1 < n) *reinterpret_cast<float4 *>(y + j) = make_float4(a.x, a.y, b.x, b.y);
+                    else if (j < n) y[j] = a;
+                }
+            }
+        }
+        if (tile + 1 < nt) stash(cur ^ 1);
+        __syncthreads();
     }
-    if (i < cnt) {
-        float2 v = zp[i];
-        float yr, yi;
-        costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
-        if (FINAL) yp[i] = make_float2(yr, yi);
-    }
+    if (!mine) return;
     if (FINAL) {
         if (k == K - 1) state_out[0] = make_float2(phase, freq);
     } else {
         E[k] = make_float2(phase, freq);
         J[k] = make_float4(t.pp, t.pf, t.fp, t.ff);
+        dirty[k] = 0;
     }
 }
 
 // ------------------------------------------------------------ hand-off solve
-// element k (0..K-2) describes boundary k+1: delta[k+1] = r_k + Jc_k delta[k]
-struct CostasMap { float a11, a12, a21, a22, b1, b2; int par; };
-
-struct CostasNewtonF {
-    typedef CostasMap T;
-    const float2 *S_ro;      // current start states
-    float2 *S;               // same buffer, written in the final phase
+// Policy for newton.h: the loop is pi-periodic in phase, so a residual of m*pi is
+// carried as a parity (aux) that shifts every later start by pi.
+struct CostasPolicy {
+    float2 *S;
     const float2 *E;
     const float4 *J;
-    float2 *dlin;            // delta of the un-gated solve, per boundary index
     int *dirty;
-    unsigned *counters;      // [0] changed, [1] not frozen, [2] max |r_phase| bits
+    unsigned *cnt;           // [0] changed, [1] not frozen, [2] max |r_phase| bits
     float trust_p, trust_f, tol_p, tol_f;
-    int phase;               // 0: write dlin, 1: gated solve + update
-    int K;
 
-    __device__ T identity() const { return T{1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0}; }
-    __device__ T combine(const T &lo, const T &hi) const
+    __device__ bool active(long long) const { return true; }
+    __device__ void residual(long long k, float &r1, float &r2, int &aux) const
     {
-        T r;
-        r.a11 = hi.a11 * lo.a11 + hi.a12 * lo.a21;
-        r.a12 = hi.a11 * lo.a12 + hi.a12 * lo.a22;
-        r.a21 = hi.a21 * lo.a11 + hi.a22 * lo.a21;
-        r.a22 = hi.a21 * lo.a12 + hi.a22 * lo.a22;
-        r.b1 = hi.a11 * lo.b1 + hi.a12 * lo.b2 + hi.b1;
-        r.b2 = hi.a21 * lo.b1 + hi.a22 * lo.b2 + hi.b2;
-        r.par = lo.par ^ hi.par;
-        return r;
-    }
-    __device__ bool cut(long long k) const
-    {
-        if (phase == 0) return false;
-        float2 d = dlin[k];
-        return !(fabsf(d.x) <= trust_p) || !(fabsf(d.y) <= trust_f);
-    }
-    __device__ T element(long long k) const
-    {
-        float2 e = E[k], s = S_ro[k + 1];
-        float rp = e.x - s.x, rf = e.y - s.y;
+        float2 e = E[k], s = S[k + 1];
+        float rp = e.x - s.x;
         float m = rintf(rp * (float)(1.0 / XR_PI_D));
-        rp -= m * (float)XR_PI_D;
-        float4 j = J[k];
-        T t;
-        if (cut(k)) { t.a11 = t.a12 = t.a21 = t.a22 = 0.f; }
-        else { t.a11 = j.x; t.a12 = j.y; t.a21 = j.z; t.a22 = j.w; }
-        t.b1 = rp; t.b2 = rf;
-        t.par = ((int)m) & 1;
-        return t;
+        r1 = rp - m * (float)XR_PI_D;
+        r2 = e.y - s.y;
+        aux = ((int)m) & 1;
     }
-    __device__ T reduce_run(long long i0, int cnt) const
+    __device__ float4 jac(long long k) const { return J[k]; }
+    __device__ bool outside_trust(float d1, float d2) const
     {
-        T m = identity();
-        for (int k = 0; k < cnt; ++k) m = combine(m, element(i0 + k));
-        return m;
+        return !(fabsf(d1) <= trust_p) || !(fabsf(d2) <= trust_f);
     }
-    __device__ void apply_run(long long i0, int cnt, const T &pre) const
+    __device__ void update(long long k, float j1, float j2, float n1, float n2, int aux_prefix, int aux_k,
+                           float r1, NewtonStat &st) const
     {
-        // delta[0] = 0 -> delta at boundary i0 is the offset part of the prefix
-        float dp = pre.b1, df = pre.b2;
-        int par = pre.par;
-        for (int q = 0; q < cnt; ++q) {
-            long long k = i0 + q;
-            T e = element(k);
-            float jp = e.a11 * dp + e.a12 * df;
-            float jf = e.a21 * dp + e.a22 * df;
-            float ndp = e.b1 + jp, ndf = e.b2 + jf;
-            if (phase == 0) {
-                dlin[k + 1] = make_float2(ndp, ndf);
-                if (k == 0) dlin[0] = make_float2(0.f, 0.f);
-            } else {
-                bool frozen = fabsf(ndp) <= tol_p && fabsf(ndf) <= tol_f && par == 0 && e.par == 0;
-                if (!frozen) {
-                    float2 ek = E[k];
-                    float2 nw = make_float2(ek.x + (par ? (float)XR_PI_D : 0.f) + jp, ek.y + jf);
-                    float2 old = S_ro[k + 1];
-                    atomicAdd(&counters[1], 1u);
-                    atomicMax(&counters[2], __float_as_uint(fabsf(e.b1)));
-                    if (nw.x != old.x || nw.y != old.y) {
-                        S[k + 1] = nw;
-                        dirty[k + 1] = 1;
-                        atomicAdd(&counters[0], 1u);
-                    }
-                }
-            }
-            dp = ndp; df = ndf;
-            par ^= e.par;
+        const int par = aux_prefix & 1;
+        const bool frozen = fabsf(n1) <= tol_p && fabsf(n2) <= tol_f && par == 0 && (aux_k & 1) == 0;
+        if (frozen) return;
+        float2 ek = E[k];
+        float2 nw = make_float2(ek.x + (par ? (float)XR_PI_D : 0.f) + j1, ek.y + j2);
+        float2 old = S[k + 1];
+        st.open_ += 1;
+        st.max_r = fmaxf(st.max_r, fabsf(r1));
+        st.sum_sq += r1 * r1;
+        if (nw.x != old.x || nw.y != old.y) {
+            S[k + 1] = nw;
+            dirty[k + 1] = 1;
+            st.changed += 1;
         }
     }
 };
@@ -261,11 +275,11 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 {
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;
-    if (L & 1) ++L;
+    L = (L + COSTAS_CT - 1) / COSTAS_CT * COSTAS_CT;   // whole LDS tiles per chain
     max_passes = max_passes_ > 0 ? max_passes_ : 32;
     XR_TRY(state.reserve(2 * sizeof(float2)));
     XR_HIP(hipMemset(state.p, 0, 2 * sizeof(float2)));
-    XR_TRY(counters.reserve(8 * sizeof(unsigned)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 2) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
     cur = 0;
     return XRIT_OK;
@@ -305,7 +319,7 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(flags.reserve((size_t)K * sizeof(int)));
     const int nbK = scan_blocks(K);
-    const size_t agg_bytes = (((size_t)(nbK + 2) * sizeof(CostasMap)) + 15) & ~(size_t)15;
+    const size_t agg_bytes = (((size_t)(2 * newton_blocks(K) + 4) * sizeof(AffMap)) + 15) & ~(size_t)15;
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
     const unsigned gridK = div_up((size_t)K, 64);
@@ -326,10 +340,16 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
                                L, gains);
             hipLaunchKernelGGL(fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, flags.as<int>(), 1, K);
         }
-        CostasNewtonF nf{S.as<float2>(), S.as<float2>(), E.as<float2>(), J.as<float4>(), dlin.as<float2>(),
-                         flags.as<int>(), counters.as<unsigned>(), trust, trust / 256.0f, tol_phase, tol_freq, 0, K};
         const long long nel = K - 1;
-        const int nbE = scan_blocks(nel);
+        const int nbE = newton_blocks(nel);
+        AffMap *aggs = work.as<AffMap>();
+        unsigned *cnt_all = counters.as<unsigned>();
+        XR_HIP(hipMemsetAsync(cnt_all, 0, (size_t)(max_passes + 1) * 8 * sizeof(unsigned), s));
+        CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), cnt_all, trust,
+                         trust / 256.0f, tol_phase, tol_freq};
+        (void)nbE;
+        // the first passes always run; after that the host looks at the change counter of each pass
+        const int blind = max_passes < 3 ? max_passes : 3;
         for (int p = 0; p < max_passes; ++p) {
             {
                 ProfScope ps(prof, "costas_pass", s);
@@ -338,29 +358,35 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
             }
             {
                 ProfScope ps(prof, "costas_solve", s);
-                XR_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned), s));
-                nf.phase = 0;
-                hipLaunchKernelGGL(scan_reduce_kernel<CostasNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<CostasMap>());
-                hipLaunchKernelGGL(scan_aggs_kernel<CostasNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
-                                   work.as<CostasMap>(), nbE);
-                hipLaunchKernelGGL(scan_apply_kernel<CostasNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<CostasMap>());
-                nf.phase = 1;
-                hipLaunchKernelGGL(scan_reduce_kernel<CostasNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<CostasMap>());
-                hipLaunchKernelGGL(scan_aggs_kernel<CostasNewtonF>, dim3(1), dim3(SCAN_BLOCK), 0, s, nf,
-                                   work.as<CostasMap>(), nbE);
-                hipLaunchKernelGGL(scan_apply_kernel<CostasNewtonF>, dim3(nbE), dim3(SCAN_BLOCK), 0, s, nf, nel,
-                                   work.as<CostasMap>());
+                pol.cnt = cnt_all + (size_t)p * 8;
+                if (newton_solve(pol, nel, aggs, dlin.as<float2>(), s) != 0) {
+                    set_error("Costas hand-off: %d chains exceed the solver's block budget", K);
+                    return XRIT_E_INVALID;
+                }
             }
-            XR_HIP(hipMemcpyAsync(h_counters, counters.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
             ++passes;
+            if (p + 1 < blind) continue;
+            XR_HIP(hipMemcpyAsync(h_counters, pol.cnt, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
             unconverged = h_counters[1];
             uint32_t bits = h_counters[2];
             memcpy(&max_residual, &bits, sizeof(float));
             if (h_counters[0] == 0) { unconverged = 0; break; }
+            // what is still open sits within a factor two of the tolerance: accept it
+            if (max_residual <= 2.0f * tol_phase) { unconverged = 0; break; }
+        }
+        if (getenv("XRIT_TRACE")) {
+            std::vector<unsigned> hc((size_t)passes * 8);
+            XR_HIP(hipMemcpyAsync(hc.data(), cnt_all, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
+            for (int p = 0; p < passes; ++p) {
+                float mr, q;
+                memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
+                memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+                fprintf(stderr, "[xrit] %s pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", "costas", p, K,
+                        hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
+                        hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
+            }
         }
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(float2), hipMemcpyDeviceToDevice, s));

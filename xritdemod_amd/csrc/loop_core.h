@@ -142,16 +142,16 @@ struct ClockState {
     cf32 c0, c1;   // their 0/1 slicer decisions
 };
 
-// One symbol.  x points at the sample buffer base, table at the 129x8 MMSE taps.
+// One symbol.  w points at the 8-sample window x[ii .. ii+7] (global memory or an
+// LDS copy of it), table at the 129x8 MMSE taps.
 template <typename TableT>
-XR_HD cf32 clock_step(const cf32 *x, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
+XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
 {
     cf32 p2 = s.p1, p1 = s.p0;
     cf32 c2 = s.c1, c1 = s.c0;
     int imu = (int)rintf(s.mu * (float)XR_MM_NSTEPS);
     if (arm_out) *arm_out = imu;
     const TableT *row = table + imu * XR_MM_NTAPS;
-    const cf32 *w = x + s.ii;
     float ar = 0.0f, ai = 0.0f;
 #pragma unroll
     for (int k = 0; k < XR_MM_NTAPS; ++k) {
@@ -178,6 +178,13 @@ XR_HD cf32 clock_step(const cf32 *x, const TableT *table, ClockState &s, const C
     s.p1 = p1; s.p0 = p0;
     s.c1 = c1; s.c0 = c0;
     return p0;
+}
+
+// x points at the sample buffer base
+template <typename TableT>
+XR_HD cf32 clock_step(const cf32 *x, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
+{
+    return clock_step_w(x + s.ii, table, s, par, arm_out);
 }
 
 // t += dt on the (ii, mu) pair

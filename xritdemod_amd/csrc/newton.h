@@ -1,0 +1,238 @@
+// newton.h -- the chain-boundary hand-off solve shared by the Costas and clock loops.
+//
+// Multiple shooting: chain k maps its start state S[k] to an end state E[k] with
+// Jacobian J[k] (2x2).  With r_k = E[k] - S[k+1] (after removing the loop's
+// exact symmetry: multiples of pi in phase / whole symbols in time, carried as an
+// integer "aux") one Newton step solves
+//        delta[k+1] = r_k + Jc_k delta[k],   delta[0] = 0
+// which is a prefix scan of 2x2 affine maps.  Jc_k = J_k, or 0 where the
+// un-gated solution delta_lin[k] is outside the trust region (the linearisation
+// of a chain whose start is that far off is not believed; such a boundary gets
+// the plain continuity hand-off).  Three launches per pass:
+//   A  per-block reduce of the un-gated maps                         -> agg0
+//   B  un-gated scan (delta_lin), gated maps built on the fly, reduce -> agg1
+//   C  gated scan, per-boundary update through the loop's policy P
+// Block prefixes come from an in-kernel look-back over the (<= NEWTON_MAX_BLOCKS)
+// block aggregates, so there is no separate aggregate-scan launch.
+//
+// Policy P (device-callable members):
+//   bool   P::active(k)                   chain k produced something (else: pass state through)
+//   void   P::residual(k, float& r1, float& r2, int& aux)
+//   float4 P::jac(k)                      (a11, a12, a21, a22)
+//   bool   P::outside_trust(d1, d2)
+//   void   P::update(k, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
+//   unsigned* P::cnt                      this pass's counter slot
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace xrit {
+
+constexpr int NEWTON_BLOCK = 256;
+constexpr int NEWTON_IPT = 4;
+constexpr int NEWTON_TILE = NEWTON_BLOCK * NEWTON_IPT;
+constexpr int NEWTON_MAX_BLOCKS = 4096;
+
+struct AffMap { float a11, a12, a21, a22, b1, b2; int aux; };
+
+// per-pass statistics, reduced per block before touching global memory
+struct NewtonStat {
+    unsigned changed, open_, large;
+    float max_r, sum_sq;
+};
+// counter slot layout: [0] changed, [1] not frozen, [2] max |r1| bits, [3] large, [4] sum r1^2 (float)
+
+__device__ __forceinline__ AffMap aff_identity() { return AffMap{1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0}; }
+
+// lo first, then hi
+__device__ __forceinline__ AffMap aff_combine(const AffMap &lo, const AffMap &hi)
+{
+    AffMap r;
+    r.a11 = hi.a11 * lo.a11 + hi.a12 * lo.a21;
+    r.a12 = hi.a11 * lo.a12 + hi.a12 * lo.a22;
+    r.a21 = hi.a21 * lo.a11 + hi.a22 * lo.a21;
+    r.a22 = hi.a21 * lo.a12 + hi.a22 * lo.a22;
+    r.b1 = hi.a11 * lo.b1 + hi.a12 * lo.b2 + hi.b1;
+    r.b2 = hi.a21 * lo.b1 + hi.a22 * lo.b2 + hi.b2;
+    r.aux = lo.aux + hi.aux;
+    return r;
+}
+
+// inclusive scan over the block; returns this thread's inclusive value, buf[] holds all of them
+__device__ __forceinline__ AffMap aff_block_scan(AffMap v, AffMap *buf)
+{
+    const int t = threadIdx.x;
+    buf[t] = v;
+    __syncthreads();
+    for (int off = 1; off < NEWTON_BLOCK; off <<= 1) {
+        AffMap lo = aff_identity();
+        const bool has = t >= off;
+        if (has) lo = buf[t - off];
+        __syncthreads();
+        if (has) {
+            v = aff_combine(lo, v);
+            buf[t] = v;
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// prefix of all blocks before blockIdx.x, computed cooperatively from the aggregate array
+__device__ __forceinline__ AffMap aff_lookback(const AffMap *aggs, AffMap *buf)
+{
+    const int nb = blockIdx.x;
+    const int t = threadIdx.x;
+    const int run = (nb + NEWTON_BLOCK - 1) / NEWTON_BLOCK;
+    const int b0 = t * run, b1 = min(nb, b0 + run);
+    AffMap v = aff_identity();
+    for (int b = b0; b < b1; ++b) v = aff_combine(v, aggs[b]);
+    aff_block_scan(v, buf);
+    AffMap total = buf[NEWTON_BLOCK - 1];
+    __syncthreads();
+    return total;
+}
+
+template <typename P>
+__device__ __forceinline__ AffMap newton_element(const P &p, long long k, bool cut)
+{
+    AffMap m = aff_identity();
+    if (!p.active(k)) {
+        m.a11 = m.a22 = 0.f;    // nothing to hand over beyond the end of the data
+        return m;
+    }
+    float r1, r2;
+    int aux;
+    p.residual(k, r1, r2, aux);
+    if (cut) { m.a11 = m.a12 = m.a21 = m.a22 = 0.f; }
+    else {
+        float4 j = p.jac(k);
+        m.a11 = j.x; m.a12 = j.y; m.a21 = j.z; m.a22 = j.w;
+    }
+    m.b1 = r1; m.b2 = r2; m.aux = aux;
+    return m;
+}
+
+template <typename P>
+__global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long long n, AffMap *agg0)
+{
+    __shared__ AffMap buf[NEWTON_BLOCK];
+    const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
+    AffMap v = aff_identity();
+    for (int q = 0; q < NEWTON_IPT; ++q)
+        if (i0 + q < n) v = aff_combine(v, newton_element(p, i0 + q, false));
+    v = aff_block_scan(v, buf);
+    if (threadIdx.x == NEWTON_BLOCK - 1) agg0[blockIdx.x] = v;
+}
+
+template <typename P>
+__global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long long n, const AffMap *agg0, AffMap *agg1,
+                                                                   float2 *dlin)
+{
+    __shared__ AffMap buf[NEWTON_BLOCK];
+    const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
+    AffMap pre = aff_lookback(agg0, buf);
+    AffMap e[NEWTON_IPT];
+    AffMap v = aff_identity();
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        e[q] = (i0 + q < n) ? newton_element(p, i0 + q, false) : aff_identity();
+        v = aff_combine(v, e[q]);
+    }
+    aff_block_scan(v, buf);
+    if (threadIdx.x > 0) pre = aff_combine(pre, buf[threadIdx.x - 1]);
+    __syncthreads();
+    // delta_lin at the start of this thread's run is the offset of the prefix map (delta[0] = 0)
+    float d1 = pre.b1, d2 = pre.b2;
+    AffMap g = aff_identity();
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        if (i0 + q >= n) break;
+        dlin[i0 + q] = make_float2(d1, d2);
+        AffMap m = e[q];
+        if (p.outside_trust(d1, d2)) { m.a11 = m.a12 = m.a21 = m.a22 = 0.f; }
+        g = aff_combine(g, m);
+        float n1 = e[q].a11 * d1 + e[q].a12 * d2 + e[q].b1;
+        float n2 = e[q].a21 * d1 + e[q].a22 * d2 + e[q].b2;
+        d1 = n1; d2 = n2;
+    }
+    g = aff_block_scan(g, buf);
+    if (threadIdx.x == NEWTON_BLOCK - 1) agg1[blockIdx.x] = g;
+}
+
+template <typename P>
+__global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg1,
+                                                                    const float2 *dlin)
+{
+    __shared__ AffMap buf[NEWTON_BLOCK];
+    const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
+    AffMap pre = aff_lookback(agg1, buf);
+    AffMap e[NEWTON_IPT];
+    AffMap v = aff_identity();
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        if (i0 + q < n) {
+            float2 dl = dlin[i0 + q];
+            e[q] = newton_element(p, i0 + q, p.outside_trust(dl.x, dl.y));
+        } else {
+            e[q] = aff_identity();
+        }
+        v = aff_combine(v, e[q]);
+    }
+    aff_block_scan(v, buf);
+    if (threadIdx.x > 0) pre = aff_combine(pre, buf[threadIdx.x - 1]);
+    float d1 = pre.b1, d2 = pre.b2;
+    int aux = pre.aux;
+    NewtonStat st{0u, 0u, 0u, 0.f, 0.f};
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        const long long k = i0 + q;
+        if (k >= n) break;
+        float j1 = e[q].a11 * d1 + e[q].a12 * d2;
+        float j2 = e[q].a21 * d1 + e[q].a22 * d2;
+        float n1 = e[q].b1 + j1, n2 = e[q].b2 + j2;
+        p.update(k, j1, j2, n1, n2, aux, e[q].aux, e[q].b1, st);
+        d1 = n1; d2 = n2;
+        aux += e[q].aux;
+    }
+    // one set of atomics per block
+    for (int off = 32; off > 0; off >>= 1) {
+        st.changed += __shfl_down(st.changed, off, 64);
+        st.open_ += __shfl_down(st.open_, off, 64);
+        st.large += __shfl_down(st.large, off, 64);
+        st.max_r = fmaxf(st.max_r, __shfl_down(st.max_r, off, 64));
+        st.sum_sq += __shfl_down(st.sum_sq, off, 64);
+    }
+    __shared__ NewtonStat wst[NEWTON_BLOCK / 64];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wst[threadIdx.x >> 6] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        NewtonStat t = wst[0];
+        for (int w = 1; w < NEWTON_BLOCK / 64; ++w) {
+            t.changed += wst[w].changed; t.open_ += wst[w].open_; t.large += wst[w].large;
+            t.max_r = fmaxf(t.max_r, wst[w].max_r); t.sum_sq += wst[w].sum_sq;
+        }
+        if (t.changed) atomicAdd(&p.cnt[0], t.changed);
+        if (t.open_) {
+            atomicAdd(&p.cnt[1], t.open_);
+            atomicMax(&p.cnt[2], __float_as_uint(t.max_r));
+            atomicAdd(reinterpret_cast<float *>(&p.cnt[4]), t.sum_sq);
+        }
+        if (t.large) atomicAdd(&p.cnt[3], t.large);
+    }
+}
+
+static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
+
+// agg storage: 2 * (blocks + 1) AffMaps; dlin: n + 1 float2
+template <typename P>
+static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dlin, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    const int nb = newton_blocks(n);
+    if (nb > NEWTON_MAX_BLOCKS) return -1;
+    AffMap *agg0 = aggs, *agg1 = aggs + nb + 1;
+    hipLaunchKernelGGL(newton_reduce_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0);
+    hipLaunchKernelGGL(newton_gate_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin);
+    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg1, dlin);
+    return 0;
+}
+
+}  // namespace xrit
