@@ -127,32 +127,54 @@ def main():
     value = total_samples / elapsed / 1e6
     b_alg = 8.0 + 4.0 / (D * sps)          # read cf32 once + one f32 soft symbol per symbol
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream)
+    # ---- roofline (HIP events recorded by the library on the launch stream, around every launch)
+    # Algorithmic bytes each kernel has to move per INPUT sample of the burst (cf32 = 8 B; circuit-rate
+    # samples are 1/D of the input samples, symbols 1/(D*sps)); DESIGN.md section 5 derives them.
+    c8 = 8.0 / D
+    own_bytes = {
+        "fir_decim": 8.0 + c8,            # read the input once, write the decimated stream
+        "agc_reduce": c8, "agc_apply": 2 * c8, "fir_rrc": 2 * c8,
+        "costas_guess": c8, "costas_pass": c8, "costas_final": 2 * c8,
+        "clock_guess": c8, "clock_pass_jac": c8, "clock_pass": c8, "clock_output": c8 + 4.0 / (D * sps),
+    }
     roofline = None
     kernels = {}
     if prof:
         for name, ms, cnt in prof:
-            kernels[name] = {"total_ms": round(ms, 4), "launches": cnt}
-        dom = max(prof, key=lambda r: r[1])
-        launches_per_step = dom[2] / K
+            avg = ms / cnt
+            k = {"total_ms": round(ms, 4), "launches": cnt, "avg_launch_ms": round(avg, 4)}
+            if name in own_bytes:
+                gbs = own_bytes[name] * n_burst / (avg * 1e-3) / 1e9
+                k["algorithmic_bytes_per_launch"] = own_bytes[name] * n_burst
+                k["achieved_gbs"] = round(gbs, 1)
+                k["hbm_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+            kernels[name] = k
+        dom = max(prof, key=lambda r: r[1])            # largest share of the step time
         avg_ms = dom[1] / dom[2]
-        # one launch of the dominant kernel covers the whole burst when it is launched once per step;
-        # kernels launched several times per step (hand-off passes) are priced per launch on the burst they sweep
-        bytes_per_launch = b_alg * n_burst
+        bytes_per_launch = own_bytes.get(dom[0], c8) * n_burst
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        fd = kernels.get("fir_decim")
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": dom[2] / K,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "chain_achieved": round(b_alg * n_burst * K / (elapsed) / 1e9, 1),
+                    # the whole chain: SURVEY.md 8(d) bytes per input sample x samples per step / step time
+                    "chain_achieved": round(b_alg * n_burst * K / elapsed / 1e9, 1),
                     "chain_frac": round(b_alg * n_burst * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)}
+        if fd:
+            # the one kernel that touches the input, priced with the chain's per-sample figure
+            a = b_alg * n_burst / (fd["avg_launch_ms"] * 1e-3) / 1e9
+            roofline["input_kernel"] = {"kernel": "fir_decim", "achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4),
+                                        "algorithmic_bytes_per_launch": b_alg * n_burst,
+                                        "avg_launch_ms": fd["avg_launch_ms"]}
         tpath = os.path.join(HERE, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if dom[0] in tj and tj[dom[0]].get("burst_log2") == args.burst_log2:
-                    roofline["traffic"] = tj[dom[0]]["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = tj[dom[0]].get("source")
+                ent = tj.get(dom[0])
+                if ent and ent.get("burst_log2") == args.burst_log2:
+                    roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = ent.get("source")
             except Exception:
                 pass
 
