@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--cpu-sample-log2", type=int, default=27, help="log2 of samples timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
+    ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +79,8 @@ def main():
                                     stream=stream.cuda_stream)
     torch.cuda.synchronize(dev)
 
-    cfg = xa.Demodulator.config("lrit", fs_in, D, device=local_rank)
+    cfg = xa.Demodulator.config("lrit", fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
+                                clock_chain_syms=args.clock_chain)
     dem = xa.Demodulator(cfg)
     sps = dem.sps
     cap = int(n_burst / (D * sps * 0.99)) + 64

@@ -268,11 +268,22 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         clock_tile_fill<NV, WP>(t, x, N, W, WS);
         __syncthreads();
         const int lim = min(SS, NS - s0);
-        for (int i = 0; i < lim; ++i) {
-            if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
-            if (alive) {
-                clock_step_tiled(t, lane, x, W, WS, s, par);
-                ++produced;
+        // fast path: every lane of the wave is running, stays inside its staged window for the whole
+        // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only
+        const long long off0 = s.ii - t.wb[lane];
+        const int A = W - XR_MM_NTAPS - 1;      // bound on the read-index advance over SS symbols
+        const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
+        if (__all(safe)) {
+            const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS) - t.wb[lane];
+            for (int i = 0; i < SS; ++i) clock_step_w(rowp + s.ii, t.table, s, par);
+            produced += SS;
+        } else {
+            for (int i = 0; i < lim; ++i) {
+                if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
+                if (alive) {
+                    clock_step_tiled(t, lane, x, W, WS, s, par);
+                    ++produced;
+                }
             }
         }
         __syncthreads();
@@ -336,12 +347,24 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
             clock_tile_fill<1, WP>(t, x, N, W, WS);
             __syncthreads();
             const int lim = min(SS, olim - s0);
-            for (int i = 0; i < lim; ++i) {
-                if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
-                if (alive) {
-                    cf32 p = clock_step_tiled(t, lane, x, W, WS, s, par);
+            const long long off0 = s.ii - t.wb[lane];
+            const int A = W - XR_MM_NTAPS - 1;
+            const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
+            if (__all(safe)) {
+                const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS) - t.wb[lane];
+                for (int i = 0; i < SS; ++i) {
+                    cf32 p = clock_step_w(rowp + s.ii, t.table, s, par);
                     otile[lane][s0 + i] = make_float2(p.x, p.y);
-                    ++produced;
+                }
+                produced += SS;
+            } else {
+                for (int i = 0; i < lim; ++i) {
+                    if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
+                    if (alive) {
+                        cf32 p = clock_step_tiled(t, lane, x, W, WS, s, par);
+                        otile[lane][s0 + i] = make_float2(p.x, p.y);
+                        ++produced;
+                    }
                 }
             }
             __syncthreads();

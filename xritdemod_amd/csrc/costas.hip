@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     if (mine) {
         cnt = (int)min((long long)L, n - base);
         float2 s = S[k];
-        phase = s.x;
+        phase = costas_prewrap(s.x);
         freq = s.y;
     }
     CostasTan t{1.f, 0.f, 0.f, 1.f};
@@ -184,14 +184,25 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
         const int cur = tile & 1;
         if (tile + 1 < nt) fetch(tile + 1);
         const int i0 = tile * COSTAS_CT;
+        if (__all(!mine || i0 + COSTAS_CT <= cnt)) {
+            // every chain of the wave has the whole tile: no per-sample guard (idle lanes compute on zeros)
 #pragma unroll
-        for (int i = 0; i < COSTAS_CT; ++i) {
-            float yr = 0.f, yi = 0.f;
-            if (i0 + i < cnt) {
+            for (int i = 0; i < COSTAS_CT; ++i) {
+                float yr, yi;
                 float2 v = tin[cur][lane][i];
                 costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
+                if (FINAL) tout[lane][i] = make_float2(yr, yi);
             }
-            if (FINAL) tout[lane][i] = make_float2(yr, yi);
+        } else {
+#pragma unroll
+            for (int i = 0; i < COSTAS_CT; ++i) {
+                float yr = 0.f, yi = 0.f;
+                if (i0 + i < cnt) {
+                    float2 v = tin[cur][lane][i];
+                    costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
+                }
+                if (FINAL) tout[lane][i] = make_float2(yr, yi);
+            }
         }
         if (FINAL) {
             __syncthreads();

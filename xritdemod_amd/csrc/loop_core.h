@@ -85,6 +85,34 @@ XR_HD CostasGains costas_gains(float loop_bw)
     return g;
 }
 
+// sin and cos of a loop phase (|x| stays within a few multiples of pi): quadrant
+// reduction with a two-term Cody-Waite split of pi/2, then the classic degree-7/8
+// kernels on [-pi/4, pi/4].  About 25 instructions and within 2 ulp, against the
+// ~150 of the library routine whose argument reduction must cover all floats --
+// the loop is issue bound on this call.
+XR_HD void loop_sincos(float x, float &s, float &c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float k = rintf(x * 0.636619772367581343f);          // x * 2/pi
+    float r = fmaf(-k, 1.57079637050628662109375f, x);         // pi/2 high part
+    r = fmaf(-k, -4.37113900018624283e-8f, r);                 // pi/2 low part
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    const float sn = fmaf(r * r2, sp, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    const float cs = fmaf(r2 * r2, cp, fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cs : sn;
+    const float cc = (q & 1) ? sn : cs;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+#else
+    ::sincosf(x, &s, &c);
+#endif
+}
+
 // tangent of (phase, freq) w.r.t. the chain's start (phase0, freq0)
 struct CostasTan { float pp, pf, fp, ff; };
 
@@ -93,11 +121,7 @@ XR_HD void costas_step(float zr, float zi, float &phase, float &freq, const Cost
                        float &yr, float &yi, CostasTan &t)
 {
     float s, c;
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincosf(-phase, &s, &c);
-#else
-    ::sincosf(-phase, &s, &c);
-#endif
+    loop_sincos(-phase, s, c);
     yr = zr * c - zi * s;
     yi = zr * s + zi * c;
     float err = yr * yi;
@@ -115,15 +139,25 @@ XR_HD void costas_step(float zr, float zi, float &phase, float &freq, const Cost
         t.pp = npp;
         t.pf = npf;
     }
-    while (phase > XR_TWOPI_F) phase -= XR_TWOPI_F;
-    while (phase < -XR_TWOPI_F) phase += XR_TWOPI_F;
-    if (freq > 1.0f) {
-        freq = 1.0f;
-        if (TANGENT) { t.fp = 0.0f; t.ff = 0.0f; }
-    } else if (freq < -1.0f) {
-        freq = -1.0f;
-        if (TANGENT) { t.fp = 0.0f; t.ff = 0.0f; }
+    // phase_wrap(): the upstream while-loops run at most once per sample here, because a step moves the phase
+    // by less than |freq| + alpha <= 1.02 rad and costas_prewrap() has put the start value in range
+    phase = phase > XR_TWOPI_F ? phase - XR_TWOPI_F : phase;
+    phase = phase < -XR_TWOPI_F ? phase + XR_TWOPI_F : phase;
+    // frequency_limit()
+    const bool clamped = (freq > 1.0f) | (freq < -1.0f);
+    freq = fminf(fmaxf(freq, -1.0f), 1.0f);
+    if (TANGENT) {
+        t.fp = clamped ? 0.0f : t.fp;
+        t.ff = clamped ? 0.0f : t.ff;
     }
+}
+
+// bring a start phase (a guess may sit a few pi away) into the range the per-sample wrap assumes
+XR_HD float costas_prewrap(float phase)
+{
+    while (phase > XR_TWOPI_F + 1.5f) phase -= XR_TWOPI_F;
+    while (phase < -XR_TWOPI_F - 1.5f) phase += XR_TWOPI_F;
+    return phase;
 }
 
 // ---------------------------------------------------- Mueller & Mueller ----
