@@ -70,6 +70,8 @@ struct ClkUnwrapF {
     double *cnt;      // out: symbol count (continuous) at block centres
     int nb;
     double sps;
+    double off;       // block b covers buffer samples [off + b*BL, off + (b+1)*BL)
+    int BL;
     __device__ T identity() const { return 0.0; }
     __device__ T combine(const T &lo, const T &hi) const { return lo + hi; }
     __device__ double ang(long long b) const
@@ -96,18 +98,18 @@ struct ClkUnwrapF {
         double s = pre;
         for (int k = 0; k < n; ++k) {
             s += diff(i0 + k);
-            double cb = ((double)(i0 + k) + 0.5) * CLK_OM_BLOCK;
+            double cb = off + ((double)(i0 + k) + 0.5) * BL;
             cnt[i0 + k] = (cb + s / (2.0 * XR_PI_D) * sps) / sps;
         }
     }
 };
 
-__device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double sps, double t)
+__device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double sps, double t, double off, int BL)
 {
-    double fb = t / CLK_OM_BLOCK - 0.5;
+    double fb = (t - off) / BL - 0.5;
     int b = (int)floor(fb);
     b = max(0, min(nb - 2, b));
-    if (nb < 2) return cnt[0] + (t - 0.5 * CLK_OM_BLOCK) / sps;
+    if (nb < 2) return cnt[0] + (t - off - 0.5 * BL) / sps;
     double c0 = cnt[b], c1 = cnt[b + 1];
     return c0 + (c1 - c0) * (fb - b);
 }
@@ -115,7 +117,8 @@ __device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double
 // start state of every chain from the unwrapped symbol-count curve
 __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, double sps, ClockState *__restrict__ S,
                                    const ClockState *__restrict__ carried, int K, int NS, float omega0,
-                                   const float2 *__restrict__ x, const float *__restrict__ table, long long ni)
+                                   const float2 *__restrict__ x, const float *__restrict__ table, long long ni,
+                                   double off, int BL)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -123,12 +126,12 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
     if (k == 0) { S[0] = s0; return; }
     double t0 = (double)s0.ii + (double)s0.mu;
     // the M&M read position t = ii+mu sits 3 samples before the interpolation instant
-    double ca = clk_count_at(cnt, nb, sps, t0) + 3.0 / sps;
+    double ca = clk_count_at(cnt, nb, sps, t0, off, BL) + 3.0 / sps;
     double target = rint(ca) + (double)k * NS;
     // invert the piecewise-linear count curve around the nominal position
-    double t = (target - cnt[0]) * sps + 0.5 * CLK_OM_BLOCK;
+    double t = (target - cnt[0]) * sps + off + 0.5 * BL;
     for (int it = 0; it < 4; ++it) {
-        double c = clk_count_at(cnt, nb, sps, t);
+        double c = clk_count_at(cnt, nb, sps, t, off, BL);
         t += (target - c) * sps;
     }
     t -= 3.0;
@@ -557,6 +560,18 @@ void ClockStage::release()
     h_counters = nullptr;
 }
 
+// The producer of this call's samples may deliver the timing-line statistic itself: nb blocks of BL samples,
+// block b covering buffer samples [offset + b*BL, ...).  Returns where to write it (double2 per block).
+double2 *ClockStage::om_slot(int nb, int BL, double offset)
+{
+    if (nb < 1 || om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))) != XRIT_OK) return nullptr;
+    om_ext = true;
+    om_nb = nb;
+    om_BL = BL;
+    om_offset = offset;
+    return om.as<double2>();
+}
+
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
     size_t need = (carry + n + 64) * sizeof(float2);
@@ -595,7 +610,11 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     // chain budget: the slowest admissible symbol clock plus slack
     const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
     const int K = (int)((double)N / (min_omega * NS)) + 3;
-    const int nb = (int)((N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
+    const bool ext = om_ext;          // statistic supplied by the producer of the samples (Costas final pass)
+    om_ext = false;
+    const int BL = ext ? om_BL : CLK_OM_BLOCK;
+    const double om_off = ext ? om_offset : 0.0;
+    const int nb = ext ? om_nb : (int)((N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
@@ -626,16 +645,17 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
-            hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, N, nb,
-                               1.0 / (double)sps);
-            ClkUnwrapF uf{X, cnt, nb, (double)sps};
+            if (!ext)
+                hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, N, nb,
+                                   1.0 / (double)sps);
+            ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL};
             hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(scan_aggs_kernel<ClkUnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbB);
             hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
-                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), ni);
+                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), ni, om_off, BL);
             hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, dirty, 1, K);
         }
         const long long nel = K - 1;

@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          const float2 *__restrict__ S, float2 *__restrict__ E,
                                                          float4 *__restrict__ J, int *__restrict__ dirty,
                                                          float2 *__restrict__ state_out, long long n, int L, int K,
-                                                         CostasGains g)
+                                                         CostasGains g, double2 *__restrict__ om, long long om_off,
+                                                         double inv_sps, float rot_c, float rot_s)
 {
     __shared__ float2 tin[2][64][COSTAS_CT + 1];
     __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_CT + 1];
@@ -153,6 +154,18 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
         freq = s.y;
     }
     CostasTan t{1.f, 0.f, 0.f, 1.f};
+    // FINAL with om != nullptr: the timing-line statistic of the clock-recovery guess, sum |y|^2 e^{-j 2 pi m / sps}
+    // over this chain (m = index in the clock-recovery input buffer), so that stage needs no sweep of its own.
+    // The phasor advances by a fixed rotation per sample, restarted per chain from a double-precision phase.
+    float om_c = 1.f, om_s = 0.f, om_r = 0.f, om_i = 0.f;
+    if (FINAL && om != nullptr && mine) {
+        double ph = (double)(om_off + base) * inv_sps;
+        ph -= floor(ph);
+        float sn, cs;
+        loop_sincos(-6.28318530717958647692f * (float)ph, sn, cs);
+        om_c = cs;
+        om_s = sn;
+    }
     const int nt = L / COSTAS_CT;
     const int lrow = lane >> 2, lcol = (lane & 3) * 2;
     float4 pre[4];
@@ -191,7 +204,15 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                 float yr, yi;
                 float2 v = tin[cur][lane][i];
                 costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
-                if (FINAL) tout[lane][i] = make_float2(yr, yi);
+                if (FINAL) {
+                    tout[lane][i] = make_float2(yr, yi);
+                    const float p = yr * yr + yi * yi;
+                    om_r = fmaf(p, om_c, om_r);
+                    om_i = fmaf(p, om_s, om_i);
+                    const float nc = om_c * rot_c - om_s * rot_s;
+                    om_s = om_c * rot_s + om_s * rot_c;
+                    om_c = nc;
+                }
             }
         } else {
 #pragma unroll
@@ -200,6 +221,14 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                 if (i0 + i < cnt) {
                     float2 v = tin[cur][lane][i];
                     costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
+                    if (FINAL) {
+                        const float p = yr * yr + yi * yi;
+                        om_r = fmaf(p, om_c, om_r);
+                        om_i = fmaf(p, om_s, om_i);
+                        const float nc = om_c * rot_c - om_s * rot_s;
+                        om_s = om_c * rot_s + om_s * rot_c;
+                        om_c = nc;
+                    }
                 }
                 if (FINAL) tout[lane][i] = make_float2(yr, yi);
             }
@@ -223,6 +252,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     if (!mine) return;
     if (FINAL) {
         if (k == K - 1) state_out[0] = make_float2(phase, freq);
+        if (om != nullptr) om[k] = make_double2((double)om_r, (double)om_i);
     } else {
         E[k] = make_float2(phase, freq);
         J[k] = make_float4(t.pp, t.pf, t.fp, t.ff);
@@ -296,6 +326,13 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     return XRIT_OK;
 }
 
+float2 *CostasStage::stat_slot(size_t n)
+{
+    const size_t K = (n + (size_t)L - 1) / (size_t)L;
+    if (stat.reserve((K + 1) * sizeof(float2)) != XRIT_OK) return nullptr;
+    return stat.as<float2>();
+}
+
 void CostasStage::release()
 {
     state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();
@@ -314,7 +351,8 @@ int CostasStage::get_state(float *phase, float *freq, hipStream_t s)
     return XRIT_OK;
 }
 
-int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)
+int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+                     double2 *om, long long om_off, double inv_sps)
 {
     passes = 0;
     unconverged = 0;
@@ -338,8 +376,9 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
-            hipLaunchKernelGGL(costas_stat_kernel, dim3(div_up((size_t)K, 4)), dim3(256), 0, s, in, stat.as<float2>(),
-                               (long long)n, L, K);
+            if (!stat_ready)
+                hipLaunchKernelGGL(costas_stat_kernel, dim3(div_up((size_t)K, 4)), dim3(256), 0, s, in, stat.as<float2>(),
+                                   (long long)n, L, K);
             UnwrapF uf{stat.as<float2>(), th2};
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
@@ -365,7 +404,8 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
             {
                 ProfScope ps(prof, "costas_pass", s);
                 hipLaunchKernelGGL(costas_pass_kernel<false>, dim3(gridK), dim3(64), 0, s, in, out, S.as<float2>(),
-                                   E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains);
+                                   E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains,
+                                   (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f);
             }
             {
                 ProfScope ps(prof, "costas_solve", s);
@@ -404,8 +444,10 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
     }
     {
         ProfScope ps(prof, "costas_final", s);
+        const double dth = -2.0 * XR_PI_D * inv_sps;
         hipLaunchKernelGGL(costas_pass_kernel<true>, dim3(gridK), dim3(64), 0, s, in, out, S.as<float2>(),
-                           E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains);
+                           E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains, om, om_off,
+                           inv_sps, (float)cos(dth), (float)sin(dth));
     }
     XR_HIP(hipGetLastError());
     cur ^= 1;

@@ -236,11 +236,19 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     XR_TRY(keep_stage(d, 0, cur, length, s));
     XR_TRY(d->agc.run(cur, B, length, s, prof));                   // :143
     XR_TRY(keep_stage(d, 1, B, length, s));
-    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof)); // :148
+    // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
+    // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
+    const int L = d->costas.L;
+    float2 *stat = length ? d->costas.stat_slot(length) : nullptr;
+    const bool stat_ready = stat && d->rrc.stat_supported(L);
+    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof, stat_ready ? stat : nullptr, L)); // :148
     XR_TRY(keep_stage(d, 2, A, length, s));
     float2 *slot = nullptr;
     XR_TRY(d->clock.input_slot(length, &slot, s));
-    XR_TRY(d->costas.run(A, slot, length, s, prof));               // :152
+    const size_t carry0 = d->clock.carry;
+    double2 *om = nullptr;
+    if (length) om = d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L, (double)carry0);
+    XR_TRY(d->costas.run(A, slot, length, s, prof, stat_ready, om, (long long)carry0, 1.0 / (double)d->sps)); // :152
     XR_TRY(keep_stage(d, 3, slot, length, s));
     float2 *sym = nullptr;
     if (d->keep_stages) {

@@ -37,11 +37,15 @@ template <> struct SampleLoad<XRIT_SAMPLE_S8IQ> {
 
 // g: RC rows of Wpad taps, g[c][i] = h[T-1 + c*D - i] (0 outside), i.e. the tap
 // that sample i of a lane's window contributes to the lane's c-th output.
+// stat != nullptr (RRC stage of the chain): also leaves sum z^2 per run of statL outputs -- the
+// statistic the Costas guess needs -- so that no separate sweep over the filtered stream is required.
+// statL divides the outputs of a block, every run belongs to one block, and the partial sums are combined
+// in a fixed order (deterministic).
 template <int RC, bool PAD, int TYPE>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
-                 int tile_len)
+                 int tile_len, float2 *__restrict__ stat, int statL)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
@@ -110,6 +114,45 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
 #pragma unroll
     for (int c = 0; c < RC; ++c)
         if (m0 + c < n_out) out[m0 + c] = acc[c];
+    if (stat != nullptr) {
+        // per-thread partial sums of z^2, split where the thread's outputs cross into the next run
+        __syncthreads();                      // the window tile is dead: reuse it
+        float2 *pa = tile, *pb = tile + nthr;
+        const int o0 = tid * RC;              // first output of this thread inside the block
+        const int first_run = o0 / statL;
+        float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            if (m0 + c < n_out) {
+                float zr = acc[c].x, zi = acc[c].y;
+                float vr = zr * zr - zi * zi, vi = 2.0f * zr * zi;
+                if ((o0 + c) / statL == first_run) { a.x += vr; a.y += vi; }
+                else { b.x += vr; b.y += vi; }
+            }
+        }
+        pa[tid] = a;
+        pb[tid] = b;
+        __syncthreads();
+        // one wave per run (round robin), one partial per lane, fixed-order shuffle tree: deterministic
+        const int runs = (nthr * RC) / statL;
+        const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+        for (int j = wave; j < runs; j += nwaves) {
+            const int lo = j * statL, hi = lo + statL;              // outputs [lo, hi) of the block
+            const int t0 = lo / RC, t1 = min(nthr - 1, (hi - 1) / RC);
+            float sr = 0.f, si = 0.f;
+            for (int t = t0 + lane; t <= t1; t += 64) {
+                const int fr = (t * RC) / statL;
+                if (fr == j) { sr += pa[t].x; si += pa[t].y; }
+                else if (fr + 1 == j) { sr += pb[t].x; si += pb[t].y; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                sr += __shfl_down(sr, off, 64);
+                si += __shfl_down(si, off, 64);
+            }
+            const long long run = out_base / statL + j;
+            if (lane == 0 && run * statL < n_out) stat[run] = make_float2(sr, si);
+        }
+    }
 }
 
 // new history = last T-1 samples of (hist | in[0..n_in)), converted to float
@@ -171,6 +214,12 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     return XRIT_OK;
 }
 
+bool FirStage::stat_supported(int statL) const
+{
+    // runs must not straddle blocks, and the two partial arrays must fit in the window tile
+    return statL > 0 && !pad && (threads * RC) % statL == 0 && statL >= RC && (size_t)2 * threads * sizeof(float2) <= lds_bytes;
+}
+
 void FirStage::release()
 {
     g.release();
@@ -180,14 +229,14 @@ void FirStage::release()
 
 template <int RC, bool PAD>
 static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out, size_t n_out, size_t n_in,
-                        hipStream_t s)
+                        hipStream_t s, float2 *stat, int statL)
 {
     unsigned blocks = div_up(n_out, (size_t)f.threads * RC);
     const float2 *h = f.hist[f.cur].as<float2>();
     const float *g = f.g.as<float>();
 #define XR_FIR_GO(TY)                                                                                          \
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
-                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len)
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL)
     if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
@@ -196,14 +245,16 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     return XRIT_OK;
 }
 
-int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof)
+int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof, float2 *stat,
+                  int statL)
 {
+    if (stat && !stat_supported(statL)) stat = nullptr;
     size_t n_in = n_out * (size_t)D;
     if (n_out > 0) {
         ProfScope ps(prof, D > 1 ? "fir_decim" : "fir_rrc", s);
-        if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s)));
-        else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s)));
-        else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s)));
+        if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s, stat, statL)));
+        else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s, stat, statL)));
+        else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s, stat, statL)));
     }
     if (T > 1 && n_in > 0) {
         ProfScope ps(prof, "fir_hist", s);

@@ -17,7 +17,10 @@ struct FirStage {
     int init(const float *taps, int ntaps, int decim);
     void release();
     // consumes n_out*D samples of `in` (sample_type as in FrontendDevice.h:11-13)
-    int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof);
+    // stat (optional): sum z^2 per run of statL outputs, written when stat_supported(statL)
+    int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof,
+            float2 *stat = nullptr, int statL = 0);
+    bool stat_supported(int statL) const;
 };
 
 // ---- AGC (demodulator.cpp:447; Work at :143) ------------------------------
@@ -49,7 +52,11 @@ struct CostasStage {
     float max_residual = 0;
     int init(float loop_bw, int chain_len, int max_passes);
     void release();
-    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    // stat_ready: stat_slot(n) was filled by the producer (FIR epilogue); om (optional): receives the clock
+    // recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready = false,
+            double2 *om = nullptr, long long om_off = 0, double inv_sps = 0.0);
+    float2 *stat_slot(size_t n);
     int get_state(float *phase, float *freq, hipStream_t s);
 };
 
@@ -79,6 +86,10 @@ struct ClockStage {
     void release();
     // where the producer must write the n new samples of this call
     int input_slot(size_t n, float2 **slot, hipStream_t s);
+    double2 *om_slot(int nb, int BL, double offset);
+    bool om_ext = false;
+    int om_nb = 0, om_BL = 256;
+    double om_offset = 0;
     // soft (real parts) and/or complex symbols; either may be null
     int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
 };
