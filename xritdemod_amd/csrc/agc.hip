@@ -20,6 +20,7 @@ struct AgcScanF {
     float *state_out;        // [0] gain after the call, [1] guard flag
     float rate, ref, maxg;
     long long n;
+    int vec;                 // both buffers 16-byte aligned: 16-byte accesses for whole runs
 
     __device__ T identity() const { return agc_identity(); }
     __device__ T combine(const T &lo, const T &hi) const { return agc_compose(lo, hi); }
@@ -27,9 +28,17 @@ struct AgcScanF {
     {
         T m = agc_identity();
         bool bad = false;
+        float2 v[SCAN_IPT];
+        if (cnt == SCAN_IPT && vec) {
+            const float4 *xp = reinterpret_cast<const float4 *>(x + i0);
+            float4 a = xp[0], b = xp[1];
+            v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w);
+            v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
+        } else {
+            for (int k = 0; k < cnt; ++k) v[k] = x[i0 + k];
+        }
         for (int k = 0; k < cnt; ++k) {
-            float2 v = x[i0 + k];
-            T e = agc_sample_map(v.x, v.y, rate, ref, maxg);
+            T e = agc_sample_map(v[k].x, v[k].y, rate, ref, maxg);
             bad |= !(e.a >= 0.0f);
             m = agc_compose(m, e);
         }
@@ -39,11 +48,24 @@ struct AgcScanF {
     __device__ void apply_run(long long i0, int cnt, const T &pre) const
     {
         float g = agc_apply(pre, state_in[0]);
-        for (int k = 0; k < cnt; ++k) {
-            float2 v = x[i0 + k];
-            float yr, yi;
-            agc_step(v.x, v.y, g, rate, ref, maxg, yr, yi);
-            y[i0 + k] = make_float2(yr, yi);
+        if (cnt == SCAN_IPT && vec) {
+            // whole run: 16-byte loads and stores (i0 is a multiple of 4 samples)
+            const float4 *xp = reinterpret_cast<const float4 *>(x + i0);
+            float4 a = xp[0], b = xp[1], oa, ob;
+            agc_step(a.x, a.y, g, rate, ref, maxg, oa.x, oa.y);
+            agc_step(a.z, a.w, g, rate, ref, maxg, oa.z, oa.w);
+            agc_step(b.x, b.y, g, rate, ref, maxg, ob.x, ob.y);
+            agc_step(b.z, b.w, g, rate, ref, maxg, ob.z, ob.w);
+            float4 *yp = reinterpret_cast<float4 *>(y + i0);
+            yp[0] = oa;
+            yp[1] = ob;
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                float2 v = x[i0 + k];
+                float yr, yi;
+                agc_step(v.x, v.y, g, rate, ref, maxg, yr, yi);
+                y[i0 + k] = make_float2(yr, yi);
+            }
         }
         if (i0 + cnt == n) state_out[0] = g;
     }
@@ -95,8 +117,9 @@ int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profil
     float *sin_ = state.as<float>() + 2 * cur;
     float *sout = state.as<float>() + 2 * (cur ^ 1);
     int nb = scan_blocks((long long)n);
-    XR_TRY(aggs.reserve((size_t)(nb + 1) * sizeof(AgcMap)));
-    AgcScanF f{in, out, sin_, sout, rate, ref, maxg, (long long)n};
+    XR_TRY(aggs.reserve((size_t)(nb + scan_blocks(nb) + 4) * sizeof(AgcMap)));
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    AgcScanF f{in, out, sin_, sout, rate, ref, maxg, (long long)n, vec};
     {
         ProfScope ps(prof, "agc_reduce", s);
         hipLaunchKernelGGL(agc_begin_kernel, dim3(1), dim3(1), 0, s, sout);
@@ -105,7 +128,7 @@ int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profil
     }
     {
         ProfScope ps(prof, "agc_scan", s);
-        hipLaunchKernelGGL(scan_aggs_kernel<AgcScanF>, dim3(1), dim3(SCAN_BLOCK), 0, s, f, aggs.as<AgcMap>(), nb);
+        scan_aggs_launch(f, aggs.as<AgcMap>(), nb, s);
     }
     {
         ProfScope ps(prof, "agc_apply", s);

@@ -277,8 +277,10 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         const int A = W - XR_MM_NTAPS - 1;      // bound on the read-index advance over SS symbols
         const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
         if (__all(safe)) {
-            const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS) - t.wb[lane];
-            for (int i = 0; i < SS; ++i) clock_step_w(rowp + s.ii, t.table, s, par);
+            const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
+            int off = (int)off0;
+            for (int i = 0; i < SS; ++i) clock_step_rel(rowp, off, t.table, s, par);
+            s.ii = t.wb[lane] + off;
             produced += SS;
         } else {
             for (int i = 0; i < lim; ++i) {
@@ -354,11 +356,13 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
             const int A = W - XR_MM_NTAPS - 1;
             const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
             if (__all(safe)) {
-                const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS) - t.wb[lane];
+                const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
+                int off = (int)off0;
                 for (int i = 0; i < SS; ++i) {
-                    cf32 p = clock_step_w(rowp + s.ii, t.table, s, par);
+                    cf32 p = clock_step_rel(rowp, off, t.table, s, par);
                     otile[lane][s0 + i] = make_float2(p.x, p.y);
                 }
+                s.ii = t.wb[lane] + off;
                 produced += SS;
             } else {
                 for (int i = 0; i < lim; ++i) {

@@ -214,6 +214,44 @@ XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const
     return p0;
 }
 
+// Same step with the read index kept as a 32-bit offset into a staged window (row points at the
+// window's first sample): no 64-bit arithmetic on the per-symbol path.
+template <typename TableT>
+XR_HD cf32 clock_step_rel(const cf32 *row, int &off, const TableT *table, ClockState &s, const ClockPar &par)
+{
+    cf32 p2 = s.p1, p1 = s.p0;
+    cf32 c2 = s.c1, c1 = s.c0;
+    int imu = (int)rintf(s.mu * (float)XR_MM_NSTEPS);
+    const TableT *trow = table + imu * XR_MM_NTAPS;
+    const cf32 *w = row + off;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int k = 0; k < XR_MM_NTAPS; ++k) {
+        float tp = (float)trow[XR_MM_NTAPS - 1 - k];
+        cf32 v = w[k];
+        ar += tp * v.x;
+        ai += tp * v.y;
+    }
+    cf32 p0{ar, ai};
+    cf32 c0{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
+    float dcr = c0.x - c2.x, dci = c0.y - c2.y;
+    float xr = dcr * p1.x + dci * p1.y;
+    float dpr = p0.x - p2.x, dpi = p0.y - p2.y;
+    float yr = dpr * c1.x + dpi * c1.y;
+    float mm = yr - xr;
+    mm = bclip(mm, 1.0f);
+    float omega = s.omega + par.gain_omega * mm;
+    omega = par.omega_mid + bclip(omega - par.omega_mid, par.omega_lim);
+    float mu = s.mu + omega + par.gain_mu * mm;
+    float fl = floorf(mu);
+    off += (int)fl;
+    s.mu = mu - fl;
+    s.omega = omega;
+    s.p1 = p1; s.p0 = p0;
+    s.c1 = c1; s.c0 = c0;
+    return p0;
+}
+
 // x points at the sample buffer base
 template <typename TableT>
 XR_HD cf32 clock_step(const cf32 *x, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)

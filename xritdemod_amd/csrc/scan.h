@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_aggs_kernel(F f, typename F::
 {
     __shared__ typename F::T buf[SCAN_BLOCK];
     const int t = threadIdx.x;
-    const int run = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int run = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;   // dependent loads: keep nb small (scan_aggs_launch)
     const int b0 = t * run;
     const int b1 = min(nb, b0 + run);
     typename F::T v = f.identity();
@@ -90,5 +90,46 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(F f, long long n
 }
 
 static inline int scan_blocks(long long n) { return (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
+
+// the aggregates of a large scan are scanned with the same three kernels, one level up
+template <typename F>
+struct AggScanF {
+    typedef typename F::T T;
+    F f;
+    T *a;
+    __device__ T identity() const { return f.identity(); }
+    __device__ T combine(const T &lo, const T &hi) const { return f.combine(lo, hi); }
+    __device__ T reduce_run(long long i0, int cnt) const
+    {
+        T m = f.identity();
+        for (int k = 0; k < cnt; ++k) m = f.combine(m, a[i0 + k]);
+        return m;
+    }
+    __device__ void apply_run(long long i0, int cnt, const T &pre) const
+    {
+        T p = pre;
+        for (int k = 0; k < cnt; ++k) {
+            T e = a[i0 + k];
+            a[i0 + k] = p;
+            p = f.combine(p, e);
+        }
+    }
+};
+
+// aggs[0..nb) -> exclusive prefixes in place; aggs must have room for nb + scan_blocks(nb) + 2 elements
+template <typename F>
+static inline void scan_aggs_launch(const F &f, typename F::T *aggs, int nb, hipStream_t s)
+{
+    if (nb <= 4 * SCAN_BLOCK) {
+        hipLaunchKernelGGL(scan_aggs_kernel<F>, dim3(1), dim3(SCAN_BLOCK), 0, s, f, aggs, nb);
+        return;
+    }
+    const int nb2 = scan_blocks(nb);
+    typename F::T *lvl2 = aggs + nb + 1;
+    AggScanF<F> af{f, aggs};
+    hipLaunchKernelGGL(scan_reduce_kernel<AggScanF<F>>, dim3(nb2), dim3(SCAN_BLOCK), 0, s, af, (long long)nb, lvl2);
+    hipLaunchKernelGGL(scan_aggs_kernel<AggScanF<F>>, dim3(1), dim3(SCAN_BLOCK), 0, s, af, lvl2, nb2);
+    hipLaunchKernelGGL(scan_apply_kernel<AggScanF<F>>, dim3(nb2), dim3(SCAN_BLOCK), 0, s, af, (long long)nb, lvl2);
+}
 
 }  // namespace xrit
