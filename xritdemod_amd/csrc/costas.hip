@@ -127,6 +127,7 @@ __global__ void costas_head_kernel(const float2 *__restrict__ stat, float2 *__re
 // per-lane ds_read_b64 conflict free.  FINAL: write the de-rotated samples (through
 // the same kind of tile), no tangent.
 constexpr int COSTAS_CT = 8;
+constexpr int COSTAS_OT = 16 / COSTAS_CT;    // input tiles per output row of 16 samples (one 128-byte line)
 
 template <bool FINAL>
 __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restrict__ z, float2 *__restrict__ y,
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          double inv_sps, float rot_c, float rot_s)
 {
     __shared__ float2 tin[2][64][COSTAS_CT + 1];
-    __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_CT + 1];
+    __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_OT * COSTAS_CT + 1];   // one 128-byte row per chain
     const int lane = threadIdx.x;
     const int kbase = blockIdx.x * 64;
     const int k = kbase + lane;
@@ -167,12 +168,15 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
         om_s = sn;
     }
     const int nt = L / COSTAS_CT;
-    const int lrow = lane >> 2, lcol = (lane & 3) * 2;
-    float4 pre[4];
+    constexpr int LPR = COSTAS_CT / 2;            // lanes per chain row (16 bytes each)
+    constexpr int RPI = 64 / LPR;                 // rows per wave instruction
+    constexpr int NIT = 64 / RPI;
+    const int lrow = lane / LPR, lcol = (lane % LPR) * 2;
+    float4 pre[NIT];
     auto fetch = [&](int tile) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = it * 16 + lrow;
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * RPI + lrow;
             const long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kbase + c < K) {
@@ -184,8 +188,8 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = it * 16 + lrow;
+        for (int it = 0; it < NIT; ++it) {
+            const int c = it * RPI + lrow;
             tin[buf][c][lcol] = make_float2(pre[it].x, pre[it].y);
             tin[buf][c][lcol + 1] = make_float2(pre[it].z, pre[it].w);
         }
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                 float2 v = tin[cur][lane][i];
                 costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
                 if (FINAL) {
-                    tout[lane][i] = make_float2(yr, yi);
+                    tout[lane][(tile % COSTAS_OT) * COSTAS_CT + i] = make_float2(yr, yi);
                     const float p = yr * yr + yi * yi;
                     om_r = fmaf(p, om_c, om_r);
                     om_i = fmaf(p, om_s, om_i);
@@ -230,17 +234,21 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                         om_c = nc;
                     }
                 }
-                if (FINAL) tout[lane][i] = make_float2(yr, yi);
+                if (FINAL) tout[lane][(tile % COSTAS_OT) * COSTAS_CT + i] = make_float2(yr, yi);
             }
         }
-        if (FINAL) {
+        if (FINAL && ((tile % COSTAS_OT) == COSTAS_OT - 1 || tile + 1 == nt)) {
+            // 16 samples per chain = one full 128-byte line, 8 lanes per row
             __syncthreads();
+            const int ncol = ((tile % COSTAS_OT) + 1) * COSTAS_CT;
+            const int ob = i0 - (tile % COSTAS_OT) * COSTAS_CT;
+            const int orow = lane >> 3, ocol = (lane & 7) * 2;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int c = it * 16 + lrow;
-                const long long j = (long long)(kbase + c) * L + (long long)i0 + lcol;
-                if (kbase + c < K) {
-                    float2 a = tout[c][lcol], b = tout[c][lcol + 1];
+            for (int it = 0; it < 8; ++it) {
+                const int c = it * 8 + orow;
+                const long long j = (long long)(kbase + c) * L + (long long)ob + ocol;
+                if (kbase + c < K && ocol < ncol) {
+                    float2 a = tout[c][ocol], b = tout[c][ocol + 1];
                     if (j + 1 < n) *reinterpret_cast<float4 *>(y + j) = make_float4(a.x, a.y, b.x, b.y);
                     else if (j < n) y[j] = a;
                 }
