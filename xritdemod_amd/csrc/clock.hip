@@ -536,6 +536,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     min_passes = max_passes < 4 ? max_passes : 4;
     if (const char *e = getenv("XRIT_CLOCK_JAC_PASSES")) jac_passes = atoi(e);   // experiment knobs
     if (const char *e = getenv("XRIT_CLOCK_NS")) NS = atoi(e);
+    if (const char *e = getenv("XRIT_CLOCK_TOL")) { tol_t = (float)atof(e); tol_w = tol_t * 0.1f; }
     if (const char *e = getenv("XRIT_CLOCK_SS")) ss_override = atoi(e);
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
     design_mmse_table(tb.data());
@@ -700,11 +701,11 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
             // moving by that much for ever; what must close are the LARGE residuals (acquisition at the head of a
             // cold-started call, symbol slips: decision flips kick mu by up to ~2e-3, acquisition and slips leave
             // residuals >> 0.02 samples).  After that, keep going only while the summed squared residual still
-            // falls by > 40 % per pass.
+            // falls by > 45 % per pass.
             unsigned large = h_counters[3];
             float q;
             memcpy(&q, &h_counters[4], sizeof(float));
-            bool stalled = q > 0.6f * q_prev;
+            bool stalled = q > 0.55f * q_prev;
             q_prev = q;
             if (passes >= min_passes && large == 0 && stalled) break;
         }

