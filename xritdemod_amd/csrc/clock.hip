@@ -240,8 +240,10 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
                                                              const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
                                                              int *__restrict__ nrun, long long N, long long ni, int K,
-                                                             int NS, ClockPar par, int SS, int W, int WS)
+                                                             int NS, ClockPar par, int SS, int W, int WS,
+                                                             const int *__restrict__ ctl)
 {
+    if (ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 endv[NV > 1 ? 2 : 1][64];
     __shared__ long long ref_ii[64];
@@ -419,8 +421,9 @@ __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *
                                                               const int *__restrict__ terminal,
                                                               const ClockState *__restrict__ carried_in,
                                                               ClockState *__restrict__ carried_out,
-                                                              ClockResult *__restrict__ res, float2 *__restrict__ x,
-                                                              long long N, int K, int NS)
+                                                              ClockResult *__restrict__ res,
+                                                              const float2 *__restrict__ x,
+                                                              float2 *__restrict__ tail_out, long long N, int K, int NS)
 {
     __shared__ long long s_ii;
     if (threadIdx.x == 0) {
@@ -447,12 +450,35 @@ __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *
         carried_out[0] = s;
     }
     __syncthreads();
+    // the unread tail goes to its own buffer: the call's input stays intact until the call is committed
     const long long ii = s_ii;
     const long long carry = N - ii;
-    float2 v = make_float2(0.f, 0.f);
-    if (threadIdx.x < carry) v = x[ii + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < carry) x[threadIdx.x] = v;
+    if (threadIdx.x < carry) tail_out[threadIdx.x] = x[ii + threadIdx.x];
+}
+
+__global__ void __launch_bounds__(1024) clock_tail_kernel(const float2 *__restrict__ tail, float2 *__restrict__ x, int carry)
+{
+    if ((int)threadIdx.x < carry) x[threadIdx.x] = tail[threadIdx.x];
+}
+
+// After every solve: ctl[0] done, ctl[1] passes run, ctl[2] open boundaries, ctl[3] max residual (bits),
+// ctl[4] previous summed squared residual (bits).  The recurrence is chaotic at the 1e-5 level
+// (interpolator-arm quantisation), so boundaries keep moving by that much for ever; what must close are the
+// LARGE residuals (acquisition at the head of a cold-started call, symbol slips: decision flips kick mu by up
+// to ~2e-3, acquisition and slips leave residuals >> 0.02 samples).  After that the passes go on only while
+// the summed squared residual still falls by > 45 % per pass.
+__global__ void clock_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, int min_passes)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0 || ctl[0]) return;
+    ctl[1] += 1;
+    ctl[2] = (int)cnt[1];
+    ctl[3] = (int)cnt[2];
+    const float q = __uint_as_float(cnt[4]);
+    const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
+    ctl[4] = __float_as_int(q);
+    if (cnt[0] == 0) { ctl[0] = 1; ctl[2] = 0; return; }
+    const bool stalled = q > 0.55f * q_prev;
+    if (ctl[1] >= min_passes && cnt[3] == 0 && stalled) ctl[0] = 1;
 }
 
 // ------------------------------------------------------------ hand-off solve
@@ -466,6 +492,7 @@ struct ClockPolicy {
     const int *nrun;      // symbols chain k produced when it last ran
     unsigned *cnt;        // [0] changed, [1] not frozen, [2] max |r_t| bits, [3] large, [4] sum r_t^2 (float)
     float trust_t, trust_w, tol_t, tol_w;
+    const int *done;      // control block word 0
 
     __device__ bool active(long long k) const { return nrun[k] > 0; }
     __device__ void residual(long long k, float &r1, float &r2, int &aux) const
@@ -536,7 +563,6 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     min_passes = max_passes < 4 ? max_passes : 4;
     if (const char *e = getenv("XRIT_CLOCK_JAC_PASSES")) jac_passes = atoi(e);   // experiment knobs
     if (const char *e = getenv("XRIT_CLOCK_NS")) NS = atoi(e);
-    if (const char *e = getenv("XRIT_CLOCK_TOL")) { tol_t = (float)atof(e); tol_w = tol_t * 0.1f; }
     if (const char *e = getenv("XRIT_CLOCK_SS")) ss_override = atoi(e);
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
     design_mmse_table(tb.data());
@@ -547,9 +573,9 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     s0.ii = 0; s0.mu = mu; s0.omega = omega;
     ClockState both[2] = {s0, s0};
     XR_HIP(hipMemcpy(st.p, both, sizeof both, hipMemcpyHostToDevice));
-    XR_TRY(counters.reserve((size_t)(max_passes + 4) * 8 * sizeof(unsigned)));
-    XR_HIP(hipHostMalloc((void **)&h_res, 64));
-    XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
+    XR_TRY(tail.reserve(2 * 1024 * sizeof(float2)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
+    XR_HIP(hipHostMalloc((void **)&h_res, 128));
     cur = 0;
     carry = 0;
     return XRIT_OK;
@@ -558,11 +584,9 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
 void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
-    work.release(); counters.release(); sym.release(); dlin.release(); flags.release();
+    work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release();
     if (h_res) (void)hipHostFree(h_res);
-    if (h_counters) (void)hipHostFree(h_counters);
     h_res = nullptr;
-    h_counters = nullptr;
 }
 
 // The producer of this call's samples may deliver the timing-line statistic itself: nb blocks of BL samples,
@@ -577,49 +601,117 @@ double2 *ClockStage::om_slot(int nb, int BL, double offset)
     return om.as<double2>();
 }
 
+// where the producer writes the n new samples of this call: behind the `carry` samples left unread by the
+// previous call (those are copied in from the tail buffer when the call begins)
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
-    size_t need = (carry + n + 64) * sizeof(float2);
-    if (need > xbuf.bytes) {
-        DevBuf nb;
-        XR_TRY(nb.reserve(need));
-        if (carry && xbuf.p) {
-            XR_HIP(hipMemcpyAsync(nb.p, xbuf.p, carry * sizeof(float2), hipMemcpyDeviceToDevice, s));
-            XR_HIP(hipStreamSynchronize(s));
-        }
-        xbuf.release();
-        xbuf = nb;
-    }
+    (void)s;
+    XR_TRY(xbuf.reserve((carry + n + 64) * sizeof(float2)));
     *slot = xbuf.as<float2>() + carry;
     return XRIT_OK;
 }
 
-int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s,
-                    Profiler *prof)
+// control block layout in `counters`: [0..8) ctl words, [8..16) ClockResult, per-pass counter slots from 16
+static inline int *clock_ctl(const DevBuf &b) { return b.as<int>(); }
+static inline ClockResult *clock_res(const DevBuf &b) { return reinterpret_cast<ClockResult *>(b.as<unsigned>() + 8); }
+static inline unsigned *clock_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + 16 + (size_t)pass * 8; }
+
+int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
+{
+    const Job &j = job;
+    ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, nullptr,
+                    0.75f, 0.01f, tol_t, tol_w, clock_ctl(counters)};
+    const unsigned gridK = div_up((size_t)j.K, 64);
+    const float2 *x = xbuf.as<float2>();
+    for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
+        const int p = job.enqueued;
+        {
+            ProfScope ps(prof, p < jac_passes ? "clock_pass_jac" : "clock_pass", s);
+#define XR_CLK_PASS(NV, WPV)                                                                                          \
+    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x, table.as<float>(), \
+                       S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, \
+                       j.SS, j.W, j.WS, clock_ctl(counters))
+            if (p < jac_passes) { if (j.wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
+            else { if (j.wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
+#undef XR_CLK_PASS
+        }
+        {
+            ProfScope ps(prof, "clock_solve", s);
+            pol.cnt = clock_cnt(counters, p);
+            if (newton_solve(pol, (long long)j.K - 1, work.as<AffMap>(), dlin.as<float2>(), s) != 0) {
+                set_error("clock hand-off: %d chains exceed the solver's block budget", j.K);
+                return XRIT_E_INVALID;
+            }
+            hipLaunchKernelGGL(clock_decide_kernel, dim3(1), dim3(1), 0, s, pol.cnt, clock_ctl(counters), min_passes);
+        }
+    }
+    return XRIT_OK;
+}
+
+int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
+{
+    const Job &j = job;
+    const float2 *x = xbuf.as<float2>();
+    const ClockState *st_in = st.as<ClockState>() + cur;
+    ClockState *st_out = st.as<ClockState>() + (cur ^ 1);
+    float2 *tail_out = tail.as<float2>() + 1024 * (cur ^ 1);
+    const unsigned gridK = div_up((size_t)j.K, 64);
+    {
+        ProfScope ps(prof, "clock_output", s);
+        hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
+        if (j.wide)
+            hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
+                               S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS);
+        else
+            hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
+                               S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS);
+        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
+                           st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
+    }
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return XRIT_OK;
+}
+
+// Everything of one call is put on the stream without waiting: the carried tail, the timing guess, a batch of
+// hand-off passes (no-ops once the device-side test has declared the hand-off closed), the output pass and the
+// copy of the control block.  finish() runs after the caller has synchronised the stream.
+int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hipStream_t s, Profiler *prof)
 {
     passes = 0;
     unconverged = 0;
     max_residual = 0;
-    const long long N = (long long)(carry + n);
-    const long long ni = N - XR_MM_NTAPS - XR_MM_FUDGE;
-    const ClockState *st_in = st.as<ClockState>() + cur;
-    ClockState *st_out = st.as<ClockState>() + (cur ^ 1);
+    job = Job{};
+    Job &j = job;
+    j.n = n; j.soft = soft_out; j.sym = sym_out; j.cap = cap;
+    j.N = (long long)(carry + n);
+    j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
+    XR_TRY(xbuf.reserve((size_t)(j.N + 64) * sizeof(float2)));
     float2 *x = xbuf.as<float2>();
-    *n_out = 0;
-    if (ni <= 0) {
-        // not enough samples for a single symbol: everything is carried
-        carry = (size_t)N;
-        last_symbols = 0;
+    if (carry)
+        hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, s, tail.as<float2>() + 1024 * cur, x, (int)carry);
+    const bool ext = om_ext;          // statistic supplied by the producer of the samples (Costas final pass)
+    om_ext = false;
+    if (j.ni <= 0) {
+        // not enough samples for a single symbol: everything is carried to the next call
+        j.short_input = true;
+        if (j.N > 1024) { set_error("clock recovery: unread tail exceeds the hand-over buffer"); return XRIT_E_INVALID; }
+        if (j.N > 0)
+            XR_HIP(hipMemcpyAsync(tail.as<float2>() + 1024 * (cur ^ 1), x, (size_t)j.N * sizeof(float2),
+                                  hipMemcpyDeviceToDevice, s));
+        XR_HIP(hipMemcpyAsync(st.as<ClockState>() + (cur ^ 1), st.as<ClockState>() + cur, sizeof(ClockState),
+                              hipMemcpyDeviceToDevice, s));
         return XRIT_OK;
     }
     // chain budget: the slowest admissible symbol clock plus slack
     const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
-    const int K = (int)((double)N / (min_omega * NS)) + 3;
-    const bool ext = om_ext;          // statistic supplied by the producer of the samples (Costas final pass)
-    om_ext = false;
+    const int K = (int)((double)j.N / (min_omega * NS)) + 3;
+    j.K = K;
     const int BL = ext ? om_BL : CLK_OM_BLOCK;
     const double om_off = ext ? om_offset : 0.0;
-    const int nb = ext ? om_nb : (int)((N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
+    const int nb = ext ? om_nb : (int)((j.N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
@@ -629,29 +721,27 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;
     XR_TRY(work.reserve((size_t)(2 * nbmax + 6) * sizeof(AffMap)));
-    int *dirty = flags.as<int>();
-    int *counts = flags.as<int>() + K;
-    int *nrun = flags.as<int>() + 2 * K;
-    int *terminal = flags.as<int>() + 3 * K;
+    j.dirty = flags.as<int>();
+    j.counts = flags.as<int>() + K;
+    j.nrun = flags.as<int>() + 2 * K;
+    j.terminal = flags.as<int>() + 3 * K;
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
-    ClockResult *d_res = reinterpret_cast<ClockResult *>(counters.as<unsigned>() + 8);
-    const unsigned gridK = div_up((size_t)K, 64);
     // staged window: SS symbols ahead, at the fastest admissible symbol clock
     const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
     int SS = ss_override > 0 ? ss_override : 4;
     while (SS > 1 && (int)ceil(SS * max_adv) + 2 + XR_MM_NTAPS > 32) --SS;
     int W = (int)ceil(SS * max_adv) + 1 + XR_MM_NTAPS + 1;
     if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
-    const int WS = W | 1;
-    const bool wide = W > 32;
-    const size_t tile_bytes = clock_tile_bytes(WS);
-
+    j.SS = SS; j.W = W; j.WS = W | 1; j.wide = W > 32;
+    j.tile_bytes = clock_tile_bytes(j.WS);
+    const ClockState *st_in = st.as<ClockState>() + cur;
+    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
             if (!ext)
-                hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, N, nb,
+                hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, j.N, nb,
                                    1.0 / (double)sps);
             ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL};
             hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
@@ -660,107 +750,85 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
             hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
-                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), ni, om_off, BL);
-            hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, dirty, 1, K);
+                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL);
+            hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, j.dirty, 1, K);
         }
-        const long long nel = K - 1;
-        AffMap *aggs = work.as<AffMap>();
-        unsigned *cnt_all = counters.as<unsigned>() + 16;
-        XR_HIP(hipMemsetAsync(cnt_all, 0, (size_t)(max_passes + 1) * 8 * sizeof(unsigned), s));
-        ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, cnt_all,
-                        0.75f, 0.01f, tol_t, tol_w};
-        float q_prev = INFINITY;
-        const int blind = min_passes < max_passes ? min_passes : max_passes;
-        for (int p = 0; p < max_passes; ++p) {
-            {
-                ProfScope ps(prof, p < jac_passes ? "clock_pass_jac" : "clock_pass", s);
-#define XR_CLK_PASS(NV, WPV)                                                                                      \
-    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), tile_bytes, s, x, table.as<float>(),  \
-                       S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), dirty, nrun, N, ni, K, NS, par, SS, W, WS)
-                if (p < jac_passes) { if (wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
-                else { if (wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
-#undef XR_CLK_PASS
-            }
-            {
-                ProfScope ps(prof, "clock_solve", s);
-                pol.cnt = cnt_all + (size_t)p * 8;
-                if (newton_solve(pol, nel, aggs, dlin.as<float2>(), s) != 0) {
-                    set_error("clock hand-off: %d chains exceed the solver's block budget", K);
-                    return XRIT_E_INVALID;
-                }
-            }
-            ++passes;
-            if (p + 1 < blind) continue;
-            XR_HIP(hipMemcpyAsync(h_counters, pol.cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
-            unconverged = h_counters[1];
-            uint32_t bits = h_counters[2];
-            memcpy(&max_residual, &bits, sizeof(float));
-            if (h_counters[0] == 0) { unconverged = 0; break; }
-            // The recurrence is chaotic at the 1e-5 level (interpolator-arm quantisation), so boundaries keep
-            // moving by that much for ever; what must close are the LARGE residuals (acquisition at the head of a
-            // cold-started call, symbol slips: decision flips kick mu by up to ~2e-3, acquisition and slips leave
-            // residuals >> 0.02 samples).  After that, keep going only while the summed squared residual still
-            // falls by > 45 % per pass.
-            unsigned large = h_counters[3];
-            float q;
-            memcpy(&q, &h_counters[4], sizeof(float));
-            bool stalled = q > 0.55f * q_prev;
-            q_prev = q;
-            if (passes >= min_passes && large == 0 && stalled) break;
-        }
-        if (getenv("XRIT_TRACE")) {
-            std::vector<unsigned> hc((size_t)passes * 8);
-            XR_HIP(hipMemcpyAsync(hc.data(), cnt_all, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
-            for (int p = 0; p < passes; ++p) {
-                float mr, q;
-                memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
-                memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
-                fprintf(stderr, "[xrit] %s pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", "clock", p, K,
-                        hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
-                        hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
-            }
-        }
+        XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
     }
-    {
-        ProfScope ps(prof, "clock_output", s);
-        hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, terminal, 0x7fffffff, 1);
-        if (wide)
-            hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), tile_bytes, s, x, table.as<float>(),
-                               S.as<ClockState>(), E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, N,
-                               ni, K, NS, par, terminal, SS, W, WS);
-        else
-            hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), tile_bytes, s, x, table.as<float>(),
-                               S.as<ClockState>(), E.as<ClockState>(), counts, soft_out, sym_out, (unsigned long long)cap, N,
-                               ni, K, NS, par, terminal, SS, W, WS);
-        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), counts, terminal,
-                           st_in, st_out, d_res, x, N, K, NS);
+    return enqueue_output(s, prof);
+}
+
+bool ClockStage::closed() const
+{
+    if (job.short_input || job.K <= 1) return true;
+    return reinterpret_cast<const int *>(h_res)[0] != 0;
+}
+
+// After a stream synchronise: continue the passes if the first batch did not close (cold start), commit the
+// carried state, report the symbol count.
+int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
+{
+    *n_out = 0;
+    if (job.short_input) {
+        carry = (size_t)job.N;
+        last_symbols = 0;
+        cur ^= 1;
+        return XRIT_OK;
     }
-    XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(h_res, d_res, sizeof(ClockResult), hipMemcpyDeviceToHost, s));
-    XR_HIP(hipStreamSynchronize(s));
+    const int *hctl = reinterpret_cast<const int *>(h_res);
+    if (!closed()) {
+        while (hctl[0] == 0 && job.enqueued < max_passes) {
+            XR_TRY(enqueue_passes(2, s, prof));
+            XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
+        }
+        XR_TRY(enqueue_output(s, prof));
+        XR_HIP(hipStreamSynchronize(s));
+    }
+    passes = job.K > 1 ? hctl[1] : 0;
+    unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
+    memcpy(&max_residual, &hctl[3], sizeof(float));
+    if (getenv("XRIT_TRACE") && job.K > 1) {
+        std::vector<unsigned> hc((size_t)passes * 8);
+        XR_HIP(hipMemcpy(hc.data(), clock_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int p = 0; p < passes; ++p) {
+            float mr, q;
+            memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
+            memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+            fprintf(stderr, "[xrit] clock pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", p, job.K,
+                    hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
+                    hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
+        }
+    }
     ClockResult r;
-    memcpy(&r, h_res, sizeof r);
+    memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + 8, sizeof r);
     cur ^= 1;
     if (!r.ok) {
         set_error("clock recovery: chain budget exhausted before the end of the input");
         return XRIT_E_INVALID;
     }
-    carry = (size_t)(N - r.ii_final);
+    carry = (size_t)(job.N - r.ii_final);
     if (carry > 1024) {
         set_error("clock recovery: carry of %zu samples exceeds the hand-over buffer", carry);
         return XRIT_E_INVALID;
     }
     last_symbols = (size_t)r.n_symbols;
     *n_out = last_symbols;
-    if (last_symbols > cap) {
-        set_error("clock recovery produced %zu symbols, capacity %zu", last_symbols, cap);
+    if (last_symbols > job.cap) {
+        set_error("clock recovery produced %zu symbols, capacity %zu", last_symbols, job.cap);
         return XRIT_E_CAPACITY;
     }
     return XRIT_OK;
+}
+
+int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s,
+                    Profiler *prof)
+{
+    XR_TRY(begin(n, soft_out, sym_out, cap, s, prof));
+    XR_HIP(hipStreamSynchronize(s));
+    return finish(n_out, s, prof);
 }
 
 }  // namespace xrit

@@ -135,8 +135,10 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          float4 *__restrict__ J, int *__restrict__ dirty,
                                                          float2 *__restrict__ state_out, long long n, int L, int K,
                                                          CostasGains g, double2 *__restrict__ om, long long om_off,
-                                                         double inv_sps, float rot_c, float rot_s)
+                                                         double inv_sps, float rot_c, float rot_s,
+                                                         const int *__restrict__ ctl)
 {
+    if (!FINAL && ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
     __shared__ float2 tin[2][64][COSTAS_CT + 1];
     __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_OT * COSTAS_CT + 1];   // one 128-byte row per chain
     const int lane = threadIdx.x;
@@ -278,6 +280,7 @@ struct CostasPolicy {
     int *dirty;
     unsigned *cnt;           // [0] changed, [1] not frozen, [2] max |r_phase| bits
     float trust_p, trust_f, tol_p, tol_f;
+    const int *done;         // control block word 0
 
     __device__ bool active(long long) const { return true; }
     __device__ void residual(long long k, float &r1, float &r2, int &aux) const
@@ -314,6 +317,18 @@ struct CostasPolicy {
     }
 };
 
+// After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits)
+__global__ void costas_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, float accept)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0 || ctl[0]) return;
+    ctl[1] += 1;
+    ctl[2] = (int)cnt[1];
+    ctl[3] = (int)cnt[2];
+    const float max_r = __uint_as_float(cnt[2]);
+    // nothing moved, or what is still open sits within a factor two of the tolerance: accept
+    if (cnt[0] == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
+}
+
 __global__ void fill_int_kernel(int *p, int v, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,7 +343,7 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     max_passes = max_passes_ > 0 ? max_passes_ : 32;
     XR_TRY(state.reserve(2 * sizeof(float2)));
     XR_HIP(hipMemset(state.p, 0, 2 * sizeof(float2)));
-    XR_TRY(counters.reserve((size_t)(max_passes + 2) * 8 * sizeof(unsigned)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 4) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
     cur = 0;
     return XRIT_OK;
@@ -359,28 +374,77 @@ int CostasStage::get_state(float *phase, float *freq, hipStream_t s)
     return XRIT_OK;
 }
 
-int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
-                     double2 *om, long long om_off, double inv_sps)
+// control block: counters[0..8) = ctl words, per-pass counter slots after it
+static inline int *costas_ctl(const DevBuf &b) { return b.as<int>(); }
+static inline unsigned *costas_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + 8 + (size_t)pass * 8; }
+
+int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
+{
+    const long long nel = job.K - 1;
+    CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
+                     tol_phase, tol_freq, costas_ctl(counters)};
+    const unsigned gridK = div_up((size_t)job.K, 64);
+    for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
+        {
+            ProfScope ps(prof, "costas_pass", s);
+            hipLaunchKernelGGL(costas_pass_kernel<false>, dim3(gridK), dim3(64), 0, s, job.in, job.out, S.as<float2>(),
+                               E.as<float2>(), J.as<float4>(), flags.as<int>(), (float2 *)nullptr, (long long)job.n, L,
+                               job.K, gains, (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f, costas_ctl(counters));
+        }
+        {
+            ProfScope ps(prof, "costas_solve", s);
+            pol.cnt = costas_cnt(counters, job.enqueued);
+            if (newton_solve(pol, nel, work.as<AffMap>(), dlin.as<float2>(), s) != 0) {
+                set_error("Costas hand-off: %d chains exceed the solver's block budget", job.K);
+                return XRIT_E_INVALID;
+            }
+            hipLaunchKernelGGL(costas_decide_kernel, dim3(1), dim3(1), 0, s, pol.cnt, costas_ctl(counters),
+                               2.0f * tol_phase);
+        }
+    }
+    return XRIT_OK;
+}
+
+int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
+{
+    ProfScope ps(prof, "costas_final", s);
+    const double dth = -2.0 * XR_PI_D * job.inv_sps;
+    float2 *st_out = state.as<float2>() + (cur ^ 1);
+    hipLaunchKernelGGL(costas_pass_kernel<true>, dim3(div_up((size_t)job.K, 64)), dim3(64), 0, s, job.in, job.out,
+                       S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)job.n, L,
+                       job.K, gains, job.om, job.om_off, job.inv_sps, (float)cos(dth), (float)sin(dth),
+                       costas_ctl(counters));
+    XR_HIP(hipMemcpyAsync(h_counters, counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipGetLastError());
+    return XRIT_OK;
+}
+
+// Everything of one call is put on the stream without waiting: guess, a batch of hand-off passes (each one a
+// no-op once the device-side test has declared the hand-off closed), the final pass and the copy of the control
+// block.  finish() is called after the caller has synchronised the stream.
+int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+                       double2 *om, long long om_off, double inv_sps)
 {
     passes = 0;
     unconverged = 0;
     max_residual = 0;
+    job = Job{};
+    job.in = in; job.out = out; job.n = n; job.om = om; job.om_off = om_off; job.inv_sps = inv_sps;
     if (n == 0) return XRIT_OK;
     const int K = (int)((n + (size_t)L - 1) / (size_t)L);
+    job.K = K;
     const float2 *st_in = state.as<float2>() + cur;
-    float2 *st_out = state.as<float2>() + (cur ^ 1);
     XR_TRY(S.reserve((size_t)K * sizeof(float2)));
     XR_TRY(E.reserve((size_t)K * sizeof(float2)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
-    XR_TRY(stat.reserve((size_t)K * sizeof(float2)));
+    XR_TRY(stat.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(flags.reserve((size_t)K * sizeof(int)));
     const int nbK = scan_blocks(K);
     const size_t agg_bytes = (((size_t)(2 * newton_blocks(K) + 4) * sizeof(AffMap)) + 15) & ~(size_t)15;
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
-    const unsigned gridK = div_up((size_t)K, 64);
-
+    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 2) * 8 * sizeof(unsigned), s));
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
@@ -398,68 +462,61 @@ int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Pro
                                L, gains);
             hipLaunchKernelGGL(fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, flags.as<int>(), 1, K);
         }
-        const long long nel = K - 1;
-        const int nbE = newton_blocks(nel);
-        AffMap *aggs = work.as<AffMap>();
-        unsigned *cnt_all = counters.as<unsigned>();
-        XR_HIP(hipMemsetAsync(cnt_all, 0, (size_t)(max_passes + 1) * 8 * sizeof(unsigned), s));
-        CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), cnt_all, trust,
-                         trust / 256.0f, tol_phase, tol_freq};
-        (void)nbE;
-        // the first passes always run; after that the host looks at the change counter of each pass
-        const int blind = max_passes < 3 ? max_passes : 3;
-        for (int p = 0; p < max_passes; ++p) {
-            {
-                ProfScope ps(prof, "costas_pass", s);
-                hipLaunchKernelGGL(costas_pass_kernel<false>, dim3(gridK), dim3(64), 0, s, in, out, S.as<float2>(),
-                                   E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains,
-                                   (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f);
-            }
-            {
-                ProfScope ps(prof, "costas_solve", s);
-                pol.cnt = cnt_all + (size_t)p * 8;
-                if (newton_solve(pol, nel, aggs, dlin.as<float2>(), s) != 0) {
-                    set_error("Costas hand-off: %d chains exceed the solver's block budget", K);
-                    return XRIT_E_INVALID;
-                }
-            }
-            ++passes;
-            if (p + 1 < blind) continue;
-            XR_HIP(hipMemcpyAsync(h_counters, pol.cnt, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
-            unconverged = h_counters[1];
-            uint32_t bits = h_counters[2];
-            memcpy(&max_residual, &bits, sizeof(float));
-            if (h_counters[0] == 0) { unconverged = 0; break; }
-            // what is still open sits within a factor two of the tolerance: accept it
-            if (max_residual <= 2.0f * tol_phase) { unconverged = 0; break; }
-        }
-        if (getenv("XRIT_TRACE")) {
-            std::vector<unsigned> hc((size_t)passes * 8);
-            XR_HIP(hipMemcpyAsync(hc.data(), cnt_all, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            XR_HIP(hipStreamSynchronize(s));
-            for (int p = 0; p < passes; ++p) {
-                float mr, q;
-                memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
-                memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
-                fprintf(stderr, "[xrit] %s pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", "costas", p, K,
-                        hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
-                        hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
-            }
-        }
+        XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(float2), hipMemcpyDeviceToDevice, s));
     }
-    {
-        ProfScope ps(prof, "costas_final", s);
-        const double dth = -2.0 * XR_PI_D * inv_sps;
-        hipLaunchKernelGGL(costas_pass_kernel<true>, dim3(gridK), dim3(64), 0, s, in, out, S.as<float2>(),
-                           E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)n, L, K, gains, om, om_off,
-                           inv_sps, (float)cos(dth), (float)sin(dth));
+    return enqueue_final(s, prof);
+}
+
+// after a stream synchronise: true when the hand-off closed within the passes enqueued so far
+bool CostasStage::closed() const
+{
+    return job.n == 0 || job.K <= 1 || h_counters[0] != 0;
+}
+
+// Continues a call whose first batch did not close (cold start, unlocked input): more passes, looked at from the
+// host every two, then the final pass again.  *redone tells the caller that the output was rewritten.
+int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
+{
+    if (redone) *redone = false;
+    if (job.n == 0) return XRIT_OK;
+    if (!closed()) {
+        if (redone) *redone = true;
+        while (h_counters[0] == 0 && job.enqueued < max_passes) {
+            XR_TRY(enqueue_passes(2, s, prof));
+            XR_HIP(hipMemcpyAsync(h_counters, counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipStreamSynchronize(s));
+        }
+        XR_TRY(enqueue_final(s, prof));
+        XR_HIP(hipStreamSynchronize(s));
     }
-    XR_HIP(hipGetLastError());
-    cur ^= 1;
+    passes = job.K > 1 ? (int)h_counters[1] : 0;
+    unconverged = job.K > 1 && h_counters[0] == 0 ? h_counters[2] : 0;
+    uint32_t bits = h_counters[3];
+    memcpy(&max_residual, &bits, sizeof(float));
+    if (getenv("XRIT_TRACE") && job.K > 1) {
+        std::vector<unsigned> hc((size_t)passes * 8);
+        XR_HIP(hipMemcpy(hc.data(), costas_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int p = 0; p < passes; ++p) {
+            float mr, q;
+            memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
+            memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+            fprintf(stderr, "[xrit] costas pass %d: K=%d changed=%u open=%u max_r=%.3e rms_r=%.3e\n", p, job.K,
+                    hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr,
+                    hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
+        }
+    }
+    cur ^= 1;     // the carried state now is the one the final pass left
     return XRIT_OK;
+}
+
+int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+                     double2 *om, long long om_off, double inv_sps)
+{
+    XR_TRY(begin(in, out, n, s, prof, stat_ready, om, om_off, inv_sps));
+    XR_HIP(hipStreamSynchronize(s));
+    return finish(s, prof, nullptr);
 }
 
 }  // namespace xrit

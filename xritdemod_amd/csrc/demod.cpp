@@ -248,15 +248,30 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     const size_t carry0 = d->clock.carry;
     double2 *om = nullptr;
     if (length) om = d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L, (double)carry0);
-    XR_TRY(d->costas.run(A, slot, length, s, prof, stat_ready, om, (long long)carry0, 1.0 / (double)d->sps)); // :152
-    XR_TRY(keep_stage(d, 3, slot, length, s));
+    // Costas (:152) and clock recovery (:156, SymbolManager.cpp:104) are enqueued back to back -- guesses, a batch
+    // of hand-off passes each with a device-side stop test, final / output passes -- and the host waits once.
+    // Only when a batch did not close (cold start, unlocked input) does it continue pass by pass.
     float2 *sym = nullptr;
     if (d->keep_stages) {
         XR_TRY(d->stage_buf[4].reserve((cap + 1) * sizeof(float2)));
         sym = d->stage_buf[4].as<float2>();
     }
+    const double inv_sps = 1.0 / (double)d->sps;
+    XR_TRY(d->costas.begin(A, slot, length, s, prof, stat_ready, om, (long long)carry0, inv_sps));
+    XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
+    XR_HIP(hipStreamSynchronize(s));
+    bool redone = false;
+    XR_TRY(d->costas.finish(s, prof, &redone));
+    if (redone) {
+        // the Costas output was rewritten after more passes: the clock recovery starts over on it
+        if (length) (void)d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L, (double)carry0);
+        XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
+        XR_HIP(hipStreamSynchronize(s));
+    }
+    XR_TRY(keep_stage(d, 3, slot, length, s));
     size_t nsym = 0;
-    int rc = d->clock.run(length, d_soft, sym, cap, &nsym, s, prof);  // :156, SymbolManager.cpp:104
+    int rc = d->clock.finish(&nsym, s, prof);
+    if (d->keep_stages) XR_HIP(hipStreamSynchronize(s));
     if (prof) d->prof.collect();
     d->stage_n[4] = nsym;
     d->stats.samples_in = n;

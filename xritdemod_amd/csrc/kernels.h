@@ -56,6 +56,19 @@ struct CostasStage {
     // recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
     int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready = false,
             double2 *om = nullptr, long long om_off = 0, double inv_sps = 0.0);
+    // the same in two halves: begin() only enqueues (guess, a batch of passes with a device-side stop test, final
+    // pass); finish() runs after the caller synchronised the stream and continues the passes if they did not close
+    int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+              double2 *om, long long om_off, double inv_sps);
+    bool closed() const;
+    int finish(hipStream_t s, Profiler *prof, bool *redone);
+    int enqueue_passes(int count, hipStream_t s, Profiler *prof);
+    int enqueue_final(hipStream_t s, Profiler *prof);
+    struct Job {
+        const float2 *in = nullptr; float2 *out = nullptr; size_t n = 0; int K = 0; int enqueued = 0;
+        double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
+    } job;
+    int batch = 4;          // passes enqueued before the host looks (3 suffice on a locked signal)
     float2 *stat_slot(size_t n);
     int get_state(float *phase, float *freq, hipStream_t s);
 };
@@ -72,8 +85,8 @@ struct ClockStage {
     DevBuf xbuf;            // [carry | new] input samples of the call
     DevBuf st;              // carried ClockState + carry count
     DevBuf S, E, J, om, work, counters, sym, dlin, flags;
-    void *h_res = nullptr;            // pinned
-    unsigned *h_counters = nullptr;   // pinned
+    DevBuf tail;                      // 2 x 1024 samples left unread by a call (ping-pong with the state)
+    void *h_res = nullptr;            // pinned copy of the control block + result
     float tol_t = 2e-6f, tol_w = 2e-7f;
     int cur = 0;
     size_t carry = 0;       // samples held over from the previous call
@@ -92,6 +105,19 @@ struct ClockStage {
     double om_offset = 0;
     // soft (real parts) and/or complex symbols; either may be null
     int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
+    // the same in two halves (see CostasStage): begin() only enqueues, finish() runs after a stream synchronise
+    int begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hipStream_t s, Profiler *prof);
+    bool closed() const;
+    int finish(size_t *n_out, hipStream_t s, Profiler *prof);
+    int enqueue_passes(int count, hipStream_t s, Profiler *prof);
+    int enqueue_output(hipStream_t s, Profiler *prof);
+    struct Job {
+        size_t n = 0, cap = 0; float *soft = nullptr; float2 *sym = nullptr;
+        long long N = 0, ni = 0; int K = 0, enqueued = 0, SS = 0, W = 0, WS = 0; bool wide = false, short_input = false;
+        size_t tile_bytes = 0;
+        int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
+    } job;
+    int batch = 7;          // passes enqueued before the host looks (5-6 suffice in steady state)
 };
 
 // ---- helpers ---------------------------------------------------------------

@@ -22,6 +22,7 @@
 //   bool   P::outside_trust(d1, d2)
 //   void   P::update(k, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
 //   unsigned* P::cnt                      this pass's counter slot
+//   const int* P::done                    non-zero: the hand-off has closed, the solve is a no-op
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -116,6 +117,7 @@ __device__ __forceinline__ AffMap newton_element(const P &p, long long k, bool c
 template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long long n, AffMap *agg0)
 {
+    if (*p.done) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap v = aff_identity();
@@ -129,6 +131,7 @@ template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long long n, const AffMap *agg0, AffMap *agg1,
                                                                    float2 *dlin)
 {
+    if (*p.done) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap pre = aff_lookback(agg0, buf);
@@ -162,6 +165,7 @@ template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg1,
                                                                     const float2 *dlin)
 {
+    if (*p.done) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap pre = aff_lookback(agg1, buf);
