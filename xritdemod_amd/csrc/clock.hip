@@ -176,7 +176,7 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
 // states) reads global memory for that symbol.
 struct ClockTile {
     float *table;          // 129 x 8
-    long long *wb;         // window base per chain (-1: row unused)
+    int *wb;               // window base per chain (-1: row unused); the buffer index fits 32 bits
     float2 *tile;          // 64 x WS
 };
 
@@ -184,7 +184,7 @@ __device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
 {
     ClockTile t;
     t.table = reinterpret_cast<float *>(smem);
-    t.wb = reinterpret_cast<long long *>(smem + 4160);
+    t.wb = reinterpret_cast<int *>(smem + 4160);
     t.tile = reinterpret_cast<float2 *>(smem + 4160 + 512);
     return t;
 }
@@ -192,8 +192,10 @@ __device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
 static inline size_t clock_tile_bytes(int WS) { return 4160 + 512 + (size_t)64 * WS * sizeof(float2); }
 
 // All threads of the block (NV waves).  WP lanes cover one row, 64/WP rows per wave
-// instruction.  Fully unrolled in three phases -- window bases, then every global
-// load, then the LDS stores -- so that all loads of a fill are in flight together.
+// instruction.  No predication: indices are clamped instead (an idle row re-reads
+// sample 0, columns past W land in the row's padding since WS > WP), so the fill is
+// a straight run of LDS reads, global loads and LDS stores with every load of the
+// fill in flight together.
 template <int NV, int WP>
 __device__ __forceinline__ void clock_tile_fill(const ClockTile &t, const float2 *__restrict__ x, long long N, int W,
                                                 int WS)
@@ -202,23 +204,21 @@ __device__ __forceinline__ void clock_tile_fill(const ClockTile &t, const float2
     constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / WP, col = lane - sub * WP;
-    long long base[ITER];
+    int idx[ITER];
     float2 v[ITER];
+    (void)W;
+    const int last = (int)(N - 1);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int row = (it * NV + wave) * RPI + sub;
-        base[it] = (row < 64 && col < W) ? t.wb[row] : -1;
+        const int row = min((it * NV + wave) * RPI + sub, 63);
+        idx[it] = min(max(t.wb[row], 0) + col, last);
     }
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        v[it] = make_float2(0.f, 0.f);
-        const long long j = base[it] + col;
-        if (base[it] >= 0 && j < N) v[it] = x[j];
-    }
+    for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int row = (it * NV + wave) * RPI + sub;
-        if (base[it] >= 0) t.tile[row * WS + col] = v[it];
+        const int row = min((it * NV + wave) * RPI + sub, 63);
+        t.tile[row * WS + col] = v[it];
     }
 }
 
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         if (NV > 1 && variant == 2) s.omega += CLK_H_W;
     }
     for (int s0 = 0; s0 < NS; s0 += SS) {
-        if (variant == 0) t.wb[lane] = alive ? (s.ii > 0 ? s.ii - 1 : 0) : -1;
+        if (variant == 0) t.wb[lane] = alive ? (int)(s.ii > 0 ? s.ii - 1 : 0) : -1;
         __syncthreads();
         clock_tile_fill<NV, WP>(t, x, N, W, WS);
         __syncthreads();
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
     for (int i0 = 0; i0 < NS; i0 += CLK_OT) {
         const int olim = min(CLK_OT, NS - i0);
         for (int s0 = 0; s0 < olim; s0 += SS) {
-            t.wb[lane] = alive ? (s.ii > 0 ? s.ii - 1 : 0) : -1;
+            t.wb[lane] = alive ? (int)(s.ii > 0 ? s.ii - 1 : 0) : -1;
             __syncthreads();
             clock_tile_fill<1, WP>(t, x, N, W, WS);
             __syncthreads();
@@ -688,6 +688,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.n = n; j.soft = soft_out; j.sym = sym_out; j.cap = cap;
     j.N = (long long)(carry + n);
     j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
+    if (j.N >= (1LL << 31)) { set_error("clock recovery: more than 2^31 samples in one call"); return XRIT_E_INVALID; }
     XR_TRY(xbuf.reserve((size_t)(j.N + 64) * sizeof(float2)));
     float2 *x = xbuf.as<float2>();
     if (carry)
@@ -733,7 +734,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     while (SS > 1 && (int)ceil(SS * max_adv) + 2 + XR_MM_NTAPS > 32) --SS;
     int W = (int)ceil(SS * max_adv) + 1 + XR_MM_NTAPS + 1;
     if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
-    j.SS = SS; j.W = W; j.WS = W | 1; j.wide = W > 32;
+    j.wide = W > 32;
+    j.SS = SS; j.W = W; j.WS = (j.wide ? 64 : 32) + 1;     // rows are one sample longer than the lanes that fill them
     j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
