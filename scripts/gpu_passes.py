@@ -27,4 +27,4 @@ for mp in (3, 4, 5, 6, 8, 12, 20):
         e = np.abs(g - want[b][:ns])
         res.append((ns == len(want[b]), float(np.sqrt(np.mean(e**2))), float(e.max()), (t1 - t0) * 1e3))
     s = dem.stats()
-    print(f"passes={mp} jac={os.environ.get('XRIT_CLOCK_JAC_PASSES','2')}: burst0 ok={res[0][0]} rms={res[0][1]:.2e} | burst1 (steady) ok={res[1][0]} rms={res[1][1]:.2e} max={res[1][2]:.1e} ms={res[1][3]:.2f} costas={s.costas_passes}")
+    print(f"passes={mp} jac={os.environ.get('XRIT_UNUSED','2')}: burst0 ok={res[0][0]} rms={res[0][1]:.2e} | burst1 (steady) ok={res[1][0]} rms={res[1][1]:.2e} max={res[1][2]:.1e} ms={res[1][3]:.2f} costas={s.costas_passes}")

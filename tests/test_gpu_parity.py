@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 from conftest import synth_signal, rms
+from xritdemod_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -253,6 +254,42 @@ def test_capacity_and_argument_errors(xa):
     bad.device = 99
     with pytest.raises(xa.XritError):
         xa.Demodulator(bad)
+
+
+def test_run_to_run_determinism(xa):
+    """Two fresh handles on the same input give bit-identical symbols (the hand-off passes, their stop test and
+    every reduction are order independent)."""
+    x = synth_signal(1500000, fs_in=6.25e6)
+    outs = []
+    for _ in range(2):
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+        outs.append((dem.process(x[:1000000]), dem.process(x[1000000:]), dem.stats().clock_passes))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+
+
+def test_stats_and_strict_mode(xa):
+    x = synth_signal(600000, fs_in=6.25e6)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    got = dem.process(x)
+    st = dem.stats()
+    assert st.samples_in == len(x) and st.circuit_samples == len(x) // 5 and st.symbols_out == len(got)
+    assert 2 <= st.costas_passes <= 32 and 4 <= st.clock_passes <= 48
+    assert st.costas_unconverged == 0 and st.costas_max_residual < 1e-3
+    # steady state: the second call closes within the first batch of passes
+    dem.process(synth.generate(synth.SynthParams(fs_in=6.25e6), 600000, start=600000))
+    s2 = dem.stats()
+    assert s2.costas_passes <= 4 and s2.clock_passes <= 8
+    # strict mode: an input the Costas loop cannot lock to is reported instead of silently accepted
+    rng = np.random.default_rng(9)
+    noise = (0.2 * (rng.standard_normal(400000) + 1j * rng.standard_normal(400000))).astype(np.complex64)
+    strict = xa.Demodulator(xa.Demodulator.config("lrit", 1.25e6, 1, strict=1, max_passes=6))
+    with pytest.raises(xa.XritError) as ei:
+        strict.process(noise)
+    assert ei.value.code == -6
+    relaxed = xa.Demodulator(xa.Demodulator.config("lrit", 1.25e6, 1, max_passes=6))
+    out = relaxed.process(noise)
+    assert len(out) > 90000 and np.isfinite(out).all() and relaxed.stats().costas_unconverged > 0
 
 
 def test_device_generator_matches_numpy_spec(xa):

@@ -473,7 +473,7 @@ __global__ void clock_decide_kernel(const unsigned *__restrict__ cnt, int *__res
     ctl[1] += 1;
     ctl[2] = (int)cnt[1];
     ctl[3] = (int)cnt[2];
-    const float q = __uint_as_float(cnt[4]);
+    const float q = newton_unfix(*reinterpret_cast<const unsigned long long *>(cnt + 4));
     const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
     ctl[4] = __float_as_int(q);
     if (cnt[0] == 0) { ctl[0] = 1; ctl[2] = 0; return; }
@@ -537,7 +537,7 @@ struct ClockPolicy {
         st.open_ += 1;
         st.max_r = fmaxf(st.max_r, fabsf(r1));
         if (fabsf(r1) > 0.02f || slip_k != 0) st.large += 1;
-        st.sum_sq += fminf(r1 * r1, 1.0f);
+        st.sum_sq += newton_fix(r1 * r1);
         const bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
         if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; st.changed += 1; }
     }
@@ -561,9 +561,6 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     NS = chain_syms > 0 ? chain_syms : 64;
     max_passes = max_passes_ > 0 ? max_passes_ : 48;
     min_passes = max_passes < 4 ? max_passes : 4;
-    if (const char *e = getenv("XRIT_CLOCK_JAC_PASSES")) jac_passes = atoi(e);   // experiment knobs
-    if (const char *e = getenv("XRIT_CLOCK_NS")) NS = atoi(e);
-    if (const char *e = getenv("XRIT_CLOCK_SS")) ss_override = atoi(e);
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
     design_mmse_table(tb.data());
     XR_TRY(table.reserve(tb.size() * sizeof(float)));
@@ -730,7 +727,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     // staged window: SS symbols ahead, at the fastest admissible symbol clock
     const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
-    int SS = ss_override > 0 ? ss_override : 4;
+    int SS = 4;               // measured at C2: 2 symbols per fill is 1.5x slower, 8 needs 64-lane rows (VGPR bound)
     while (SS > 1 && (int)ceil(SS * max_adv) + 2 + XR_MM_NTAPS > 32) --SS;
     int W = (int)ceil(SS * max_adv) + 1 + XR_MM_NTAPS + 1;
     if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
@@ -796,9 +793,11 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         std::vector<unsigned> hc((size_t)passes * 8);
         XR_HIP(hipMemcpy(hc.data(), clock_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (int p = 0; p < passes; ++p) {
-            float mr, q;
+            float mr;
+            unsigned long long qf;
             memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
-            memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+            memcpy(&qf, &hc[(size_t)p * 8 + 4], 8);
+            const float q = (float)((double)qf / 1099511627776.0);
             fprintf(stderr, "[xrit] clock pass %d: K=%d changed=%u open=%u max_r=%.3e large=%u rms_r=%.3e\n", p, job.K,
                     hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr, hc[(size_t)p * 8 + 3],
                     hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);

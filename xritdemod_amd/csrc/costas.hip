@@ -308,7 +308,7 @@ struct CostasPolicy {
         float2 old = S[k + 1];
         st.open_ += 1;
         st.max_r = fmaxf(st.max_r, fabsf(r1));
-        st.sum_sq += r1 * r1;
+        st.sum_sq += newton_fix(r1 * r1);
         if (nw.x != old.x || nw.y != old.y) {
             S[k + 1] = nw;
             dirty[k + 1] = 1;
@@ -499,9 +499,11 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         std::vector<unsigned> hc((size_t)passes * 8);
         XR_HIP(hipMemcpy(hc.data(), costas_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (int p = 0; p < passes; ++p) {
-            float mr, q;
+            float mr;
+            unsigned long long qf;
             memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
-            memcpy(&q, &hc[(size_t)p * 8 + 4], 4);
+            memcpy(&qf, &hc[(size_t)p * 8 + 4], 8);
+            const float q = (float)((double)qf / 1099511627776.0);
             fprintf(stderr, "[xrit] costas pass %d: K=%d changed=%u open=%u max_r=%.3e rms_r=%.3e\n", p, job.K,
                     hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr,
                     hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);

@@ -79,7 +79,6 @@ struct ClockStage {
     float sps = 0, mu0 = 0.5f;
     int NS = 64;            // symbols per chain
     int max_passes = 48, min_passes = 4;
-    int ss_override = 0;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
     DevBuf xbuf;            // [carry | new] input samples of the call

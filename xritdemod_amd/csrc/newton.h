@@ -39,9 +39,13 @@ struct AffMap { float a11, a12, a21, a22, b1, b2; int aux; };
 // per-pass statistics, reduced per block before touching global memory
 struct NewtonStat {
     unsigned changed, open_, large;
-    float max_r, sum_sq;
+    float max_r;
+    unsigned long long sum_sq;    // sum of min(r1^2, 1) in units of 2^-40: integer adds commute, so the
+                                  // statistic (and the stop decision taken from it) is run-to-run deterministic
 };
-// counter slot layout: [0] changed, [1] not frozen, [2] max |r1| bits, [3] large, [4] sum r1^2 (float)
+__device__ __forceinline__ unsigned long long newton_fix(float sq) { return (unsigned long long)(fminf(sq, 1.0f) * 1099511627776.0f); }
+__device__ __forceinline__ float newton_unfix(unsigned long long v) { return (float)((double)v * (1.0 / 1099511627776.0)); }
+// counter slot layout (8 words): [0] changed, [1] not frozen, [2] max |r1| bits, [3] large, [4..5] sum r1^2 (u64, 2^-40)
 
 __device__ __forceinline__ AffMap aff_identity() { return AffMap{1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0}; }
 
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
     if (threadIdx.x > 0) pre = aff_combine(pre, buf[threadIdx.x - 1]);
     float d1 = pre.b1, d2 = pre.b2;
     int aux = pre.aux;
-    NewtonStat st{0u, 0u, 0u, 0.f, 0.f};
+    NewtonStat st{0u, 0u, 0u, 0.f, 0ull};
     for (int q = 0; q < NEWTON_IPT; ++q) {
         const long long k = i0 + q;
         if (k >= n) break;
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
         st.open_ += __shfl_down(st.open_, off, 64);
         st.large += __shfl_down(st.large, off, 64);
         st.max_r = fmaxf(st.max_r, __shfl_down(st.max_r, off, 64));
-        st.sum_sq += __shfl_down(st.sum_sq, off, 64);
+        st.sum_sq += (unsigned long long)__shfl_down((long long)st.sum_sq, off, 64);
     }
     __shared__ NewtonStat wst[NEWTON_BLOCK / 64];
     __syncthreads();
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
         if (t.open_) {
             atomicAdd(&p.cnt[1], t.open_);
             atomicMax(&p.cnt[2], __float_as_uint(t.max_r));
-            atomicAdd(reinterpret_cast<float *>(&p.cnt[4]), t.sum_sq);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&p.cnt[4]), t.sum_sq);
         }
         if (t.large) atomicAdd(&p.cnt[3], t.large);
     }
