@@ -55,17 +55,58 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     const long long out_base = (long long)blockIdx.x * OB;
     const long long tile_start = out_base * D - (T - 1);
 
-    for (int idx = tid; idx < tile_len; idx += nthr) {
-        long long j = tile_start + idx;
-        float2 v = make_float2(0.f, 0.f);
-        if (j < 0) {
-            long long hj = (T - 1) + j;
-            if (hj >= 0) v = hist[hj];
-        } else if (j < n_in) {
-            v = SampleLoad<TYPE>::at(in, (size_t)j);
+    if (tile_start >= 0 && tile_start + tile_len <= n_in) {
+        // interior block: no history, no end of input -> eight loads in flight per lane before the first store
+        // (the guarded loop below waits for every single load: ~16 serial memory latencies per block)
+        int idx = tid;
+        if (TYPE == XRIT_SAMPLE_FLOATIQ && !PAD && (tile_start & 1) == 0 &&
+            (reinterpret_cast<size_t>(in) & 15) == 0) {
+            // cf32 input, even start: two samples per 16-byte load / LDS store
+            const float4 *in4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in) + tile_start);
+            float4 *tile4 = reinterpret_cast<float4 *>(tile);
+            const int pairs = tile_len >> 1;
+            int p = tid;
+#define XR_TILE_BATCH4(U)                                                                   \
+    for (; p + (U - 1) * nthr < pairs; p += U * nthr) {                                     \
+        float4 v[U];                                                                        \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) v[u] = in4[p + u * nthr];             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) tile4[p + u * nthr] = v[u];           \
+    }
+            XR_TILE_BATCH4(8)
+            XR_TILE_BATCH4(4)
+            XR_TILE_BATCH4(2)
+            XR_TILE_BATCH4(1)
+#undef XR_TILE_BATCH4
+            idx = 2 * pairs + tid;          // an odd last sample is left to the 8-byte loop below
         }
-        int pos = PAD ? idx + idx / D : idx;
-        tile[pos] = v;
+#define XR_TILE_BATCH(U)                                                                                      \
+    for (; idx + (U - 1) * nthr < tile_len; idx += U * nthr) {                                               \
+        float2 v[U];                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                         \
+            v[u] = SampleLoad<TYPE>::at(in, (size_t)(tile_start + idx + u * nthr));                           \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
+            const int q = idx + u * nthr;                                                                     \
+            tile[PAD ? q + q / D : q] = v[u];                                                                 \
+        }                                                                                                     \
+    }
+        XR_TILE_BATCH(8)
+        XR_TILE_BATCH(4)
+        XR_TILE_BATCH(2)
+        XR_TILE_BATCH(1)
+#undef XR_TILE_BATCH
+    } else {
+        for (int idx = tid; idx < tile_len; idx += nthr) {
+            long long j = tile_start + idx;
+            float2 v = make_float2(0.f, 0.f);
+            if (j < 0) {
+                long long hj = (T - 1) + j;
+                if (hj >= 0) v = hist[hj];
+            } else if (j < n_in) {
+                v = SampleLoad<TYPE>::at(in, (size_t)j);
+            }
+            int pos = PAD ? idx + idx / D : idx;
+            tile[pos] = v;
+        }
     }
     __syncthreads();
 
