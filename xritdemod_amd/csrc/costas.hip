@@ -175,17 +175,16 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     constexpr int NIT = 64 / RPI;
     const int lrow = lane / LPR, lcol = (lane % LPR) * 2;
     float4 pre[NIT];
+    // unconditional, clamped loads (chains past K / samples past n re-read the last pair; their results are
+    // never used; the input buffer has 8 samples of slack): no branches between the loads, so a tile's requests are all in flight together
+    const long long last_pair = (n - 1) & ~1LL;     // an odd n reads one sample of the buffer's slack
     auto fetch = [&](int tile) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int c = it * RPI + lrow;
-            const long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kbase + c < K) {
-                if (j + 1 < n) v = *reinterpret_cast<const float4 *>(z + j);
-                else if (j < n) { float2 u = z[j]; v.x = u.x; v.y = u.y; }
-            }
-            pre[it] = v;
+            const int c = min(it * RPI + lrow, K - 1 - kbase);
+            long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
+            j = j < last_pair ? j : last_pair;
+            pre[it] = *reinterpret_cast<const float4 *>(z + j);
         }
     };
     auto stash = [&](int buf) {
