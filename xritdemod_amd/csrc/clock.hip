@@ -177,6 +177,7 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
 struct ClockTile {
     float *table;          // 129 x 8
     int *wb;               // window base per chain (-1: row unused); the buffer index fits 32 bits
+    int *nb;               // base of the window being prefetched for the next SS symbols
     float2 *tile;          // 64 x WS
 };
 
@@ -185,6 +186,7 @@ __device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
     ClockTile t;
     t.table = reinterpret_cast<float *>(smem);
     t.wb = reinterpret_cast<int *>(smem + 4160);
+    t.nb = reinterpret_cast<int *>(smem + 4160 + 256);
     t.tile = reinterpret_cast<float2 *>(smem + 4160 + 512);
     return t;
 }
@@ -193,34 +195,39 @@ static inline size_t clock_tile_bytes(int WS) { return 4160 + 512 + (size_t)64 *
 
 // All threads of the block (NV waves).  WP lanes cover one row, 64/WP rows per wave
 // instruction.  No predication: indices are clamped instead (an idle row re-reads
-// sample 0, columns past W land in the row's padding since WS > WP), so the fill is
-// a straight run of LDS reads, global loads and LDS stores with every load of the
-// fill in flight together.
-template <int NV, int WP>
-__device__ __forceinline__ void clock_tile_fill(const ClockTile &t, const float2 *__restrict__ x, long long N, int W,
-                                                int WS)
-{
-    constexpr int RPI = 64 / WP;                       // rows per wave instruction
-    constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane / WP, col = lane - sub * WP;
-    int idx[ITER];
+// sample 0, columns past W land in the row's padding since WS > WP), so a fill is a
+// straight run of global loads with all of them in flight together.  The fill is
+// split in two so that the loads for the NEXT SS symbols (from a predicted base) can
+// be issued before the current symbols are computed and be stored afterwards.
+template <int NV, int WP> struct ClockFill {
+    static constexpr int RPI = 64 / WP;                       // rows per wave instruction
+    static constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
     float2 v[ITER];
-    (void)W;
-    const int last = (int)(N - 1);
+    __device__ __forceinline__ void issue(const int *base, const float2 *__restrict__ x, long long N)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = lane / WP, col = lane - sub * WP;
+        const int last = (int)(N - 1);
+        int idx[ITER];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int row = min((it * NV + wave) * RPI + sub, 63);
-        idx[it] = min(max(t.wb[row], 0) + col, last);
+        for (int it = 0; it < ITER; ++it) {
+            const int row = min((it * NV + wave) * RPI + sub, 63);
+            idx[it] = min(max(base[row], 0) + col, last);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
     }
+    __device__ __forceinline__ void commit(float2 *tile, int WS) const
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = lane / WP, col = lane - sub * WP;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int row = min((it * NV + wave) * RPI + sub, 63);
-        t.tile[row * WS + col] = v[it];
+        for (int it = 0; it < ITER; ++it) {
+            const int row = min((it * NV + wave) * RPI + sub, 63);
+            tile[row * WS + col] = v[it];
+        }
     }
-}
+};
 
 __device__ __forceinline__ cf32 clock_step_tiled(const ClockTile &t, int lane, const float2 *__restrict__ x, int W,
                                                  int WS, ClockState &s, const ClockPar &par)
@@ -240,8 +247,8 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
                                                              const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
                                                              int *__restrict__ nrun, long long N, long long ni, int K,
-                                                             int NS, ClockPar par, int SS, int W, int WS,
-                                                             const int *__restrict__ ctl)
+                                                             int NS, ClockPar par, int SS, int W, int WS, int A,
+                                                             int AMIN, const int *__restrict__ ctl)
 {
     if (ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,16 +274,23 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         if (NV > 1 && variant == 1) clock_shift(s, CLK_H_T);
         if (NV > 1 && variant == 2) s.omega += CLK_H_W;
     }
+    ClockFill<NV, WP> fill;
+    if (variant == 0) t.wb[lane] = alive ? (int)s.ii : -1;
+    __syncthreads();
+    fill.issue(t.wb, x, N);
+    fill.commit(t.tile, WS);
+    __syncthreads();
     for (int s0 = 0; s0 < NS; s0 += SS) {
-        if (variant == 0) t.wb[lane] = alive ? (int)(s.ii > 0 ? s.ii - 1 : 0) : -1;
+        const bool more = s0 + SS < NS;
+        // the read index advances by at least AMIN over SS symbols: request the next window from there now,
+        // so that its loads overlap the symbols computed below
+        if (more && variant == 0) t.nb[lane] = alive ? (int)s.ii + AMIN : -1;
         __syncthreads();
-        clock_tile_fill<NV, WP>(t, x, N, W, WS);
-        __syncthreads();
+        if (more) fill.issue(t.nb, x, N);
         const int lim = min(SS, NS - s0);
         // fast path: every lane of the wave is running, stays inside its staged window for the whole
         // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only
         const long long off0 = s.ii - t.wb[lane];
-        const int A = W - XR_MM_NTAPS - 1;      // bound on the read-index advance over SS symbols
         const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
         if (__all(safe)) {
             const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
@@ -292,6 +306,11 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
                     ++produced;
                 }
             }
+        }
+        __syncthreads();
+        if (more) {
+            fill.commit(t.tile, WS);
+            if (variant == 0) t.wb[lane] = t.nb[lane];
         }
         __syncthreads();
     }
@@ -330,7 +349,8 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                                                           int *__restrict__ counts, float *__restrict__ soft,
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
                                                           long long ni, int K, int NS, ClockPar par,
-                                                          int *__restrict__ terminal, int SS, int W, int WS)
+                                                          int *__restrict__ terminal, int SS, int W, int WS, int A,
+                                                          int AMIN)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 otile[64][CLK_OT + 1];
@@ -346,16 +366,21 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
     if (mine) s = S[k];
     int produced = 0;
     bool alive = mine;
+    ClockFill<1, WP> fill;
+    t.wb[lane] = alive ? (int)s.ii : -1;
+    __syncthreads();
+    fill.issue(t.wb, x, N);
+    fill.commit(t.tile, WS);
+    __syncthreads();
     for (int i0 = 0; i0 < NS; i0 += CLK_OT) {
         const int olim = min(CLK_OT, NS - i0);
         for (int s0 = 0; s0 < olim; s0 += SS) {
-            t.wb[lane] = alive ? (int)(s.ii > 0 ? s.ii - 1 : 0) : -1;
+            const bool more = i0 + s0 + SS < NS;
+            if (more) t.nb[lane] = alive ? (int)s.ii + AMIN : -1;
             __syncthreads();
-            clock_tile_fill<1, WP>(t, x, N, W, WS);
-            __syncthreads();
+            if (more) fill.issue(t.nb, x, N);
             const int lim = min(SS, olim - s0);
             const long long off0 = s.ii - t.wb[lane];
-            const int A = W - XR_MM_NTAPS - 1;
             const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
             if (__all(safe)) {
                 const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
@@ -375,6 +400,11 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                         ++produced;
                     }
                 }
+            }
+            __syncthreads();
+            if (more) {
+                fill.commit(t.tile, WS);
+                t.wb[lane] = t.nb[lane];
             }
             __syncthreads();
         }
@@ -627,7 +657,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 #define XR_CLK_PASS(NV, WPV)                                                                                          \
     hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x, table.as<float>(), \
                        S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, \
-                       j.SS, j.W, j.WS, clock_ctl(counters))
+                       j.SS, j.W, j.WS, j.A, j.AMIN, clock_ctl(counters))
             if (p < jac_passes) { if (j.wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
             else { if (j.wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
 #undef XR_CLK_PASS
@@ -659,11 +689,11 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
         if (j.wide)
             hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
                                S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS);
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.AMIN);
         else
             hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
                                S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS);
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.AMIN);
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
                            st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
@@ -725,14 +755,23 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.terminal = flags.as<int>() + 3 * K;
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
-    // staged window: SS symbols ahead, at the fastest admissible symbol clock
+    // staged window.  Over SS symbols the read index advances by A at most and AMIN at least; a window is
+    // requested from (index + AMIN) one sub-step ahead, so it must hold the uncertainty (A - AMIN), one sample
+    // for the finite-difference lanes, the advance itself and the 8 interpolator taps.
     const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
-    int SS = 4;               // measured at C2: 2 symbols per fill is 1.5x slower, 8 needs 64-lane rows (VGPR bound)
-    while (SS > 1 && (int)ceil(SS * max_adv) + 2 + XR_MM_NTAPS > 32) --SS;
-    int W = (int)ceil(SS * max_adv) + 1 + XR_MM_NTAPS + 1;
+    const double min_adv = (double)par.omega_mid - (double)par.omega_lim - 0.004;
+    int SS = 4, A = 0, AMIN = 0, W = 0;
+    for (;; --SS) {
+        A = (int)ceil(SS * max_adv) + 1;
+        AMIN = (int)floor(SS * min_adv) - 1;
+        if (AMIN < 0) AMIN = 0;
+        W = (A - AMIN) + 1 + A + XR_MM_NTAPS;
+        if (W <= 32 || SS == 1) break;
+    }
     if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
     j.wide = W > 32;
-    j.SS = SS; j.W = W; j.WS = (j.wide ? 64 : 32) + 1;     // rows are one sample longer than the lanes that fill them
+    j.SS = SS; j.W = W; j.A = A; j.AMIN = AMIN;
+    j.WS = (j.wide ? 64 : 32) + 1;     // rows are one sample longer than the lanes that fill them
     j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
