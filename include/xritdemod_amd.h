@@ -133,7 +133,9 @@ typedef struct xrit_demod_stats {
 int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s);
 
 /* Per-kernel timing with HIP events on the stream the kernels are launched on.
- * enable=1 brackets every launch of the following process calls. */
+ * enable=1 brackets every launch of the following process calls; enable=2 only the decimating FIR (the
+ * launch that reads the input) -- an event record is a queue barrier that stops neighbouring kernels from
+ * overlapping, about 0.27 ms per 256 Mi-sample burst when all ~70 launches are bracketed; enable=0: off. */
 int xrit_demod_profile(xrit_demod *d, int enable);
 /* name/ms arrays are filled with up to cap entries (accumulated since enable);
  * launches[] = number of launches per kernel.  Returns entries written. */

@@ -332,6 +332,7 @@ class Demodulator(_Handle):
         return s
 
     def profile(self, enable=True):
+        """True/1: bracket every kernel with HIP events; 2: only the decimating FIR; False/0: off."""
         _check(lib().xrit_demod_profile(self._h, int(enable)))
 
     def profile_read(self):

@@ -345,6 +345,7 @@ int xrit_demod_profile(xrit_demod *d, int enable)
 {
     if (!d) return XRIT_E_INVALID;
     d->prof.enabled = enable != 0;
+    d->prof.light = enable == 2;
     d->prof.reset();
     return XRIT_OK;
 }
