@@ -506,6 +506,7 @@ __global__ void clock_decide_kernel(const unsigned *__restrict__ cnt, int *__res
     const float q = newton_unfix(*reinterpret_cast<const unsigned long long *>(cnt + 4));
     const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
     ctl[4] = __float_as_int(q);
+    ctl[5] = (cnt[3] != 0 || __uint_as_float(cnt[2]) > 0.02f) ? 1 : 0;   // trust gate only while residuals are large
     if (cnt[0] == 0) { ctl[0] = 1; ctl[2] = 0; return; }
     const bool stalled = q > 0.55f * q_prev;
     if (ctl[1] >= min_passes && cnt[3] == 0 && stalled) ctl[0] = 1;
@@ -775,6 +776,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, clock_ctl(counters) + 5, 1, 1);   // first solve: gated
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);

@@ -317,7 +317,7 @@ struct CostasPolicy {
 };
 
 // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits)
-__global__ void costas_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, float accept)
+__global__ void costas_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, float accept, float gate)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0 || ctl[0]) return;
     ctl[1] += 1;
@@ -326,6 +326,7 @@ __global__ void costas_decide_kernel(const unsigned *__restrict__ cnt, int *__re
     const float max_r = __uint_as_float(cnt[2]);
     // nothing moved, or what is still open sits within a factor two of the tolerance: accept
     if (cnt[0] == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
+    ctl[5] = max_r > gate ? 1 : 0;     // residuals this small cannot leave the trust region: skip the gate scan
 }
 
 __global__ void fill_int_kernel(int *p, int v, int n)
@@ -398,7 +399,7 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
                 return XRIT_E_INVALID;
             }
             hipLaunchKernelGGL(costas_decide_kernel, dim3(1), dim3(1), 0, s, pol.cnt, costas_ctl(counters),
-                               2.0f * tol_phase);
+                               2.0f * tol_phase, 0.02f * trust);
         }
     }
     return XRIT_OK;
@@ -444,6 +445,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 2) * 8 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(1), 0, s, costas_ctl(counters) + 5, 1, 1);   // first solve: gated
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);

@@ -22,7 +22,9 @@
 //   bool   P::outside_trust(d1, d2)
 //   void   P::update(k, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
 //   unsigned* P::cnt                      this pass's counter slot
-//   const int* P::done                    non-zero: the hand-off has closed, the solve is a no-op
+//   const int* P::done                    control block: [0] non-zero = the hand-off has closed, the solve is a
+//                                         no-op; [5] non-zero = residuals are still large enough for the trust
+//                                         gate to matter (else kernel B returns at once and C scans un-gated)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -135,7 +137,7 @@ template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long long n, const AffMap *agg0, AffMap *agg1,
                                                                    float2 *dlin)
 {
-    if (*p.done) return;
+    if (p.done[0] || !p.done[5]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap pre = aff_lookback(agg0, buf);
@@ -166,19 +168,24 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long lon
 }
 
 template <typename P>
-__global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg1,
-                                                                    const float2 *dlin)
+__global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg0,
+                                                                    const AffMap *agg1, const float2 *dlin)
 {
     if (*p.done) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
-    AffMap pre = aff_lookback(agg1, buf);
+    const bool gated = p.done[5] != 0;
+    AffMap pre = aff_lookback(gated ? agg1 : agg0, buf);
     AffMap e[NEWTON_IPT];
     AffMap v = aff_identity();
     for (int q = 0; q < NEWTON_IPT; ++q) {
         if (i0 + q < n) {
-            float2 dl = dlin[i0 + q];
-            e[q] = newton_element(p, i0 + q, p.outside_trust(dl.x, dl.y));
+            bool cut = false;
+            if (gated) {
+                float2 dl = dlin[i0 + q];
+                cut = p.outside_trust(dl.x, dl.y);
+            }
+            e[q] = newton_element(p, i0 + q, cut);
         } else {
             e[q] = aff_identity();
         }
@@ -239,7 +246,7 @@ static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dl
     AffMap *agg0 = aggs, *agg1 = aggs + nb + 1;
     hipLaunchKernelGGL(newton_reduce_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0);
     hipLaunchKernelGGL(newton_gate_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin);
-    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg1, dlin);
+    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin);
     return 0;
 }
 
