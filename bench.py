@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
     ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
+    ap.add_argument("--slices", type=int, default=0, help="time slices per call (0 = library default, 1 = off)")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +82,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     cfg = xa.Demodulator.config("lrit", fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
-                                clock_chain_syms=args.clock_chain)
+                                clock_chain_syms=args.clock_chain, slices=args.slices)
     dem = xa.Demodulator(cfg)
     sps = dem.sps
     cap = int(n_burst / (D * sps * 0.99)) + 64

@@ -83,8 +83,11 @@ typedef struct xrit_demod_config {
     int32_t  clock_chain_syms;  /* symbols per clock-recovery chain */
     int32_t  max_passes;        /* hand-off passes before giving up (per loop) */
     int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED instead of accepting the residual */
-    int32_t  clock_min_passes;  /* clock hand-off passes always run (0 = default 5); max_passes caps both loops */
-    int32_t  reserved[7];
+    int32_t  clock_min_passes;  /* clock hand-off passes always run (0 = default); max_passes caps both loops */
+    int32_t  slices;            /* > 1: cut a large call into that many time slices so that the front end of one
+                                   overlaps the loops of the previous on a second stream (0/1 = off, the default:
+                                   measured slower on MI355X, see demod.cpp) */
+    int32_t  reserved[6];
 } xrit_demod_config;
 
 /* setLRITMode / setHRITMode + Parameters.h defaults (demodulator.cpp:177-197) */

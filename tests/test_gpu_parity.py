@@ -256,6 +256,18 @@ def test_capacity_and_argument_errors(xa):
         xa.Demodulator(bad)
 
 
+def test_time_slices_are_chunk_invariant(xa, oracle_mod):
+    """cfg.slices > 1 overlaps the front end of one slice with the loops of the previous on a second stream; the
+    symbols must be the ones of the un-sliced call (state is carried from slice to slice)."""
+    x = synth_signal(6000000, fs_in=6.25e6)
+    want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, 5)).process(x)
+    one = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5)).process(x)
+    three = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, slices=3)).process(x)
+    assert len(one) == len(three) == len(want)
+    check_symbols(three, want)
+    assert rms(one - three) <= 4e-4 and (np.sign(one) == np.sign(three))[np.abs(want) > 1e-3].all()
+
+
 def test_run_to_run_determinism(xa):
     """Two fresh handles on the same input give bit-identical symbols (the hand-off passes, their stop test and
     every reduction are order independent)."""

@@ -26,7 +26,7 @@ class DemodConfig(C.Structure):
                 ("clock_omega_limit", C.c_float),
                 ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
                 ("max_passes", C.c_int32), ("strict", C.c_int32), ("clock_min_passes", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("slices", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class DemodStats(C.Structure):

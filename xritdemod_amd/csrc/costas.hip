@@ -349,13 +349,6 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     return XRIT_OK;
 }
 
-float2 *CostasStage::stat_slot(size_t n)
-{
-    const size_t K = (n + (size_t)L - 1) / (size_t)L;
-    if (stat.reserve((K + 1) * sizeof(float2)) != XRIT_OK) return nullptr;
-    return stat.as<float2>();
-}
-
 void CostasStage::release()
 {
     state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();
@@ -422,8 +415,8 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
 // Everything of one call is put on the stream without waiting: guess, a batch of hand-off passes (each one a
 // no-op once the device-side test has declared the hand-off closed), the final pass and the copy of the control
 // block.  finish() is called after the caller has synchronised the stream.
-int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
-                       double2 *om, long long om_off, double inv_sps)
+int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof,
+                       const float2 *stat_ext, double2 *om, long long om_off, double inv_sps)
 {
     passes = 0;
     unconverged = 0;
@@ -449,18 +442,20 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
-            if (!stat_ready)
+            const float2 *st = stat_ext;      // statistic left by the producer (FIR epilogue) or computed here
+            if (!st) {
                 hipLaunchKernelGGL(costas_stat_kernel, dim3(div_up((size_t)K, 4)), dim3(256), 0, s, in, stat.as<float2>(),
                                    (long long)n, L, K);
-            UnwrapF uf{stat.as<float2>(), th2};
+                st = stat.as<float2>();
+            }
+            UnwrapF uf{st, th2};
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(scan_aggs_kernel<UnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbK);
             hipLaunchKernelGGL(scan_apply_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(costas_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, th2, S.as<float2>(), K, L);
-            hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, stat.as<float2>(), S.as<float2>(), st_in, K,
-                               L, gains);
+            hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains);
             hipLaunchKernelGGL(fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, flags.as<int>(), 1, K);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
@@ -514,10 +509,10 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
     return XRIT_OK;
 }
 
-int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext,
                      double2 *om, long long om_off, double inv_sps)
 {
-    XR_TRY(begin(in, out, n, s, prof, stat_ready, om, om_off, inv_sps));
+    XR_TRY(begin(in, out, n, s, prof, stat_ext, om, om_off, inv_sps));
     XR_HIP(hipStreamSynchronize(s));
     return finish(s, prof, nullptr);
 }

@@ -51,7 +51,9 @@ struct xrit_demod {
     AgcStage agc;
     CostasStage costas;
     ClockStage clock;
-    DevBuf bufA, bufB, in_dev, soft_dev, q_in, q_out;
+    DevBuf bufA[2], bufB[2], stat[2], in_dev, soft_dev, q_in, q_out;   // two sets: one per time slice in flight
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_fe[2] = {nullptr, nullptr}, ev_lp[2] = {nullptr, nullptr};
     bool keep_stages = false;
     DevBuf stage_buf[5];
     size_t stage_n[5] = {0, 0, 0, 0, 0};
@@ -164,7 +166,12 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
     d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
     int rc = XRIT_OK;
     do {
-        if (hipStreamCreate(&d->stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+        if (hipStreamCreate(&d->stream) != hipSuccess || hipStreamCreate(&d->stream2) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+        bool ev_ok = hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && ev_ok; ++i)
+            ev_ok = hipEventCreateWithFlags(&d->ev_fe[i], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&d->ev_lp[i], hipEventDisableTiming) == hipSuccess;
+        if (!ev_ok) { set_error("hipEventCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
@@ -188,7 +195,11 @@ void xrit_demod_destroy(xrit_demod *d)
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    d->bufA.release(); d->bufB.release(); d->in_dev.release(); d->soft_dev.release();
+    for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->stat[i].release(); }
+    d->in_dev.release(); d->soft_dev.release();
+    if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
+    if (d->ev_in) (void)hipEventDestroy(d->ev_in);
+    for (int i = 0; i < 2; ++i) { if (d->ev_fe[i]) (void)hipEventDestroy(d->ev_fe[i]); if (d->ev_lp[i]) (void)hipEventDestroy(d->ev_lp[i]); }
     d->q_in.release(); d->q_out.release();
     for (auto &b : d->stage_buf) b.release();
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -207,31 +218,36 @@ static int keep_stage(xrit_demod *d, int idx, const void *src, size_t n, hipStre
     return XRIT_OK;
 }
 
-int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, int type, float *d_soft, size_t cap,
-                              size_t *n_out, void *stream)
+// ---- one time slice through the chain, in two halves ------------------------------------------------------
+// front_end(): ingest conversion, decimator, AGC, RRC (demodulator.cpp:54-74,136-149) into buffer set `set`;
+// loops(): Costas and clock recovery (:152-157) on what front_end() left.  Split so that the front end of the
+// next slice can run on a second stream while the feedback loops of this one iterate.
+struct SliceIO {
+    size_t length = 0;          // circuit-rate samples
+    const float2 *rrc = nullptr;
+    bool stat_ready = false;
+};
+
+static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set, hipStream_t s, Profiler *prof,
+                     SliceIO *io)
 {
-    if (!d || !n_out || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
-    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
-    *n_out = 0;
-    XR_HIP(hipSetDevice(d->device));
-    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
-    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
     const unsigned D = d->cfg.decimation;
     size_t length = n;
-    const float2 *cur = nullptr;
     if (D > 1) length = n / D;   // demodulator.cpp:137 -- the remainder of the chunk is dropped
-    XR_TRY(d->bufA.reserve((length + 8) * sizeof(float2)));
-    XR_TRY(d->bufB.reserve((length + 8) * sizeof(float2)));
-    float2 *A = d->bufA.as<float2>(), *B = d->bufB.as<float2>();
+    io->length = length;
+    XR_TRY(d->bufA[set].reserve((length + 8) * sizeof(float2)));
+    XR_TRY(d->bufB[set].reserve((length + 8) * sizeof(float2)));
+    float2 *A = d->bufA[set].as<float2>(), *B = d->bufB[set].as<float2>();
+    const float2 *cur = nullptr;
     if (D > 1) {
-        XR_TRY(d->dec.run(d_samples, type, A, length, s, prof));   // :138
+        XR_TRY(d->dec.run(in, type, A, length, s, prof));          // :138
         cur = A;
     } else if (type != XRIT_SAMPLE_FLOATIQ) {
         ProfScope ps(prof, "convert", s);
-        XR_TRY(launch_convert(d_samples, type, A, length, s));     // :57-70
+        XR_TRY(launch_convert(in, type, A, length, s));            // :57-70
         cur = A;
     } else {
-        cur = reinterpret_cast<const float2 *>(d_samples);
+        cur = reinterpret_cast<const float2 *>(in);
     }
     XR_TRY(keep_stage(d, 0, cur, length, s));
     XR_TRY(d->agc.run(cur, B, length, s, prof));                   // :143
@@ -239,10 +255,20 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
     const int L = d->costas.L;
-    float2 *stat = length ? d->costas.stat_slot(length) : nullptr;
-    const bool stat_ready = stat && d->rrc.stat_supported(L);
-    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof, stat_ready ? stat : nullptr, L)); // :148
+    const size_t K = (length + (size_t)L - 1) / (size_t)L;
+    XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
+    io->stat_ready = length > 0 && d->rrc.stat_supported(L);
+    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L)); // :148
     XR_TRY(keep_stage(d, 2, A, length, s));
+    io->rrc = A;
+    return XRIT_OK;
+}
+
+static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_t cap, size_t *nsym, hipStream_t s,
+                 Profiler *prof)
+{
+    const size_t length = io.length;
+    const int L = d->costas.L;
     float2 *slot = nullptr;
     XR_TRY(d->clock.input_slot(length, &slot, s));
     const size_t carry0 = d->clock.carry;
@@ -257,7 +283,8 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         sym = d->stage_buf[4].as<float2>();
     }
     const double inv_sps = 1.0 / (double)d->sps;
-    XR_TRY(d->costas.begin(A, slot, length, s, prof, stat_ready, om, (long long)carry0, inv_sps));
+    const float2 *stat = io.stat_ready ? d->stat[set].as<float2>() : nullptr;
+    XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
     XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
     XR_HIP(hipStreamSynchronize(s));
     bool redone = false;
@@ -269,28 +296,100 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         XR_HIP(hipStreamSynchronize(s));
     }
     XR_TRY(keep_stage(d, 3, slot, length, s));
-    size_t nsym = 0;
-    int rc = d->clock.finish(&nsym, s, prof);
+    int rc = d->clock.finish(nsym, s, prof);
     if (d->keep_stages) XR_HIP(hipStreamSynchronize(s));
-    if (prof) d->prof.collect();
-    d->stage_n[4] = nsym;
-    d->stats.samples_in = n;
-    d->stats.circuit_samples = length;
-    d->stats.symbols_out = nsym;
-    d->stats.costas_passes = d->costas.passes;
-    d->stats.clock_passes = d->clock.passes;
-    d->stats.costas_unconverged = d->costas.unconverged;
-    d->stats.clock_unconverged = d->clock.unconverged;
-    d->stats.costas_max_residual = d->costas.max_residual;
-    d->stats.clock_max_residual = d->clock.max_residual;
-    {
-        float flag = 0.f;   // the stream is idle here: clock.run() ended with a synchronise
-        if (length && d->agc.fallback_flag(&flag, s) == XRIT_OK) d->stats.agc_serial_fallback = flag == 2.0f;
+    return rc;
+}
+
+int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, int type, float *d_soft, size_t cap,
+                              size_t *n_out, void *stream)
+{
+    if (!d || !n_out || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    *n_out = 0;
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    const unsigned D = d->cfg.decimation;
+    const size_t esz = type == XRIT_SAMPLE_FLOATIQ ? 8 : (type == XRIT_SAMPLE_S16IQ ? 4 : 2);
+
+    // A call can be cut into time slices so that the front end of slice c+1 (stream 2) overlaps the feedback
+    // loops of slice c (caller's stream).  The chain is chunk invariant (state is carried from slice to slice
+    // exactly as from call to call) and slices are multiples of decimation x 5120 samples, so nothing is dropped
+    // between them.  Off unless asked for (cfg.slices > 1): measured at C2, every extra slice costs ~0.5 ms of
+    // per-slice fixed work (solves, guesses, one host synchronise) and the concurrent kernels slow each other
+    // down, 3.4 ms -> 3.8 / 4.3 / 4.8 ms for 2 / 3 / 4 slices.
+    const size_t quantum = (size_t)D * 5120;
+    size_t slices = 1;
+    if (!d->keep_stages && d->cfg.slices > 1 && n >= ((size_t)1 << 22)) {
+        slices = (size_t)d->cfg.slices;
+        while (slices > 1 && n / slices < ((size_t)1 << 20)) --slices;
     }
-    *n_out = nsym;
+    const size_t per = slices > 1 ? (n / slices) / quantum * quantum : n;
+
+    size_t total_sym = 0, total_len = 0;
+    int rc = XRIT_OK;
+    int worst_cp = 0, worst_kp = 0;
+    unsigned unc_c = 0, unc_k = 0;
+    float res_c = 0, res_k = 0;
+    SliceIO io[2];
+    hipStream_t s2 = d->stream2;
+    if (slices > 1) {
+        // stream 2 may read the caller's buffer only after whatever the caller queued on its stream
+        XR_HIP(hipEventRecord(d->ev_in, s));
+        XR_HIP(hipStreamWaitEvent(s2, d->ev_in, 0));
+    }
+    for (size_t c = 0; c < slices && rc == XRIT_OK; ++c) {
+        const size_t off = c * per;
+        const size_t cnt = (c + 1 == slices) ? n - off : per;
+        const int set = (int)(c & 1);
+        if (c == 0) {
+            XR_TRY(front_end(d, (const char *)d_samples + off * esz, cnt, type, set, slices > 1 ? s2 : s, prof, &io[set]));
+            if (slices > 1) XR_HIP(hipEventRecord(d->ev_fe[set], s2));
+        }
+        if (c + 1 < slices) {
+            // front end of the next slice: its buffers were last read by the loops of slice c-1
+            const size_t off1 = (c + 1) * per;
+            const size_t cnt1 = (c + 2 == slices) ? n - off1 : per;
+            const int set1 = (int)((c + 1) & 1);
+            if (c >= 1) XR_HIP(hipStreamWaitEvent(s2, d->ev_lp[set1], 0));
+            XR_TRY(front_end(d, (const char *)d_samples + off1 * esz, cnt1, type, set1, s2, prof, &io[set1]));
+            XR_HIP(hipEventRecord(d->ev_fe[set1], s2));
+        }
+        if (slices > 1) XR_HIP(hipStreamWaitEvent(s, d->ev_fe[set], 0));
+        size_t nsym = 0;
+        rc = loops(d, io[set], set, d_soft ? d_soft + total_sym : nullptr, cap > total_sym ? cap - total_sym : 0, &nsym, s,
+                   prof);
+        if (slices > 1) XR_HIP(hipEventRecord(d->ev_lp[set], s));
+        total_sym += nsym;
+        total_len += io[set].length;
+        worst_cp = d->costas.passes > worst_cp ? d->costas.passes : worst_cp;
+        worst_kp = d->clock.passes > worst_kp ? d->clock.passes : worst_kp;
+        unc_c += d->costas.unconverged;
+        unc_k += d->clock.unconverged;
+        res_c = d->costas.max_residual > res_c ? d->costas.max_residual : res_c;
+        res_k = d->clock.max_residual > res_k ? d->clock.max_residual : res_k;
+    }
+    if (slices > 1) XR_HIP(hipStreamSynchronize(s2));
+    if (prof) d->prof.collect();
+    d->stage_n[4] = total_sym;
+    d->stats.samples_in = n;
+    d->stats.circuit_samples = total_len;
+    d->stats.symbols_out = total_sym;
+    d->stats.costas_passes = worst_cp;
+    d->stats.clock_passes = worst_kp;
+    d->stats.costas_unconverged = unc_c;
+    d->stats.clock_unconverged = unc_k;
+    d->stats.costas_max_residual = res_c;
+    d->stats.clock_max_residual = res_k;
+    {
+        float flag = 0.f;   // the streams are idle here
+        if (total_len && d->agc.fallback_flag(&flag, s) == XRIT_OK) d->stats.agc_serial_fallback = flag == 2.0f;
+    }
+    *n_out = total_sym;
     if (rc != XRIT_OK) return rc;
-    if (d->cfg.strict && d->costas.unconverged) {
-        set_error("Costas hand-off did not close: %u boundaries above tolerance", d->costas.unconverged);
+    if (d->cfg.strict && unc_c) {
+        set_error("Costas hand-off did not close: %u boundaries above tolerance", unc_c);
         return XRIT_E_NOT_CONVERGED;
     }
     return XRIT_OK;

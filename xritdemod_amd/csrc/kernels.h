@@ -52,13 +52,13 @@ struct CostasStage {
     float max_residual = 0;
     int init(float loop_bw, int chain_len, int max_passes);
     void release();
-    // stat_ready: stat_slot(n) was filled by the producer (FIR epilogue); om (optional): receives the clock
-    // recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
-    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready = false,
+    // stat_ext (optional): sum z^2 per chain already left by the producer (FIR epilogue); om (optional): receives
+    // the clock recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext = nullptr,
             double2 *om = nullptr, long long om_off = 0, double inv_sps = 0.0);
     // the same in two halves: begin() only enqueues (guess, a batch of passes with a device-side stop test, final
     // pass); finish() runs after the caller synchronised the stream and continues the passes if they did not close
-    int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool stat_ready,
+    int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext,
               double2 *om, long long om_off, double inv_sps);
     bool closed() const;
     int finish(hipStream_t s, Profiler *prof, bool *redone);
@@ -69,7 +69,6 @@ struct CostasStage {
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
     } job;
     int batch = 4;          // passes enqueued before the host looks (3 suffice on a locked signal)
-    float2 *stat_slot(size_t n);
     int get_state(float *phase, float *freq, hipStream_t s);
 };
 
