@@ -150,8 +150,8 @@ def main():
     own_bytes = {
         "fir_decim": 8.0 + c8,            # read the input once, write the decimated stream
         "agc_reduce": c8, "agc_apply": 2 * c8, "fir_rrc": 2 * c8,
-        "costas_guess": c8, "costas_pass": c8, "costas_final": 2 * c8,
-        "clock_guess": c8, "clock_pass_jac": c8, "clock_pass": c8, "clock_output": c8 + 4.0 / (D * sps),
+        "costas_pass": c8, "costas_final": 2 * c8,      # the guesses read per-chain statistics only (fused upstream)
+        "clock_pass_jac": c8, "clock_pass": c8, "clock_output": c8 + 4.0 / (D * sps),
     }
     roofline = None
     kernels = {}
