@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own copy of the HIP runtime; when libxritdemod_amd.so (linked against /opt/rocm) initialises
+# HIP first, torch's copy then reports "No HIP GPUs are available".  Loading torch first makes both share one
+# runtime.  Only the GPU tests that allocate through torch need it; the product itself never imports torch.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

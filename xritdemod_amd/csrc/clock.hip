@@ -168,16 +168,24 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
 // Sample access.  A lane advances through its chain at its own, data dependent
 // pace, reading an 8-sample window per symbol; done straight from global memory
 // every wave instruction touches 64 different cache lines.  Instead the block
-// stages, for every chain, the window it will need during the next SS symbols
-// (W samples from the base lane's read index - 1) with coalesced loads: a row of W
-// samples is one contiguous run, WP lanes per row.  Rows are WS = W|1 float2 apart
-// so that the per-lane ds_read_b64 stay spread over the banks.  A lane whose read
-// index leaves its staged window (possible only for perturbed or wildly wrong
-// states) reads global memory for that symbol.
+// keeps, for every chain, a ring of R = WP samples in LDS (row stride WS = R + 1
+// float2 so that the per-lane ds_read_b64 stay spread over the banks).  The ring of
+// a chain that starts at read index ii0 begins at origin = ii0 - CLK_M and moves
+// on a FIXED schedule: during sub-step j (SS symbols) it holds samples
+// origin + cum_j + [0, R), cum_j = floor(j * SS * omega_mid).  Within a chain the
+// read index stays within a sample or two of that schedule (omega is clipped to
+// +-omega_lim around omega_mid), so the samples a sub-step adds -- cum_{j+1} - cum_j
+// per row -- are known without looking at the state: they are requested before
+// the current symbols are computed and stored afterwards (sample a lives in slot
+// (a - origin) mod R), and every sample is fetched once.  A wave in which some lane
+// has left its ring (acquisition, wildly wrong start, end of input) computes that
+// sub-step from global memory.
+constexpr int CLK_M = 2;      // samples kept below the start index
+constexpr int CLK_SLACK = 3;  // head room above the schedule: R >= CLK_M + CLK_SLACK + A + 8
+
 struct ClockTile {
     float *table;          // 129 x 8
-    int *wb;               // window base per chain (-1: row unused); the buffer index fits 32 bits
-    int *nb;               // base of the window being prefetched for the next SS symbols
+    int *wb;               // ring origin per chain (-1: row unused); the buffer index fits 32 bits
     float2 *tile;          // 64 x WS
 };
 
@@ -186,56 +194,73 @@ __device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
     ClockTile t;
     t.table = reinterpret_cast<float *>(smem);
     t.wb = reinterpret_cast<int *>(smem + 4160);
-    t.nb = reinterpret_cast<int *>(smem + 4160 + 256);
-    t.tile = reinterpret_cast<float2 *>(smem + 4160 + 512);
+    t.tile = reinterpret_cast<float2 *>(smem + 4160 + 256);
     return t;
 }
 
-static inline size_t clock_tile_bytes(int WS) { return 4160 + 512 + (size_t)64 * WS * sizeof(float2); }
+static inline size_t clock_tile_bytes(int WS) { return 4160 + 256 + (size_t)64 * WS * sizeof(float2); }
 
 // All threads of the block (NV waves).  WP lanes cover one row, 64/WP rows per wave
-// instruction.  No predication: indices are clamped instead (an idle row re-reads
-// sample 0, columns past W land in the row's padding since WS > WP), so a fill is a
-// straight run of global loads with all of them in flight together.  The fill is
-// split in two so that the loads for the NEXT SS symbols (from a predicted base) can
-// be issued before the current symbols are computed and be stored afterwards.
+// instruction; lane column c fetches sample origin + first + c and stores it in
+// slot (first + c) mod WP, columns >= ncol stay idle.  Indices are clamped, not
+// predicated per load (an unused row re-reads sample 0), so a fill is a straight run
+// of global loads with all of them in flight together.  The fill is split in two so
+// that the loads for the NEXT sub-step can be issued before the current symbols are
+// computed and be stored afterwards.
 template <int NV, int WP> struct ClockFill {
     static constexpr int RPI = 64 / WP;                       // rows per wave instruction
     static constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
     float2 v[ITER];
-    __device__ __forceinline__ void issue(const int *base, const float2 *__restrict__ x, long long N)
+    __device__ __forceinline__ void issue(const int *origin, int first, int ncol, const float2 *__restrict__ x,
+                                          long long N)
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int sub = lane / WP, col = lane - sub * WP;
         const int last = (int)(N - 1);
-        int idx[ITER];
+        if (col < ncol) {
+            int idx[ITER];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int row = min((it * NV + wave) * RPI + sub, 63);
-            idx[it] = min(max(base[row], 0) + col, last);
+            for (int it = 0; it < ITER; ++it) {
+                const int row = min((it * NV + wave) * RPI + sub, 63);
+                idx[it] = min(max(origin[row], 0) + first + col, last);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
         }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
     }
-    __device__ __forceinline__ void commit(float2 *tile, int WS) const
+    __device__ __forceinline__ void commit(float2 *tile, int WS, int first, int ncol) const
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int sub = lane / WP, col = lane - sub * WP;
+        if (col < ncol) {
+            const int slot = (first + col) & (WP - 1);
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int row = min((it * NV + wave) * RPI + sub, 63);
-            tile[row * WS + col] = v[it];
+            for (int it = 0; it < ITER; ++it) {
+                const int row = min((it * NV + wave) * RPI + sub, 63);
+                tile[row * WS + slot] = v[it];
+            }
         }
     }
 };
 
-__device__ __forceinline__ cf32 clock_step_tiled(const ClockTile &t, int lane, const float2 *__restrict__ x, int W,
-                                                 int WS, ClockState &s, const ClockPar &par)
+// ring position of the schedule after jj sub-steps (16.16 fixed point step)
+__device__ __forceinline__ int clock_cum(int jj, int STEP) { return (int)(((long long)jj * STEP) >> 16); }
+
+// One symbol from the ring: the window x[ii .. ii+7] sits in slots (off + k) mod R, off = ii - origin.
+template <int R>
+__device__ __forceinline__ cf32 clock_step_ring(const cf32 *row, int &off, const float *table, ClockState &s,
+                                                const ClockPar &par)
 {
-    const long long off = s.ii - t.wb[lane];
-    if (off >= 0 && off + XR_MM_NTAPS <= W)
-        return clock_step_w(reinterpret_cast<const cf32 *>(t.tile + lane * WS + off), t.table, s, par);
-    return clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
+    cf32 w[XR_MM_NTAPS];
+#pragma unroll
+    for (int k = 0; k < XR_MM_NTAPS; ++k) w[k] = row[(off + k) & (R - 1)];
+    ClockState t = s;
+    t.ii = 0;
+    cf32 p = clock_step_w(w, table, t, par);
+    off += (int)t.ii;
+    t.ii = s.ii;
+    s = t;
+    return p;
 }
 
 // NV == 3 (192 threads): wave 0 = base trajectories of 64 chains, wave 1 = start
@@ -248,7 +273,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
                                                              int *__restrict__ nrun, long long N, long long ni, int K,
                                                              int NS, ClockPar par, int SS, int W, int WS, int A,
-                                                             int AMIN, const int *__restrict__ ctl)
+                                                             int STEP, const int *__restrict__ ctl)
 {
     if (ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,43 +300,43 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         if (NV > 1 && variant == 2) s.omega += CLK_H_W;
     }
     ClockFill<NV, WP> fill;
-    if (variant == 0) t.wb[lane] = alive ? (int)s.ii : -1;
+    if (variant == 0) t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
     __syncthreads();
-    fill.issue(t.wb, x, N);
-    fill.commit(t.tile, WS);
+    const int origin = t.wb[lane];
+    fill.issue(t.wb, 0, WP, x, N);
+    fill.commit(t.tile, WS, 0, WP);
     __syncthreads();
-    for (int s0 = 0; s0 < NS; s0 += SS) {
+    int off = (int)(s.ii - origin), cum = 0, jj = 0;
+    for (int s0 = 0; s0 < NS; s0 += SS, ++jj) {
         const bool more = s0 + SS < NS;
-        // the read index advances by at least AMIN over SS symbols: request the next window from there now,
-        // so that its loads overlap the symbols computed below
-        if (more && variant == 0) t.nb[lane] = alive ? (int)s.ii + AMIN : -1;
-        __syncthreads();
-        if (more) fill.issue(t.nb, x, N);
+        // the samples the next sub-step adds to the rings: request them now, so that the loads overlap the
+        // symbols computed below
+        const int cum_next = clock_cum(jj + 1, STEP);
+        if (more) fill.issue(t.wb, cum + WP, cum_next - cum, x, N);
         const int lim = min(SS, NS - s0);
-        // fast path: every lane of the wave is running, stays inside its staged window for the whole
-        // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only
-        const long long off0 = s.ii - t.wb[lane];
-        const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
+        // fast path: every lane of the wave is running, stays inside its ring for the whole sub-step and
+        // cannot reach the end of the input -> no per-symbol guards, LDS reads only
+        const int rel = off - cum;
+        const bool safe = alive && lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
+                          (long long)origin + off + A < ni;
         if (__all(safe)) {
             const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
-            int off = (int)off0;
-            for (int i = 0; i < SS; ++i) clock_step_rel(rowp, off, t.table, s, par);
-            s.ii = t.wb[lane] + off;
+            for (int i = 0; i < SS; ++i) clock_step_ring<WP>(rowp, off, t.table, s, par);
+            s.ii = (long long)origin + off;
             produced += SS;
         } else {
             for (int i = 0; i < lim; ++i) {
                 if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
                 if (alive) {
-                    clock_step_tiled(t, lane, x, W, WS, s, par);
+                    clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
                     ++produced;
                 }
             }
+            off = (int)(s.ii - origin);
         }
         __syncthreads();
-        if (more) {
-            fill.commit(t.tile, WS);
-            if (variant == 0) t.wb[lane] = t.nb[lane];
-        }
+        if (more) fill.commit(t.tile, WS, cum, cum_next - cum);
+        cum = cum_next;
         __syncthreads();
     }
     if (NV > 1) {
@@ -350,7 +375,7 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
                                                           long long ni, int K, int NS, ClockPar par,
                                                           int *__restrict__ terminal, int SS, int W, int WS, int A,
-                                                          int AMIN)
+                                                          int STEP)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 otile[64][CLK_OT + 1];
@@ -367,45 +392,45 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
     int produced = 0;
     bool alive = mine;
     ClockFill<1, WP> fill;
-    t.wb[lane] = alive ? (int)s.ii : -1;
+    t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
     __syncthreads();
-    fill.issue(t.wb, x, N);
-    fill.commit(t.tile, WS);
+    const int origin = t.wb[lane];
+    fill.issue(t.wb, 0, WP, x, N);
+    fill.commit(t.tile, WS, 0, WP);
     __syncthreads();
+    int off = (int)(s.ii - origin), cum = 0, jj = 0;
     for (int i0 = 0; i0 < NS; i0 += CLK_OT) {
         const int olim = min(CLK_OT, NS - i0);
-        for (int s0 = 0; s0 < olim; s0 += SS) {
+        for (int s0 = 0; s0 < olim; s0 += SS, ++jj) {      // SS divides CLK_OT: only the last sub-step may be short
             const bool more = i0 + s0 + SS < NS;
-            if (more) t.nb[lane] = alive ? (int)s.ii + AMIN : -1;
-            __syncthreads();
-            if (more) fill.issue(t.nb, x, N);
+            const int cum_next = clock_cum(jj + 1, STEP);
+            if (more) fill.issue(t.wb, cum + WP, cum_next - cum, x, N);
             const int lim = min(SS, olim - s0);
-            const long long off0 = s.ii - t.wb[lane];
-            const bool safe = alive && lim == SS && off0 >= 0 && off0 + A + XR_MM_NTAPS <= W && s.ii + A < ni;
+            const int rel = off - cum;
+            const bool safe = alive && lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
+                              (long long)origin + off + A < ni;
             if (__all(safe)) {
                 const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
-                int off = (int)off0;
                 for (int i = 0; i < SS; ++i) {
-                    cf32 p = clock_step_rel(rowp, off, t.table, s, par);
+                    cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
                     otile[lane][s0 + i] = make_float2(p.x, p.y);
                 }
-                s.ii = t.wb[lane] + off;
+                s.ii = (long long)origin + off;
                 produced += SS;
             } else {
                 for (int i = 0; i < lim; ++i) {
                     if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
                     if (alive) {
-                        cf32 p = clock_step_tiled(t, lane, x, W, WS, s, par);
+                        cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
                         otile[lane][s0 + i] = make_float2(p.x, p.y);
                         ++produced;
                     }
                 }
+                off = (int)(s.ii - origin);
             }
             __syncthreads();
-            if (more) {
-                fill.commit(t.tile, WS);
-                t.wb[lane] = t.nb[lane];
-            }
+            if (more) fill.commit(t.tile, WS, cum, cum_next - cum);
+            cum = cum_next;
             __syncthreads();
         }
         made[lane] = produced - i0;          // symbols of this tile that exist (may be <= 0)
@@ -658,7 +683,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 #define XR_CLK_PASS(NV, WPV)                                                                                          \
     hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x, table.as<float>(), \
                        S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, \
-                       j.SS, j.W, j.WS, j.A, j.AMIN, clock_ctl(counters))
+                       j.SS, j.W, j.WS, j.A, j.STEP, clock_ctl(counters))
             if (p < jac_passes) { if (j.wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
             else { if (j.wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
 #undef XR_CLK_PASS
@@ -690,11 +715,11 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
         if (j.wide)
             hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
                                S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.AMIN);
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP);
         else
             hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
                                S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.AMIN);
+                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP);
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
                            st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
@@ -756,23 +781,22 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.terminal = flags.as<int>() + 3 * K;
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
-    // staged window.  Over SS symbols the read index advances by A at most and AMIN at least; a window is
-    // requested from (index + AMIN) one sub-step ahead, so it must hold the uncertainty (A - AMIN), one sample
-    // for the finite-difference lanes, the advance itself and the 8 interpolator taps.
+    // sample rings (see ClockTile).  Over SS symbols the read index advances by A at most; a ring of R samples
+    // must hold CLK_M below the schedule, CLK_SLACK above it, the advance and the 8 interpolator taps.  SS
+    // divides the output tile (16 symbols).
     const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
-    const double min_adv = (double)par.omega_mid - (double)par.omega_lim - 0.004;
-    int SS = 4, A = 0, AMIN = 0, W = 0;
-    for (;; --SS) {
+    static const int tries[6][2] = {{32, 4}, {32, 2}, {64, 4}, {32, 1}, {64, 2}, {64, 1}};
+    int SS = 1, A = 0, R = 64;
+    for (int q = 0; q < 6; ++q) {
+        R = tries[q][0];
+        SS = tries[q][1];
         A = (int)ceil(SS * max_adv) + 1;
-        AMIN = (int)floor(SS * min_adv) - 1;
-        if (AMIN < 0) AMIN = 0;
-        W = (A - AMIN) + 1 + A + XR_MM_NTAPS;
-        if (W <= 32 || SS == 1) break;
+        if (CLK_M + CLK_SLACK + A + XR_MM_NTAPS <= R) break;    // else: very large sps, sub-steps run from global memory
     }
-    if (W > 64) W = 64;      // very large sps: part of the reads fall back to global memory
-    j.wide = W > 32;
-    j.SS = SS; j.W = W; j.A = A; j.AMIN = AMIN;
-    j.WS = (j.wide ? 64 : 32) + 1;     // rows are one sample longer than the lanes that fill them
+    j.wide = R > 32;
+    j.SS = SS; j.W = R; j.A = A;
+    j.STEP = (int)floor((double)SS * (double)par.omega_mid * 65536.0);
+    j.WS = R + 1;
     j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));

@@ -111,7 +111,7 @@ struct ClockStage {
     int enqueue_output(hipStream_t s, Profiler *prof);
     struct Job {
         size_t n = 0, cap = 0; float *soft = nullptr; float2 *sym = nullptr;
-        long long N = 0, ni = 0; int K = 0, enqueued = 0, SS = 0, W = 0, WS = 0, A = 0, AMIN = 0; bool wide = false, short_input = false;
+        long long N = 0, ni = 0; int K = 0, enqueued = 0, SS = 0, W = 0, WS = 0, A = 0, STEP = 0; bool wide = false, short_input = false;
         size_t tile_bytes = 0;
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
