@@ -200,46 +200,42 @@ __device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
 
 static inline size_t clock_tile_bytes(int WS) { return 4160 + 256 + (size_t)64 * WS * sizeof(float2); }
 
-// All threads of the block (NV waves).  WP lanes cover one row, 64/WP rows per wave
-// instruction; lane column c fetches sample origin + first + c and stores it in
-// slot (first + c) mod WP, columns >= ncol stay idle.  Indices are clamped, not
-// predicated per load (an unused row re-reads sample 0), so a fill is a straight run
-// of global loads with all of them in flight together.  The fill is split in two so
-// that the loads for the NEXT sub-step can be issued before the current symbols are
-// computed and be stored afterwards.
-template <int NV, int WP> struct ClockFill {
-    static constexpr int RPI = 64 / WP;                       // rows per wave instruction
-    static constexpr int ITER = (64 / RPI + NV - 1) / NV;     // instructions per wave
-    float2 v[ITER];
-    __device__ __forceinline__ void issue(const int *origin, int first, int ncol, const float2 *__restrict__ x,
-                                          long long N)
+// All threads of the block (NV waves).  A fill moves nc consecutive samples of every row, starting at
+// origin + first, into ring slots (first + col) mod R; only columns < ncol are stored (a sub-step adds nc or
+// nc - 1 samples, the surplus column is the first sample of the next fill: same cache line, no traffic).  The
+// 64 x nc elements are dealt to the lanes in row-major order, IT wave instructions per wave; every lane keeps
+// its elements' source index and LDS position in registers (prepare), so a fill is a straight run of
+// unconditional global loads that are all in flight together -- issued before the symbols they overlap are
+// computed, stored afterwards.  The loads must not sit under a lane predicate: the registers would become
+// phis and the compiler would wait for the data on the spot.
+template <int NV, int IT> struct ClockFill {
+    int gb[IT];         // sample index of the element at first = 0 (unused rows and surplus elements: 0)
+    int lc[IT];         // (row * WS) << 8 | col, -1: nothing to store
+    float2 v[IT];
+    __device__ __forceinline__ void prepare(const int *origin, int nc, int WS)
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int sub = lane / WP, col = lane - sub * WP;
-        const int last = (int)(N - 1);
-        if (col < ncol) {
-            int idx[ITER];
+        const int magic = 65536 / nc + 1;                 // floor(e / nc) = (e * magic) >> 16 for e < 64 * 64
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int row = min((it * NV + wave) * RPI + sub, 63);
-                idx[it] = min(max(origin[row], 0) + first + col, last);
-            }
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) v[it] = x[idx[it]];
+        for (int it = 0; it < IT; ++it) {
+            const int e = (it * NV + wave) * 64 + lane;
+            const int row = (e * magic) >> 16, col = e - row * nc;
+            const bool ok = row < 64;
+            gb[it] = ok ? max(origin[min(row, 63)], 0) + col : 0;
+            lc[it] = ok ? ((row * WS) << 8) | col : -1;
         }
     }
-    __device__ __forceinline__ void commit(float2 *tile, int WS, int first, int ncol) const
+    __device__ __forceinline__ void issue(int first, const float2 *__restrict__ x, int last)
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int sub = lane / WP, col = lane - sub * WP;
-        if (col < ncol) {
-            const int slot = (first + col) & (WP - 1);
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int row = min((it * NV + wave) * RPI + sub, 63);
-                tile[row * WS + slot] = v[it];
-            }
-        }
+        for (int it = 0; it < IT; ++it) v[it] = x[min(gb[it] + first, last)];
+    }
+    template <int R> __device__ __forceinline__ void commit(float2 *tile, int first, int ncol) const
+    {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+            if ((unsigned)(lc[it] & 255) < (unsigned)ncol && lc[it] >= 0)
+                tile[(lc[it] >> 8) + ((first + lc[it]) & (R - 1))] = v[it];
     }
 };
 
@@ -263,11 +259,121 @@ __device__ __forceinline__ cf32 clock_step_ring(const cf32 *row, int &off, const
     return p;
 }
 
+// interpolator table -> LDS.  All loads are issued before the first store: as a plain copy loop the compiler
+// emits load / wait / store per element, 17 serial memory latencies at the head of every 64-thread block.
+template <int NTHR>
+__device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__restrict__ src)
+{
+    constexpr int NEL = (XR_MM_NSTEPS + 1) * XR_MM_NTAPS;
+    constexpr int NIT = (NEL + NTHR - 1) / NTHR;
+    float tv[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) tv[q] = src[min((int)threadIdx.x + q * NTHR, NEL - 1)];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+        const int i = (int)threadIdx.x + q * NTHR;
+        if (i < NEL) dst[i] = tv[q];
+    }
+}
+
+// SS symbols of one lane.  Fast path: every running lane of the wave stays inside its ring for the whole
+// sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only.  Otherwise the wave
+// computes the sub-step from global memory with the guards.  orow (output pass): where the symbols go.
+template <int WP, bool OUT>
+__device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *__restrict__ x, int WS, int lane,
+                                              int origin, int cum, int lim, int SS, int A, long long ni,
+                                              const ClockPar &par, ClockState &s, int &off, bool &alive,
+                                              int &produced, float2 *orow)
+{
+    const int rel = off - cum;
+    const bool safe = !alive || (lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
+                                 (long long)origin + off + A < ni);
+    if (__all(safe)) {
+        if (alive) {
+            const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
+            for (int i = 0; i < SS; ++i) {
+                cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
+                if (OUT) orow[i] = make_float2(p.x, p.y);
+            }
+            s.ii = (long long)origin + off;
+            produced += SS;
+        }
+    } else {
+        for (int i = 0; i < lim; ++i) {
+            if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
+            if (alive) {
+                cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
+                if (OUT) orow[i] = make_float2(p.x, p.y);
+                ++produced;
+            }
+        }
+        off = (int)(s.ii - origin);
+    }
+}
+
+// The sub-step loop with the ring fills two sub-steps ahead of the compute: the samples sub-step j+2 adds are
+// requested (into registers) before sub-step j is computed and stored after sub-step j+1.  compute(j, cum_j)
+// does the work of sub-step j.  Called by all threads of the block, t.wb (ring origins) already visible.
+template <int NV, int WP, int IT, typename Compute>
+__device__ __forceinline__ void clock_pipeline(const ClockTile &t, const float2 *__restrict__ x, long long N, int WS,
+                                               int nsub, int STEP, Compute &&compute)
+{
+    const int last = (int)(N - 1);
+    {
+        // the first window: all R columns of every row
+        ClockFill<NV, (WP + NV - 1) / NV> w;
+        w.prepare(t.wb, WP, WS);
+        w.issue(0, x, last);
+        w.template commit<WP>(t.tile, 0, WP);
+    }
+    const int nc = (STEP >> 16) + 1;
+    if constexpr (IT * NV > 32) {
+        // wide rings (sps > ~18): one fill in flight -- two would not fit the register file
+        ClockFill<NV, IT> f;
+        f.prepare(t.wb, nc, WS);
+        lds_barrier();
+        int c0 = 0;
+        for (int j = 0; j < nsub; ++j) {
+            const int c1 = clock_cum(j + 1, STEP);
+            if (j + 1 < nsub) f.issue(c0 + WP, x, last);
+            compute(j, c0);
+            lds_barrier();
+            if (j + 1 < nsub) f.template commit<WP>(t.tile, c0 + WP, c1 - c0);
+            lds_barrier();
+            c0 = c1;
+        }
+        return;
+    }
+    ClockFill<NV, IT> f0, f1;
+    f0.prepare(t.wb, nc, WS);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { f1.gb[it] = f0.gb[it]; f1.lc[it] = f0.lc[it]; }
+    lds_barrier();
+    int c0 = 0, c1 = clock_cum(1, STEP);
+    if (nsub > 1) f1.issue(c0 + WP, x, last);
+    for (int j = 0; j < nsub; j += 2) {
+        const int c2 = clock_cum(j + 2, STEP), c3 = clock_cum(j + 3, STEP);
+        if (j + 2 < nsub) f0.issue(c1 + WP, x, last);
+        compute(j, c0);
+        lds_barrier();
+        if (j + 1 < nsub) f1.template commit<WP>(t.tile, c0 + WP, c1 - c0);
+        lds_barrier();
+        if (j + 1 >= nsub) break;
+        if (j + 3 < nsub) f1.issue(c2 + WP, x, last);
+        compute(j + 1, c1);
+        lds_barrier();
+        if (j + 2 < nsub) f0.template commit<WP>(t.tile, c1 + WP, c2 - c1);
+        lds_barrier();
+        c0 = c2;
+        c1 = c3;
+    }
+}
+
 // NV == 3 (192 threads): wave 0 = base trajectories of 64 chains, wave 1 = start
 // shifted by h_t, wave 2 = omega shifted by h_w; the base lane forms the
 // finite-difference Jacobian.  NV == 1 (64 threads): base trajectories only, the
 // Jacobian of an earlier pass is kept (quasi-Newton).
-template <int NV, int WP>
+template <int NV, int WP, int NCM>
 __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                              const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
@@ -288,7 +394,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
     if (threadIdx.x == 0) any_run = 0;
     __syncthreads();
     if (run && variant == 0) any_run = 1;
-    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) t.table[i] = table_g[i];
+    clock_table_to_lds<64 * NV>(t.table, table_g);
     __syncthreads();
     if (!any_run) return;
     ClockState s{};
@@ -299,46 +405,15 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
         if (NV > 1 && variant == 1) clock_shift(s, CLK_H_T);
         if (NV > 1 && variant == 2) s.omega += CLK_H_W;
     }
-    ClockFill<NV, WP> fill;
     if (variant == 0) t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
     __syncthreads();
     const int origin = t.wb[lane];
-    fill.issue(t.wb, 0, WP, x, N);
-    fill.commit(t.tile, WS, 0, WP);
-    __syncthreads();
-    int off = (int)(s.ii - origin), cum = 0, jj = 0;
-    for (int s0 = 0; s0 < NS; s0 += SS, ++jj) {
-        const bool more = s0 + SS < NS;
-        // the samples the next sub-step adds to the rings: request them now, so that the loads overlap the
-        // symbols computed below
-        const int cum_next = clock_cum(jj + 1, STEP);
-        if (more) fill.issue(t.wb, cum + WP, cum_next - cum, x, N);
-        const int lim = min(SS, NS - s0);
-        // fast path: every lane of the wave is running, stays inside its ring for the whole sub-step and
-        // cannot reach the end of the input -> no per-symbol guards, LDS reads only
-        const int rel = off - cum;
-        const bool safe = alive && lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
-                          (long long)origin + off + A < ni;
-        if (__all(safe)) {
-            const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
-            for (int i = 0; i < SS; ++i) clock_step_ring<WP>(rowp, off, t.table, s, par);
-            s.ii = (long long)origin + off;
-            produced += SS;
-        } else {
-            for (int i = 0; i < lim; ++i) {
-                if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
-                if (alive) {
-                    clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
-                    ++produced;
-                }
-            }
-            off = (int)(s.ii - origin);
-        }
-        __syncthreads();
-        if (more) fill.commit(t.tile, WS, cum, cum_next - cum);
-        cum = cum_next;
-        __syncthreads();
-    }
+    int off = (int)(s.ii - origin);
+    const int nsub = (NS + SS - 1) / SS;
+    clock_pipeline<NV, WP, (NCM + NV - 1) / NV>(t, x, N, WS, nsub, STEP, [&](int j, int cum) {
+        clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                 produced, nullptr);
+    });
     if (NV > 1) {
         // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
         if (variant == 0) ref_ii[lane] = s.ii;
@@ -368,7 +443,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
 // CLK_OT symbols per chain and written out row-wise (4 lanes x 16 B per chain row).
 constexpr int CLK_OT = 16;
 
-template <int WP>
+template <int WP, int NCM>
 __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
@@ -381,7 +456,7 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
     __shared__ float2 otile[64][CLK_OT + 1];
     __shared__ int made[64];
     const ClockTile t = clock_tile_carve(smem);
-    for (int i = threadIdx.x; i < (XR_MM_NSTEPS + 1) * XR_MM_NTAPS; i += blockDim.x) t.table[i] = table_g[i];
+    clock_table_to_lds<64>(t.table, table_g);
     __syncthreads();
     const int lane = threadIdx.x;
     const int kbase = blockIdx.x * 64;
@@ -391,50 +466,20 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
     if (mine) s = S[k];
     int produced = 0;
     bool alive = mine;
-    ClockFill<1, WP> fill;
     t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
     __syncthreads();
     const int origin = t.wb[lane];
-    fill.issue(t.wb, 0, WP, x, N);
-    fill.commit(t.tile, WS, 0, WP);
-    __syncthreads();
-    int off = (int)(s.ii - origin), cum = 0, jj = 0;
-    for (int i0 = 0; i0 < NS; i0 += CLK_OT) {
+    int off = (int)(s.ii - origin);
+    const int nsub = (NS + SS - 1) / SS;
+    int i0 = 0;                                   // first symbol of the output tile being collected
+    clock_pipeline<1, WP, NCM>(t, x, N, WS, nsub, STEP, [&](int j, int cum) {
+        const int s0 = j * SS - i0;               // SS divides CLK_OT: a sub-step never straddles two tiles
+        clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                produced, &otile[lane][s0]);
+        if (s0 + SS < CLK_OT && j + 1 < nsub) return;
         const int olim = min(CLK_OT, NS - i0);
-        for (int s0 = 0; s0 < olim; s0 += SS, ++jj) {      // SS divides CLK_OT: only the last sub-step may be short
-            const bool more = i0 + s0 + SS < NS;
-            const int cum_next = clock_cum(jj + 1, STEP);
-            if (more) fill.issue(t.wb, cum + WP, cum_next - cum, x, N);
-            const int lim = min(SS, olim - s0);
-            const int rel = off - cum;
-            const bool safe = alive && lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
-                              (long long)origin + off + A < ni;
-            if (__all(safe)) {
-                const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
-                for (int i = 0; i < SS; ++i) {
-                    cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
-                    otile[lane][s0 + i] = make_float2(p.x, p.y);
-                }
-                s.ii = (long long)origin + off;
-                produced += SS;
-            } else {
-                for (int i = 0; i < lim; ++i) {
-                    if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
-                    if (alive) {
-                        cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
-                        otile[lane][s0 + i] = make_float2(p.x, p.y);
-                        ++produced;
-                    }
-                }
-                off = (int)(s.ii - origin);
-            }
-            __syncthreads();
-            if (more) fill.commit(t.tile, WS, cum, cum_next - cum);
-            cum = cum_next;
-            __syncthreads();
-        }
         made[lane] = produced - i0;          // symbols of this tile that exist (may be <= 0)
-        __syncthreads();
+        lds_barrier();
         // row-wise write: lane l handles chain (it*16 + l/4), symbols (l%4)*4 .. +3
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -462,8 +507,9 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                 }
             }
         }
-        __syncthreads();
-    }
+        lds_barrier();
+        i0 += CLK_OT;
+    });
     if (!mine) return;
     E[k] = s;
     counts[k] = produced;
@@ -680,12 +726,20 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
         const int p = job.enqueued;
         {
             ProfScope ps(prof, p < jac_passes ? "clock_pass_jac" : "clock_pass", s);
-#define XR_CLK_PASS(NV, WPV)                                                                                          \
-    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x, table.as<float>(), \
-                       S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, \
-                       j.SS, j.W, j.WS, j.A, j.STEP, clock_ctl(counters))
-            if (p < jac_passes) { if (j.wide) XR_CLK_PASS(3, 64); else XR_CLK_PASS(3, 32); }
-            else { if (j.wide) XR_CLK_PASS(1, 64); else XR_CLK_PASS(1, 32); }
+#define XR_CLK_PASS(NV, WPV, NCM)                                                                                     \
+    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV, NCM>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x,             \
+                       table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun,    \
+                       j.N, j.ni, j.K, NS, par, j.SS, j.W, j.WS, j.A, j.STEP, clock_ctl(counters))
+#define XR_CLK_PASS_NV(NV)                                                                                            \
+    do {                                                                                                              \
+        if (!j.wide && narrow) XR_CLK_PASS(NV, 32, 20);                                                               \
+        else if (!j.wide) XR_CLK_PASS(NV, 32, 32);                                                                    \
+        else XR_CLK_PASS(NV, 64, 64);                                                                                 \
+    } while (0)
+            const bool narrow = (j.STEP >> 16) + 1 <= 20;      // columns a sub-step adds to a ring
+            if (p < jac_passes) XR_CLK_PASS_NV(3);
+            else XR_CLK_PASS_NV(1);
+#undef XR_CLK_PASS_NV
 #undef XR_CLK_PASS
         }
         {
@@ -712,14 +766,15 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
     {
         ProfScope ps(prof, "clock_output", s);
         hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
-        if (j.wide)
-            hipLaunchKernelGGL(clock_output_kernel<64>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
-                               S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP);
-        else
-            hipLaunchKernelGGL(clock_output_kernel<32>, dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(),
-                               S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,
-                               j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP);
+#define XR_CLK_OUT(WPV, NCM)                                                                                          \
+    hipLaunchKernelGGL((clock_output_kernel<WPV, NCM>), dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(), \
+                       S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,   \
+                       j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP)
+        const bool narrow = (j.STEP >> 16) + 1 <= 20;
+        if (!j.wide && narrow) XR_CLK_OUT(32, 20);
+        else if (!j.wide) XR_CLK_OUT(32, 32);
+        else XR_CLK_OUT(64, 64);
+#undef XR_CLK_OUT
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
                            st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
@@ -785,7 +840,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // must hold CLK_M below the schedule, CLK_SLACK above it, the advance and the 8 interpolator taps.  SS
     // divides the output tile (16 symbols).
     const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
-    static const int tries[6][2] = {{32, 4}, {32, 2}, {64, 4}, {32, 1}, {64, 2}, {64, 1}};
+    static const int tries[6][2] = {{32, 4}, {32, 2}, {32, 1}, {64, 4}, {64, 2}, {64, 1}};
     int SS = 1, A = 0, R = 64;
     for (int q = 0; q < 6; ++q) {
         R = tries[q][0];

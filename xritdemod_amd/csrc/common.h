@@ -129,6 +129,18 @@ struct ProfScope {
     ~ProfScope() { if (p) p->end(s); }
 };
 
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. it waits
+// for every outstanding global load (s_waitcnt vmcnt(0)) -- which would serialise register prefetches that
+// are meant to stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace xrit
