@@ -562,27 +562,6 @@ __global__ void __launch_bounds__(1024) clock_tail_kernel(const float2 *__restri
     if ((int)threadIdx.x < carry) x[threadIdx.x] = tail[threadIdx.x];
 }
 
-// After every solve: ctl[0] done, ctl[1] passes run, ctl[2] open boundaries, ctl[3] max residual (bits),
-// ctl[4] previous summed squared residual (bits).  The recurrence is chaotic at the 1e-5 level
-// (interpolator-arm quantisation), so boundaries keep moving by that much for ever; what must close are the
-// LARGE residuals (acquisition at the head of a cold-started call, symbol slips: decision flips kick mu by up
-// to ~2e-3, acquisition and slips leave residuals >> 0.02 samples).  After that the passes go on only while
-// the summed squared residual still falls by > 45 % per pass.
-__global__ void clock_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, int min_passes)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0 || ctl[0]) return;
-    ctl[1] += 1;
-    ctl[2] = (int)cnt[1];
-    ctl[3] = (int)cnt[2];
-    const float q = newton_unfix(*reinterpret_cast<const unsigned long long *>(cnt + 4));
-    const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
-    ctl[4] = __float_as_int(q);
-    ctl[5] = (cnt[3] != 0 || __uint_as_float(cnt[2]) > 0.02f) ? 1 : 0;   // trust gate only while residuals are large
-    if (cnt[0] == 0) { ctl[0] = 1; ctl[2] = 0; return; }
-    const bool stalled = q > 0.55f * q_prev;
-    if (ctl[1] >= min_passes && cnt[3] == 0 && stalled) ctl[0] = 1;
-}
-
 // ------------------------------------------------------------ hand-off solve
 // Policy for newton.h.  State components: (t = ii + mu, omega).  A residual of m
 // whole symbol periods is carried as a slip count (aux) that shifts all later chains.
@@ -594,7 +573,7 @@ struct ClockPolicy {
     const int *nrun;      // symbols chain k produced when it last ran
     unsigned *cnt;        // [0] changed, [1] not frozen, [2] max |r_t| bits, [3] large, [4] sum r_t^2 (float)
     float trust_t, trust_w, tol_t, tol_w;
-    const int *done;      // control block word 0
+    int min_passes;
 
     __device__ bool active(long long k) const { return nrun[k] > 0; }
     __device__ void residual(long long k, float &r1, float &r2, int &aux) const
@@ -642,6 +621,29 @@ struct ClockPolicy {
         st.sum_sq += newton_fix(r1 * r1);
         const bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
         if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; st.changed += 1; }
+    }
+    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] open boundaries, ctl[3] max residual (bits),
+    // ctl[4] previous summed squared residual (bits).  The recurrence is chaotic at the 1e-5 level
+    // (interpolator-arm quantisation), so boundaries keep moving by that much for ever; what must close are the
+    // LARGE residuals (acquisition at the head of a cold-started call, symbol slips: decision flips kick mu by up
+    // to ~2e-3, acquisition and slips leave residuals >> 0.02 samples).  After that the passes go on only while
+    // the summed squared residual still falls by > 45 % per pass.
+    __device__ void decide(int *ctl) const
+    {
+        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1);
+        const unsigned mr = newton_cnt_load(cnt + 2), large = newton_cnt_load(cnt + 3);
+        const unsigned long long sq = (unsigned long long)newton_cnt_load(cnt + 4) |
+                                      ((unsigned long long)newton_cnt_load(cnt + 5) << 32);
+        ctl[1] += 1;
+        ctl[2] = (int)open_;
+        ctl[3] = (int)mr;
+        const float q = newton_unfix(sq);
+        const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
+        ctl[4] = __float_as_int(q);
+        ctl[5] = (large != 0 || __uint_as_float(mr) > 0.02f) ? 1 : 0;   // trust gate only while residuals are large
+        if (changed == 0) { ctl[0] = 1; ctl[2] = 0; return; }
+        const bool stalled = q > 0.55f * q_prev;
+        if (ctl[1] >= min_passes && large == 0 && stalled) ctl[0] = 1;
     }
 };
 
@@ -719,7 +721,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
     const Job &j = job;
     ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, nullptr,
-                    0.75f, 0.01f, tol_t, tol_w, clock_ctl(counters)};
+                    0.75f, 0.01f, tol_t, tol_w, min_passes};
     const unsigned gridK = div_up((size_t)j.K, 64);
     const float2 *x = xbuf.as<float2>();
     for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
@@ -745,11 +747,10 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
         {
             ProfScope ps(prof, "clock_solve", s);
             pol.cnt = clock_cnt(counters, p);
-            if (newton_solve(pol, (long long)j.K - 1, work.as<AffMap>(), dlin.as<float2>(), s) != 0) {
+            if (newton_solve(pol, (long long)j.K - 1, work.as<AffMap>(), dlin.as<float2>(), clock_ctl(counters), s) != 0) {
                 set_error("clock hand-off: %d chains exceed the solver's block budget", j.K);
                 return XRIT_E_INVALID;
             }
-            hipLaunchKernelGGL(clock_decide_kernel, dim3(1), dim3(1), 0, s, pol.cnt, clock_ctl(counters), min_passes);
         }
     }
     return XRIT_OK;
@@ -824,11 +825,11 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
-    XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(flags.reserve((size_t)(3 * K + 4) * sizeof(int)));
     XR_TRY(om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))));
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;
+    XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(work.reserve((size_t)(2 * nbmax + 6) * sizeof(AffMap)));
     j.dirty = flags.as<int>();
     j.counts = flags.as<int>() + K;

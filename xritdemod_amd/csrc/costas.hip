@@ -279,7 +279,7 @@ struct CostasPolicy {
     int *dirty;
     unsigned *cnt;           // [0] changed, [1] not frozen, [2] max |r_phase| bits
     float trust_p, trust_f, tol_p, tol_f;
-    const int *done;         // control block word 0
+    float accept, gate;      // stop test: accept when max residual <= accept; trust gate needed while > gate
 
     __device__ bool active(long long) const { return true; }
     __device__ void residual(long long k, float &r1, float &r2, int &aux) const
@@ -314,20 +314,19 @@ struct CostasPolicy {
             st.changed += 1;
         }
     }
+    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits)
+    __device__ void decide(int *ctl) const
+    {
+        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1), mr = newton_cnt_load(cnt + 2);
+        ctl[1] += 1;
+        ctl[2] = (int)open_;
+        ctl[3] = (int)mr;
+        const float max_r = __uint_as_float(mr);
+        // nothing moved, or what is still open sits within a factor two of the tolerance: accept
+        if (changed == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
+        ctl[5] = max_r > gate ? 1 : 0;     // residuals this small cannot leave the trust region: skip the gate phase
+    }
 };
-
-// After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits)
-__global__ void costas_decide_kernel(const unsigned *__restrict__ cnt, int *__restrict__ ctl, float accept, float gate)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0 || ctl[0]) return;
-    ctl[1] += 1;
-    ctl[2] = (int)cnt[1];
-    ctl[3] = (int)cnt[2];
-    const float max_r = __uint_as_float(cnt[2]);
-    // nothing moved, or what is still open sits within a factor two of the tolerance: accept
-    if (cnt[0] == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
-    ctl[5] = max_r > gate ? 1 : 0;     // residuals this small cannot leave the trust region: skip the gate scan
-}
 
 __global__ void fill_int_kernel(int *p, int v, int n)
 {
@@ -375,7 +374,7 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
     const long long nel = job.K - 1;
     CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
-                     tol_phase, tol_freq, costas_ctl(counters)};
+                     tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust};
     const unsigned gridK = div_up((size_t)job.K, 64);
     for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
         {
@@ -387,12 +386,10 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
         {
             ProfScope ps(prof, "costas_solve", s);
             pol.cnt = costas_cnt(counters, job.enqueued);
-            if (newton_solve(pol, nel, work.as<AffMap>(), dlin.as<float2>(), s) != 0) {
+            if (newton_solve(pol, nel, work.as<AffMap>(), dlin.as<float2>(), costas_ctl(counters), s) != 0) {
                 set_error("Costas hand-off: %d chains exceed the solver's block budget", job.K);
                 return XRIT_E_INVALID;
             }
-            hipLaunchKernelGGL(costas_decide_kernel, dim3(1), dim3(1), 0, s, pol.cnt, costas_ctl(counters),
-                               2.0f * tol_phase, 0.02f * trust);
         }
     }
     return XRIT_OK;
@@ -431,10 +428,10 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     XR_TRY(E.reserve((size_t)K * sizeof(float2)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
     XR_TRY(stat.reserve((size_t)(K + 1) * sizeof(float2)));
-    XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(flags.reserve((size_t)K * sizeof(int)));
     const int nbK = scan_blocks(K);
     const size_t agg_bytes = (((size_t)(2 * newton_blocks(K) + 4) * sizeof(AffMap)) + 15) & ~(size_t)15;
+    XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 2) * 8 * sizeof(unsigned), s));

@@ -22,9 +22,11 @@
 //   bool   P::outside_trust(d1, d2)
 //   void   P::update(k, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
 //   unsigned* P::cnt                      this pass's counter slot
-//   const int* P::done                    control block: [0] non-zero = the hand-off has closed, the solve is a
-//                                         no-op; [5] non-zero = residuals are still large enough for the trust
-//                                         gate to matter (else kernel B returns at once and C scans un-gated)
+//   void   P::decide(int* ctl)            stop test from the pass's counters; run by one thread of the block
+//                                         of kernel C that finishes last
+//   unsigned* P::cnt                      [0..5] statistics (see NewtonStat), [7] blocks of kernel C done
+//   control block ctl: [0] non-zero = the hand-off has closed, the solve is a no-op; [5] non-zero = residuals
+//   are still large enough for the trust gate to matter (else kernel B returns at once and C scans un-gated)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -121,9 +123,9 @@ __device__ __forceinline__ AffMap newton_element(const P &p, long long k, bool c
 }
 
 template <typename P>
-__global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long long n, AffMap *agg0)
+__global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long long n, AffMap *agg0, const int *ctl)
 {
-    if (*p.done) return;
+    if (ctl[0]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap v = aff_identity();
@@ -135,9 +137,9 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long l
 
 template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long long n, const AffMap *agg0, AffMap *agg1,
-                                                                   float2 *dlin)
+                                                                   float2 *dlin, const int *ctl)
 {
-    if (p.done[0] || !p.done[5]) return;
+    if (ctl[0] || !ctl[5]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     AffMap pre = aff_lookback(agg0, buf);
@@ -169,12 +171,12 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long lon
 
 template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg0,
-                                                                    const AffMap *agg1, const float2 *dlin)
+                                                                    const AffMap *agg1, const float2 *dlin, int *ctl)
 {
-    if (*p.done) return;
+    if (ctl[0]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
-    const bool gated = p.done[5] != 0;
+    const bool gated = ctl[5] != 0;
     AffMap pre = aff_lookback(gated ? agg1 : agg0, buf);
     AffMap e[NEWTON_IPT];
     AffMap v = aff_identity();
@@ -231,22 +233,32 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
             atomicAdd(reinterpret_cast<unsigned long long *>(&p.cnt[4]), t.sum_sq);
         }
         if (t.large) atomicAdd(&p.cnt[3], t.large);
+        // release: this block's statistics; acquire: the block that finishes last sees everybody's and takes
+        // the stop decision (nobody reads ctl any more in this launch) -- no separate decision launch
+        if (__hip_atomic_fetch_add(&p.cnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+            p.decide(ctl);
     }
+}
+
+// counters as the deciding thread must read them (other blocks' atomics)
+__device__ __forceinline__ unsigned newton_cnt_load(const unsigned *c)
+{
+    return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
 
 // agg storage: 2 * (blocks + 1) AffMaps; dlin: n + 1 float2
 template <typename P>
-static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dlin, hipStream_t s)
+static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dlin, int *ctl, hipStream_t s)
 {
     if (n <= 0) return 0;
     const int nb = newton_blocks(n);
     if (nb > NEWTON_MAX_BLOCKS) return -1;
     AffMap *agg0 = aggs, *agg1 = aggs + nb + 1;
-    hipLaunchKernelGGL(newton_reduce_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0);
-    hipLaunchKernelGGL(newton_gate_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin);
-    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin);
+    hipLaunchKernelGGL(newton_reduce_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, ctl);
+    hipLaunchKernelGGL(newton_gate_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin, ctl);
+    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin, ctl);
     return 0;
 }
 
