@@ -9,6 +9,7 @@
 // serially (never seen with normalised SDR samples; kept for exactness).
 #include "kernels.h"
 #include "scan.h"
+#include "agc_wave.h"
 
 namespace xrit {
 
@@ -134,6 +135,98 @@ int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profil
         ProfScope ps(prof, "agc_apply", s);
         hipLaunchKernelGGL(scan_apply_kernel<AgcScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, (long long)n,
                            aggs.as<AgcMap>());
+        hipLaunchKernelGGL(agc_serial_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg,
+                           (long long)n, 0);
+    }
+    XR_HIP(hipGetLastError());
+    cur ^= 1;
+    return XRIT_OK;
+}
+
+// ---- fused path: the producer of `in` (the decimator) has left one composed map per run of 64 * PL samples --
+// the outputs of one of its waves (fir.hip, AgcEpilogue).  Their exclusive prefixes give every run its start
+// gain; here too a run is one wave (PL samples per lane), so the prefix inside a run is a shuffle scan, and the
+// recurrence is replayed literally per lane.
+struct AgcRunF {
+    typedef AgcMap T;
+    __device__ T identity() const { return agc_identity(); }
+    __device__ T combine(const T &lo, const T &hi) const { return agc_compose(lo, hi); }
+};
+
+template <int PL>
+__global__ void __launch_bounds__(256) agc_apply_runs_kernel(const float2 *__restrict__ x, float2 *__restrict__ y,
+                                                             const AgcMap *__restrict__ pre_run,
+                                                             const float *__restrict__ state_in,
+                                                             float *__restrict__ state_out, float rate, float ref,
+                                                             float maxg, long long n)
+{
+    const int lane = threadIdx.x & 63;
+    const long long run = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long i0 = run * (64 * PL) + (long long)lane * PL;
+    int cnt = 0;
+    if (i0 < n) cnt = (int)((n - i0) < PL ? (n - i0) : PL);
+    float2 v[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) v[k] = k < cnt ? x[i0 + k] : make_float2(0.f, 0.f);
+    AgcMap m = agc_identity();
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+        if (k < cnt) m = agc_compose(m, agc_sample_map(v[k].x, v[k].y, rate, ref, maxg));
+    const AgcMap ex = agc_wave_exclusive(m);      // the lanes before this one, in order
+    if (cnt == 0) return;
+    float g = agc_apply(agc_compose(pre_run[run], ex), state_in[0]);
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+        if (k < cnt) {
+            float yr, yi;
+            agc_step(v[k].x, v[k].y, g, rate, ref, maxg, yr, yi);
+            y[i0 + k] = make_float2(yr, yi);
+        }
+    }
+    if (i0 + cnt == n) state_out[0] = g;
+}
+
+int AgcStage::fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi)
+{
+    const size_t rl = (size_t)64 * per_lane;
+    const int nr = (int)((n + rl - 1) / rl);
+    XR_TRY(aggs.reserve((size_t)(nr + scan_blocks(nr) + 8) * sizeof(AgcMap)));
+    float *sout = state.as<float>() + 2 * (cur ^ 1);
+    hipLaunchKernelGGL(agc_begin_kernel, dim3(1), dim3(1), 0, s, sout);
+    epi->maps = aggs.as<AgcMap>();
+    epi->state_out = sout;
+    epi->rate = rate;
+    epi->ref = ref;
+    epi->maxg = maxg;
+    return XRIT_OK;
+}
+
+int AgcStage::fused_finish(const float2 *in, float2 *out, size_t n, int per_lane, hipStream_t s, Profiler *prof)
+{
+    if (n == 0) return XRIT_OK;
+    float *sin_ = state.as<float>() + 2 * cur;
+    float *sout = state.as<float>() + 2 * (cur ^ 1);
+    const size_t rl = (size_t)64 * per_lane;
+    const int nr = (int)((n + rl - 1) / rl);
+    {
+        ProfScope ps(prof, "agc_scan", s);
+        scan_aggs_launch(AgcRunF{}, aggs.as<AgcMap>(), nr, s);
+    }
+    {
+        ProfScope ps(prof, "agc_apply", s);
+        const dim3 grid(div_up((size_t)nr, 4));
+#define XR_AGC_APPLY(PL)                                                                                        \
+    hipLaunchKernelGGL(agc_apply_runs_kernel<PL>, grid, dim3(256), 0, s, in, out, aggs.as<AgcMap>(), sin_, sout, \
+                       rate, ref, maxg, (long long)n)
+        switch (per_lane) {
+        case 1: XR_AGC_APPLY(1); break;
+        case 2: XR_AGC_APPLY(2); break;
+        case 3: XR_AGC_APPLY(3); break;
+        case 4: XR_AGC_APPLY(4); break;
+        case 5: XR_AGC_APPLY(5); break;
+        default: set_error("AGC: unsupported run shape %d", per_lane); return XRIT_E_INVALID;
+        }
+#undef XR_AGC_APPLY
         hipLaunchKernelGGL(agc_serial_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg,
                            (long long)n, 0);
     }

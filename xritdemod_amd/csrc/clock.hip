@@ -908,6 +908,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         XR_HIP(hipStreamSynchronize(s));
     }
     passes = job.K > 1 ? hctl[1] : 0;
+    if (job.K > 1) batch = passes + 1 < 5 ? 5 : (passes + 1 > 8 ? 8 : passes + 1);
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
     memcpy(&max_residual, &hctl[3], sizeof(float));
     if (getenv("XRIT_TRACE") && job.K > 1) {

@@ -239,8 +239,13 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     XR_TRY(d->bufB[set].reserve((length + 8) * sizeof(float2)));
     float2 *A = d->bufA[set].as<float2>(), *B = d->bufB[set].as<float2>();
     const float2 *cur = nullptr;
+    // with a decimator in front, its epilogue leaves the AGC's composed gain maps: the AGC sweeps the stream
+    // twice (scan of the maps aside) instead of three times
+    const bool agc_fused = D > 1 && length > 0 && d->dec.agc_supported();
     if (D > 1) {
-        XR_TRY(d->dec.run(in, type, A, length, s, prof));          // :138
+        AgcEpilogue epi{};
+        if (agc_fused) XR_TRY(d->agc.fused_begin(length, d->dec.RC, s, &epi));
+        XR_TRY(d->dec.run(in, type, A, length, s, prof, nullptr, 0, agc_fused ? &epi : nullptr));          // :138
         cur = A;
     } else if (type != XRIT_SAMPLE_FLOATIQ) {
         ProfScope ps(prof, "convert", s);
@@ -250,7 +255,8 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
         cur = reinterpret_cast<const float2 *>(in);
     }
     XR_TRY(keep_stage(d, 0, cur, length, s));
-    XR_TRY(d->agc.run(cur, B, length, s, prof));                   // :143
+    if (agc_fused) XR_TRY(d->agc.fused_finish(cur, B, length, d->dec.RC, s, prof));   // :143
+    else XR_TRY(d->agc.run(cur, B, length, s, prof));
     XR_TRY(keep_stage(d, 1, B, length, s));
     // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it

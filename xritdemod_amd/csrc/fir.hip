@@ -13,6 +13,7 @@
 // operands.  RC*D odd gives a conflict-free ds_read_b64 lane stride; for even
 // strides the LDS image is skewed by one sample per D (PAD).
 #include "kernels.h"
+#include "agc_wave.h"
 
 namespace xrit {
 
@@ -45,7 +46,7 @@ template <int RC, bool PAD, int TYPE>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
-                 int tile_len, float2 *__restrict__ stat, int statL)
+                 int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
@@ -155,6 +156,25 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
 #pragma unroll
     for (int c = 0; c < RC; ++c)
         if (m0 + c < n_out) out[m0 + c] = acc[c];
+    if (!PAD && agc.maps != nullptr) {
+        // AGC reduce sweep, fused: the composed gain map g -> min(a g + b, c) of every run of 64 * RC outputs,
+        // i.e. of the outputs of one wave.  Composition is not commutative: a lane composes its own outputs in
+        // order, agc_wave_total composes the lanes in order.
+        AgcMap v = agc_identity();
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            if (m0 + c < n_out) {
+                AgcMap e = agc_sample_map(acc[c].x, acc[c].y, agc.rate, agc.ref, agc.maxg);
+                bad |= !(e.a >= 0.0f);
+                v = agc_compose(v, e);
+            }
+        }
+        if (bad) agc.state_out[1] = 1.0f;
+        v = agc_wave_total(v);
+        const int lane = tid & 63;
+        if (lane == 0 && m0 < n_out) agc.maps[m0 / (64 * RC)] = v;
+    }
     if (stat != nullptr) {
         // per-thread partial sums of z^2, split where the thread's outputs cross into the next run
         __syncthreads();                      // the window tile is dead: reuse it
@@ -256,6 +276,11 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     return XRIT_OK;
 }
 
+bool FirStage::agc_supported() const
+{
+    return !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs
+}
+
 bool FirStage::stat_supported(int statL) const
 {
     // runs must not straddle blocks, and the two partial arrays must fit in the window tile
@@ -271,14 +296,14 @@ void FirStage::release()
 
 template <int RC, bool PAD>
 static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out, size_t n_out, size_t n_in,
-                        hipStream_t s, float2 *stat, int statL)
+                        hipStream_t s, float2 *stat, int statL, const AgcEpilogue &agc)
 {
     unsigned blocks = div_up(n_out, (size_t)f.threads * RC);
     const float2 *h = f.hist[f.cur].as<float2>();
     const float *g = f.g.as<float>();
 #define XR_FIR_GO(TY)                                                                                          \
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
-                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL)
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc)
     if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
@@ -288,15 +313,23 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
 }
 
 int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof, float2 *stat,
-                  int statL)
+                  int statL, const AgcEpilogue *agc_in)
 {
     if (stat && !stat_supported(statL)) stat = nullptr;
+    AgcEpilogue agc{nullptr, nullptr, 0.f, 0.f, 0.f};
+    if (agc_in) {
+        if (!agc_supported()) {
+            set_error("FIR: this block shape cannot produce the AGC epilogue");
+            return XRIT_E_INVALID;
+        }
+        agc = *agc_in;
+    }
     size_t n_in = n_out * (size_t)D;
     if (n_out > 0) {
         ProfScope ps(prof, D > 1 ? "fir_decim" : "fir_rrc", s);
-        if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s, stat, statL)));
-        else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s, stat, statL)));
-        else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s, stat, statL)));
+        if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
+        else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
+        else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
     }
     if (T > 1 && n_in > 0) {
         ProfScope ps(prof, "fir_hist", s);

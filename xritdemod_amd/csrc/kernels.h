@@ -18,9 +18,19 @@ struct FirStage {
     void release();
     // consumes n_out*D samples of `in` (sample_type as in FrontendDevice.h:11-13)
     // stat (optional): sum z^2 per run of statL outputs, written when stat_supported(statL)
+    // agc (optional): the AGC's composed gain map per run of 64 * RC outputs, see AgcStage::fused_begin
     int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof,
-            float2 *stat = nullptr, int statL = 0);
+            float2 *stat = nullptr, int statL = 0, const struct AgcEpilogue *agc = nullptr);
     bool stat_supported(int statL) const;
+    bool agc_supported() const;
+};
+
+// What the decimator's epilogue needs to leave the AGC's first sweep behind (AgcStage::fused_begin fills it).
+constexpr int AGC_RUN_MAX_PER_LANE = 5;
+struct AgcEpilogue {
+    struct AgcMap *maps;     // one per run of 64 * RC outputs (the outputs of one wave of the FIR kernel)
+    float *state_out;        // [1] guard flag
+    float rate, ref, maxg;
 };
 
 // ---- AGC (demodulator.cpp:447; Work at :143) ------------------------------
@@ -33,6 +43,10 @@ struct AgcStage {
     int init(float rate, float reference, float gain, float max_gain);
     void release();
     int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    // the same in two halves around the kernel that produces `in` (the decimator): fused_begin() before it
+    // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
+    int fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi);      // per_lane: the producer's RC
+    int fused_finish(const float2 *in, float2 *out, size_t n, int per_lane, hipStream_t s, Profiler *prof);
     int gain(float *g, hipStream_t s);
     int fallback_flag(float *flag, hipStream_t s);
 };
@@ -68,7 +82,8 @@ struct CostasStage {
         const float2 *in = nullptr; float2 *out = nullptr; size_t n = 0; int K = 0; int enqueued = 0;
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
     } job;
-    int batch = 4;          // passes enqueued before the host looks (3 suffice on a locked signal)
+    int batch = 4;          // passes enqueued before the host looks: one more than the previous call needed
+                            // (2 on a locked signal); every surplus pass is ~4 no-op launches of ~5 us
     int get_state(float *phase, float *freq, hipStream_t s);
 };
 
@@ -115,7 +130,8 @@ struct ClockStage {
         size_t tile_bytes = 0;
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
-    int batch = 7;          // passes enqueued before the host looks (5-6 suffice in steady state)
+    int batch = 7;          // passes enqueued before the host looks: one more than the previous call needed
+                            // (5-6 in steady state)
 };
 
 // ---- helpers ---------------------------------------------------------------
