@@ -177,12 +177,12 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         d->dec_ntaps = (int)lp.size();
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
+        if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
-        if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
     } while (0);
     if (rc != XRIT_OK) { xrit_demod_destroy(d); return rc; }
     *out = d;

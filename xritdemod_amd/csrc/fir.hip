@@ -175,7 +175,29 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         const int lane = tid & 63;
         if (lane == 0 && m0 < n_out) agc.maps[m0 / (64 * RC)] = v;
     }
-    if (stat != nullptr) {
+    if (stat != nullptr && statL == 64 * RC) {
+        // one run per wave: sum in registers, DPP row sums, four row totals -- fixed order, no LDS
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            if (m0 + c < n_out) {
+                const float zr = acc[c].x, zi = acc[c].y;
+                sr += zr * zr - zi * zi;
+                si += 2.0f * zr * zi;
+            }
+        }
+        sr += agc_dpp<0x111>(0.f, sr); si += agc_dpp<0x111>(0.f, si);
+        sr += agc_dpp<0x112>(0.f, sr); si += agc_dpp<0x112>(0.f, si);
+        sr += agc_dpp<0x114>(0.f, sr); si += agc_dpp<0x114>(0.f, si);
+        sr += agc_dpp<0x118>(0.f, sr); si += agc_dpp<0x118>(0.f, si);
+        float tr = 0.f, ti = 0.f;
+#pragma unroll
+        for (int r = 15; r < 64; r += 16) {
+            tr += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), r));
+            ti += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(si), r));
+        }
+        if ((tid & 63) == 0 && m0 < n_out) stat[m0 / (64 * RC)] = make_float2(tr, ti);
+    } else if (stat != nullptr) {
         // per-thread partial sums of z^2, split where the thread's outputs cross into the next run
         __syncthreads();                      // the window tile is dead: reuse it
         float2 *pa = tile, *pb = tile + nthr;
@@ -284,6 +306,7 @@ bool FirStage::agc_supported() const
 bool FirStage::stat_supported(int statL) const
 {
     // runs must not straddle blocks, and the two partial arrays must fit in the window tile
+    if (statL == 64 * RC && !pad && threads % 64 == 0) return true;      // one run per wave
     return statL > 0 && !pad && (threads * RC) % statL == 0 && statL >= RC && (size_t)2 * threads * sizeof(float2) <= lds_bytes;
 }
 
