@@ -575,19 +575,20 @@ struct ClockPolicy {
     float trust_t, trust_w, tol_t, tol_w;
     int min_passes;
 
-    __device__ bool active(long long k) const { return nrun[k] > 0; }
-    __device__ void residual(long long k, float &r1, float &r2, int &aux) const
+    struct Elem { ClockState e, s; float4 j; int nrun; };
+    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], J[k], nrun[k]}; }
+    __device__ bool active(const Elem &el) const { return el.nrun > 0; }
+    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
     {
-        ClockState e = E[k], s = S[k + 1];
-        float rt = clock_tdiff(e, s);
-        float m = rintf(rt / e.omega);
-        r1 = rt - m * e.omega;
-        r2 = e.omega - s.omega;
+        float rt = clock_tdiff(el.e, el.s);
+        float m = rintf(rt / el.e.omega);
+        r1 = rt - m * el.e.omega;
+        r2 = el.e.omega - el.s.omega;
         aux = (int)m;
     }
-    __device__ float4 jac(long long k) const
+    __device__ float4 jac(const Elem &el) const
     {
-        float4 j = J[k];
+        float4 j = el.j;
         if (!(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 16384.f) || !(fabsf(j.z) < 1.f) || !(fabsf(j.w) < 4.f))
             j = make_float4(0.f, 0.f, 0.f, 0.f);
         return j;
@@ -596,14 +597,14 @@ struct ClockPolicy {
     {
         return !(fabsf(d1) <= trust_t) || !(fabsf(d2) <= trust_w);
     }
-    __device__ void update(long long k, float j1, float j2, float n1, float n2, int slip, int slip_k, float r1,
-                           NewtonStat &st) const
+    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int slip, int slip_k,
+                           float r1, NewtonStat &st) const
     {
-        ClockState ek = E[k], old = S[k + 1];
+        const ClockState ek = el.e, old = el.s;
         const bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
                                ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
                                ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
-        if (!active(k)) {
+        if (!active(el)) {
             // chain k produced nothing: its successor starts where it stands
             const bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
             if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; st.changed += 1; }

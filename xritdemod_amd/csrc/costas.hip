@@ -282,30 +282,31 @@ struct CostasPolicy {
     float trust_p, trust_f, tol_p, tol_f;
     float accept, gate;      // stop test: accept when max residual <= accept; trust gate needed while > gate
 
-    __device__ bool active(long long) const { return true; }
-    __device__ void residual(long long k, float &r1, float &r2, int &aux) const
+    struct Elem { float2 e, s; float4 j; };
+    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], J[k]}; }
+    __device__ bool active(const Elem &) const { return true; }
+    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
     {
-        float2 e = E[k], s = S[k + 1];
-        float rp = e.x - s.x;
+        float rp = el.e.x - el.s.x;
         float m = rintf(rp * (float)(1.0 / XR_PI_D));
         r1 = rp - m * (float)XR_PI_D;
-        r2 = e.y - s.y;
+        r2 = el.e.y - el.s.y;
         aux = ((int)m) & 1;
     }
-    __device__ float4 jac(long long k) const { return J[k]; }
+    __device__ float4 jac(const Elem &el) const { return el.j; }
     __device__ bool outside_trust(float d1, float d2) const
     {
         return !(fabsf(d1) <= trust_p) || !(fabsf(d2) <= trust_f);
     }
-    __device__ void update(long long k, float j1, float j2, float n1, float n2, int aux_prefix, int aux_k,
-                           float r1, NewtonStat &st) const
+    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int aux_prefix,
+                           int aux_k, float r1, NewtonStat &st) const
     {
         const int par = aux_prefix & 1;
         const bool frozen = fabsf(n1) <= tol_p && fabsf(n2) <= tol_f && par == 0 && (aux_k & 1) == 0;
         if (frozen) return;
-        float2 ek = E[k];
+        const float2 ek = el.e;
         float2 nw = make_float2(ek.x + (par ? (float)XR_PI_D : 0.f) + j1, ek.y + j2);
-        float2 old = S[k + 1];
+        const float2 old = el.s;
         st.open_ += 1;
         st.max_r = fmaxf(st.max_r, fabsf(r1));
         st.sum_sq += newton_fix(r1 * r1);
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256) costas_verify_kernel(CostasPolicy p, long
     if (k < n) {
         float r1, r2;
         int aux;
-        p.residual(k, r1, r2, aux);
+        p.residual(p.fetch(k), r1, r2, aux);
         bad = !(fabsf(r1) <= 2.0f * p.accept) || (aux & 1);
     }
     const unsigned long long m = __ballot(bad);

@@ -16,11 +16,15 @@
 // block aggregates, so there is no separate aggregate-scan launch.
 //
 // Policy P (device-callable members):
-//   bool   P::active(k)                   chain k produced something (else: pass state through)
-//   void   P::residual(k, float& r1, float& r2, int& aux)
-//   float4 P::jac(k)                      (a11, a12, a21, a22)
+//   P::Elem P::fetch(k)                   everything boundary k needs from memory, loaded unconditionally: the
+//                                         kernels fetch all their boundaries first, so the loads of a thread
+//                                         are in flight together (these kernels are a chain of memory
+//                                         latencies, not bandwidth)
+//   bool   P::active(el)                  chain k produced something (else: pass state through)
+//   void   P::residual(el, float& r1, float& r2, int& aux)
+//   float4 P::jac(el)                     (a11, a12, a21, a22)
 //   bool   P::outside_trust(d1, d2)
-//   void   P::update(k, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
+//   void   P::update(k, el, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
 //   unsigned* P::cnt                      this pass's counter slot
 //   void   P::decide(int* ctl)            stop test from the pass's counters; run by one thread of the block
 //                                         of kernel C that finishes last
@@ -103,23 +107,31 @@ __device__ __forceinline__ AffMap aff_lookback(const AffMap *aggs, AffMap *buf)
 }
 
 template <typename P>
-__device__ __forceinline__ AffMap newton_element(const P &p, long long k, bool cut)
+__device__ __forceinline__ AffMap newton_element(const P &p, const typename P::Elem &el, bool cut)
 {
     AffMap m = aff_identity();
-    if (!p.active(k)) {
+    if (!p.active(el)) {
         m.a11 = m.a22 = 0.f;    // nothing to hand over beyond the end of the data
         return m;
     }
     float r1, r2;
     int aux;
-    p.residual(k, r1, r2, aux);
+    p.residual(el, r1, r2, aux);
     if (cut) { m.a11 = m.a12 = m.a21 = m.a22 = 0.f; }
     else {
-        float4 j = p.jac(k);
+        float4 j = p.jac(el);
         m.a11 = j.x; m.a12 = j.y; m.a21 = j.z; m.a22 = j.w;
     }
     m.b1 = r1; m.b2 = r2; m.aux = aux;
     return m;
+}
+
+// the thread's NEWTON_IPT boundaries, all loads issued before anything is used (indices clamped, not predicated)
+template <typename P>
+__device__ __forceinline__ void newton_fetch(const P &p, long long i0, long long n, typename P::Elem (&el)[NEWTON_IPT])
+{
+#pragma unroll
+    for (int q = 0; q < NEWTON_IPT; ++q) el[q] = p.fetch(i0 + q < n ? i0 + q : n - 1);
 }
 
 template <typename P>
@@ -128,9 +140,12 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_reduce_kernel(P p, long l
     if (ctl[0]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
+    typename P::Elem el[NEWTON_IPT];
+    newton_fetch(p, i0, n, el);
     AffMap v = aff_identity();
+#pragma unroll
     for (int q = 0; q < NEWTON_IPT; ++q)
-        if (i0 + q < n) v = aff_combine(v, newton_element(p, i0 + q, false));
+        if (i0 + q < n) v = aff_combine(v, newton_element(p, el[q], false));
     v = aff_block_scan(v, buf);
     if (threadIdx.x == NEWTON_BLOCK - 1) agg0[blockIdx.x] = v;
 }
@@ -142,11 +157,14 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long lon
     if (ctl[0] || !ctl[5]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
+    typename P::Elem el[NEWTON_IPT];
+    newton_fetch(p, i0, n, el);
     AffMap pre = aff_lookback(agg0, buf);
     AffMap e[NEWTON_IPT];
     AffMap v = aff_identity();
+#pragma unroll
     for (int q = 0; q < NEWTON_IPT; ++q) {
-        e[q] = (i0 + q < n) ? newton_element(p, i0 + q, false) : aff_identity();
+        e[q] = (i0 + q < n) ? newton_element(p, el[q], false) : aff_identity();
         v = aff_combine(v, e[q]);
     }
     aff_block_scan(v, buf);
@@ -177,20 +195,18 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
     __shared__ AffMap buf[NEWTON_BLOCK];
     const long long i0 = (long long)blockIdx.x * NEWTON_TILE + (long long)threadIdx.x * NEWTON_IPT;
     const bool gated = ctl[5] != 0;
+    typename P::Elem el[NEWTON_IPT];
+    newton_fetch(p, i0, n, el);
+    float2 dl[NEWTON_IPT];
+#pragma unroll
+    for (int q = 0; q < NEWTON_IPT; ++q) dl[q] = gated ? dlin[i0 + q < n ? i0 + q : n - 1] : make_float2(0.f, 0.f);
     AffMap pre = aff_lookback(gated ? agg1 : agg0, buf);
     AffMap e[NEWTON_IPT];
     AffMap v = aff_identity();
+#pragma unroll
     for (int q = 0; q < NEWTON_IPT; ++q) {
-        if (i0 + q < n) {
-            bool cut = false;
-            if (gated) {
-                float2 dl = dlin[i0 + q];
-                cut = p.outside_trust(dl.x, dl.y);
-            }
-            e[q] = newton_element(p, i0 + q, cut);
-        } else {
-            e[q] = aff_identity();
-        }
+        if (i0 + q < n) e[q] = newton_element(p, el[q], gated && p.outside_trust(dl[q].x, dl[q].y));
+        else e[q] = aff_identity();
         v = aff_combine(v, e[q]);
     }
     aff_block_scan(v, buf);
@@ -198,13 +214,14 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
     float d1 = pre.b1, d2 = pre.b2;
     int aux = pre.aux;
     NewtonStat st{0u, 0u, 0u, 0.f, 0ull};
+#pragma unroll
     for (int q = 0; q < NEWTON_IPT; ++q) {
         const long long k = i0 + q;
         if (k >= n) break;
         float j1 = e[q].a11 * d1 + e[q].a12 * d2;
         float j2 = e[q].a21 * d1 + e[q].a22 * d2;
         float n1 = e[q].b1 + j1, n2 = e[q].b2 + j2;
-        p.update(k, j1, j2, n1, n2, aux, e[q].aux, e[q].b1, st);
+        p.update(k, el[q], j1, j2, n1, n2, aux, e[q].aux, e[q].b1, st);
         d1 = n1; d2 = n2;
         aux += e[q].aux;
     }
