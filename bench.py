@@ -149,7 +149,7 @@ def main():
     c8 = 8.0 / D
     own_bytes = {
         "fir_decim": 8.0 + c8,            # read the input once, write the decimated stream
-        "agc_reduce": c8, "agc_apply": 2 * c8, "fir_rrc": 2 * c8,
+        "agc_apply": 2 * c8, "fir_rrc": 2 * c8,      # the AGC reduce sweep lives in fir_decim's epilogue
         "costas_pass": c8, "costas_final": 2 * c8,      # the guesses read per-chain statistics only (fused upstream)
         "clock_pass_jac": c8, "clock_pass": c8, "clock_output": c8 + 4.0 / (D * sps),
     }
