@@ -84,3 +84,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in text and "xrit_oracle" not in text and "oracle/" not in text, f
+
+
+HOST_BIN = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+
+
+def test_host_program_builds_and_has_no_cpu_path(xa, tmp_path):
+    """The file-source / TCP-sink host loop is plain C++ on the C ABI; without a HIP
+    device it must fail loudly instead of demodulating on the CPU."""
+    assert os.path.exists(HOST_BIN), "make -C xritdemod_amd/csrc builds it"
+    r = subprocess.run([HOST_BIN], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr
+    if xa.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    f = tmp_path / "x.cf32"
+    np.zeros(2048, np.complex64).tofile(f)
+    r = subprocess.run([HOST_BIN, "--input", str(f), "--sink", "null"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU path" in r.stderr
+    src = open(os.path.join(ROOT, "xritdemod_amd", "host", "xrit_demod_host.cpp")).read()
+    assert "hip/hip_runtime" not in src          # the boundary is the C ABI only

@@ -23,6 +23,7 @@ from xritdemod_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "oracle_stages.npz")
 
 
@@ -354,3 +355,48 @@ def test_full_size_burst_properties(xa):
     assert np.array_equal(hard[skip:] * sign, seg[:len(hard) - skip])      # BER = 0 over 25 M symbols
     st = dem.stats()
     assert st.costas_unconverged == 0
+
+
+def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_path):
+    """xrit_demod_host = the reference's plumbing around the library (CFileFrontend -> processSamples ->
+    SymbolManager): a cf32 capture file goes through the chain block by block and arrives at a listening
+    'decoder' socket as int8 soft symbols (x127, clamp, truncation; pieces of <= 16384 bytes)."""
+    import socket
+    import subprocess
+    import threading
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    assert os.path.exists(host_bin)
+    n, block = 1500000, 400000
+    x = synth_signal(n)
+    f = tmp_path / "capture.cf32"
+    x.tofile(f)
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+    got = bytearray()
+
+    def serve():
+        conn, _ = srv.accept()
+        while True:
+            b = conn.recv(65536)
+            if not b:
+                break
+            got.extend(b)
+        conn.close()
+
+    th = threading.Thread(target=serve)
+    th.start()
+    r = subprocess.run([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
+                        "--sink", f"tcp://127.0.0.1:{port}", "--stats"], capture_output=True, text=True, timeout=120)
+    th.join(timeout=30)
+    srv.close()
+    assert r.returncode == 0, r.stderr
+    od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
+    want = np.concatenate([od.process(x[i:i + block]) for i in range(0, n, block)])
+    wq = oracle_mod.quantize_i8(want)
+    gq = np.frombuffer(bytes(got), np.int8)
+    assert len(gq) == len(wq)
+    d = np.abs(gq.astype(np.int16) - wq.astype(np.int16))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.99          # soft symbols agree to ~2e-4: a truncation edge now and then
+    assert np.array_equal(np.sign(gq[np.abs(wq) > 2]), np.sign(wq[np.abs(wq) > 2]))

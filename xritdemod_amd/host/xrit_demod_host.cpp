@@ -1,0 +1,242 @@
+// xrit_demod_host -- the reference demodulator's plumbing around libxritdemod_amd:
+// IQ file source -> demodulation chain on the GPU -> int8 soft symbols -> TCP client
+// socket towards a decoder (or a file).  It is the host loop SURVEY.md section 8(b)/(f)
+// asks for, so that the unmodified xritDecoder listening on :5000 can attach.
+//
+// What it mirrors of /root/reference/demodulator/src:
+//   * CFileFrontend.cpp:35-60   blocks of complex samples read from a raw IQ file; with
+//                               --paced the blocks are released at the capture's sample
+//                               rate like the reference does (default: as fast as possible)
+//   * demodulator.cpp:100-168   processSamples(): one chain call per block, state carried
+//   * SymbolManager.cpp:37-52   soft symbol -> int8 (x127, clamp, C-cast truncation), sent
+//                               in pieces of at most 16384 bytes (SM_SOCKET_BUFFER_SIZE)
+//   * SymbolManager.cpp:23-35   the demodulator is the TCP *client*; it retries the
+//                               connection once per second until the decoder listens
+// Only the C ABI of include/xritdemod_amd.h is used (no HIP headers): this file builds
+// with plain g++.
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/xritdemod_amd.h"
+
+namespace {
+
+struct Options {
+    std::string mode = "lrit";
+    std::string input;
+    std::string format = "cf32";
+    std::string sink = "tcp://127.0.0.1:5000";
+    double sample_rate = 2.5e6;
+    unsigned decimation = 1;
+    size_t block = 1u << 22;       // complex samples per chain call (>= 4 Mi when throughput matters)
+    int device = 0;
+    int connect_tries = 30;
+    bool paced = false;
+    bool stats = false;
+};
+
+void usage()
+{
+    std::fprintf(stderr,
+                 "usage: xrit_demod_host --input FILE [--format cf32|s16|s8] [--mode lrit|hrit]\n"
+                 "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
+                 "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n");
+}
+
+bool parse(int argc, char **argv, Options &o)
+{
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); return nullptr; }
+            return argv[++i];
+        };
+        const char *v = nullptr;
+        if (a == "--input") { if (!(v = need("--input"))) return false; o.input = v; }
+        else if (a == "--format") { if (!(v = need("--format"))) return false; o.format = v; }
+        else if (a == "--mode") { if (!(v = need("--mode"))) return false; o.mode = v; }
+        else if (a == "--sink") { if (!(v = need("--sink"))) return false; o.sink = v; }
+        else if (a == "--sample-rate") { if (!(v = need("--sample-rate"))) return false; o.sample_rate = std::atof(v); }
+        else if (a == "--decimation") { if (!(v = need("--decimation"))) return false; o.decimation = (unsigned)std::atoi(v); }
+        else if (a == "--block") { if (!(v = need("--block"))) return false; o.block = (size_t)std::atoll(v); }
+        else if (a == "--device") { if (!(v = need("--device"))) return false; o.device = std::atoi(v); }
+        else if (a == "--connect-tries") { if (!(v = need("--connect-tries"))) return false; o.connect_tries = std::atoi(v); }
+        else if (a == "--paced") o.paced = true;
+        else if (a == "--stats") o.stats = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
+    }
+    return !o.input.empty() && o.block > 0 && o.decimation >= 1;
+}
+
+// ---- sink ------------------------------------------------------------------------------------------------
+struct Sink {
+    enum Kind { NONE, TCP, FILE_ } kind = NONE;
+    int fd = -1;
+    FILE *f = nullptr;
+    std::string host;
+    int port = 0;
+    int tries = 30;
+    size_t sent = 0;
+
+    bool open(const std::string &spec, int connect_tries)
+    {
+        tries = connect_tries;
+        if (spec == "null") { kind = NONE; return true; }
+        if (spec.rfind("file:", 0) == 0) {
+            kind = FILE_;
+            f = std::fopen(spec.c_str() + 5, "wb");
+            if (!f) { std::perror("sink file"); return false; }
+            return true;
+        }
+        if (spec.rfind("tcp://", 0) == 0) {
+            kind = TCP;
+            std::string hp = spec.substr(6);
+            size_t c = hp.rfind(':');
+            if (c == std::string::npos) { std::fprintf(stderr, "sink: tcp://HOST:PORT expected\n"); return false; }
+            host = hp.substr(0, c);
+            port = std::atoi(hp.c_str() + c + 1);
+            return connect_retry();
+        }
+        std::fprintf(stderr, "sink: unknown spec %s\n", spec.c_str());
+        return false;
+    }
+    bool connect_once()
+    {
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_INET;
+        hints.ai_socktype = SOCK_STREAM;
+        if (getaddrinfo(host.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res) return false;
+        fd = ::socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+        bool ok = fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0;
+        freeaddrinfo(res);
+        if (!ok) {
+            if (fd >= 0) ::close(fd);
+            fd = -1;
+            return false;
+        }
+        int one = 1;
+        (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        return true;
+    }
+    // SymbolManager.cpp:23-35: try, sleep one second, try again
+    bool connect_retry()
+    {
+        for (int t = 0; t < tries; ++t) {
+            std::fprintf(stderr, "Trying to connect to decoder at %s:%d\n", host.c_str(), port);
+            if (connect_once()) return true;
+            std::this_thread::sleep_for(std::chrono::seconds(1));
+        }
+        std::fprintf(stderr, "sink: no decoder at %s:%d\n", host.c_str(), port);
+        return false;
+    }
+    bool send_all(const int8_t *p, size_t n)
+    {
+        sent += n;
+        if (kind == NONE) return true;
+        if (kind == FILE_) return std::fwrite(p, 1, n, f) == n;
+        // pieces of at most SM_SOCKET_BUFFER_SIZE bytes, like SymbolManager::process
+        while (n > 0) {
+            size_t piece = n > 16384 ? 16384 : n;
+            ssize_t w = ::send(fd, p, piece, MSG_NOSIGNAL);
+            if (w <= 0) {
+                std::fprintf(stderr, "Disconnected from decoder.\n");
+                ::close(fd);
+                fd = -1;
+                if (!connect_retry()) return false;
+                continue;
+            }
+            p += w;
+            n -= (size_t)w;
+        }
+        return true;
+    }
+    void close_all()
+    {
+        if (fd >= 0) ::close(fd);
+        if (f) std::fclose(f);
+        fd = -1;
+        f = nullptr;
+    }
+};
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    if (!parse(argc, argv, o)) { usage(); return 2; }
+    int type;
+    size_t bytes_per_sample;
+    if (o.format == "cf32") { type = XRIT_SAMPLE_FLOATIQ; bytes_per_sample = 8; }
+    else if (o.format == "s16") { type = XRIT_SAMPLE_S16IQ; bytes_per_sample = 4; }
+    else if (o.format == "s8") { type = XRIT_SAMPLE_S8IQ; bytes_per_sample = 2; }
+    else { usage(); return 2; }
+
+    xrit_demod_config cfg;
+    if (o.mode == "hrit") xrit_demod_config_hrit(&cfg, (float)o.sample_rate, o.decimation);
+    else xrit_demod_config_lrit(&cfg, (float)o.sample_rate, o.decimation);
+    int rc = XRIT_OK;
+    cfg.device = o.device;
+    xrit_demod *chain = nullptr;
+    if (xrit_demod_create(&cfg, &chain) != XRIT_OK) {
+        // e.g. no HIP device: there is no CPU path
+        std::fprintf(stderr, "xritdemod_amd: %s\n", xrit_last_error());
+        return 1;
+    }
+
+    FILE *in = std::fopen(o.input.c_str(), "rb");
+    if (!in) { std::perror("input"); xrit_demod_destroy(chain); return 1; }
+    Sink sink;
+    if (!sink.open(o.sink, o.connect_tries)) { std::fclose(in); xrit_demod_destroy(chain); return 1; }
+
+    std::vector<unsigned char> raw(o.block * bytes_per_sample);
+    const size_t cap = o.block + 64;
+    std::vector<float> soft(cap);
+    std::vector<int8_t> q(cap);
+    size_t total_in = 0, total_sym = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto t_release = t_start;
+    int exit_code = 0;
+    for (;;) {
+        size_t n = std::fread(raw.data(), bytes_per_sample, o.block, in);
+        if (n == 0) { std::fprintf(stderr, "EOF\n"); break; }
+        if (o.paced) {
+            // CFileFrontend.cpp:36-47: one block per block period
+            std::this_thread::sleep_until(t_release);
+            t_release += std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                std::chrono::duration<double>((double)n / o.sample_rate));
+        }
+        size_t nsym = 0;
+        rc = xrit_demod_process(chain, raw.data(), n, type, soft.data(), cap, &nsym);
+        if (rc != XRIT_OK) { std::fprintf(stderr, "process: %s\n", xrit_last_error()); exit_code = 1; break; }
+        rc = xrit_quantize_i8(chain, soft.data(), q.data(), nsym);
+        if (rc != XRIT_OK) { std::fprintf(stderr, "quantize: %s\n", xrit_last_error()); exit_code = 1; break; }
+        if (!sink.send_all(q.data(), nsym)) { exit_code = 1; break; }
+        total_in += n;
+        total_sym += nsym;
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (o.stats) {
+        xrit_demod_stats st;
+        if (xrit_demod_get_stats(chain, &st) == XRIT_OK)
+            std::fprintf(stderr, "samples in %zu, symbols out %zu, %.3f s (%.2f Msamples/s incl. file and PCIe)\n",
+                         total_in, total_sym, secs, secs > 0 ? total_in / secs * 1e-6 : 0.0);
+    }
+    sink.close_all();
+    std::fclose(in);
+    xrit_demod_destroy(chain);
+    return exit_code;
+}
