@@ -32,6 +32,67 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in):
+    """One stream per step, cut in `world` slices of n_burst samples: every rank cold-starts over a halo received
+    from its predecessor (dist.send / dist.recv of device tensors = RCCL over xGMI), polarity and the boundary
+    symbol are settled from 256 exchanged symbols, one all-gather gives the output offsets."""
+    from xritdemod_amd import dist as xd
+    K, W = args.steps, args.warmup
+    sp = _capi.synth_params(fs_in=fs_in)
+    stream = torch.cuda.current_stream(dev)
+    cfg = lambda: xa.Demodulator.config("lrit", fs_in, D, device=local_rank)
+    probe = xa.Demodulator(cfg())
+    halo = xd.halo_samples(D, probe.sps, probe.decimator_ntaps)
+    halo = min(halo - halo % D, n_burst)
+    body = torch.empty((n_burst, 2), dtype=torch.float32, device=dev)
+    # a fresh chain per step would re-allocate its buffers: keep two handles and re-create them outside the timing
+    nsym = 0
+
+    def one(step):
+        nonlocal nsym
+        start = (step * world + rank) * n_burst
+        _capi.synth_generate_device(sp, start, n_burst, body.data_ptr(), device=local_rank, stream=stream.cuda_stream)
+        out, _ = xd.demodulate_contiguous_device(lambda: xa.Demodulator(cfg()), body, dist, rank, world, halo,
+                                                 stream=stream.cuda_stream)
+        nsym += int(out.shape[0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for s in range(W):
+        one(s)
+    nsym = 0
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        one(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(nsym)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, nsym_all = float(tmax[0].item()), float(t[1].item())
+    else:
+        nsym_all = float(nsym)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Msamples/s in -> soft-symbols/s out (LRIT 293 ksym/s chain); % HBM roofline",
+            "value": round(n_burst * world * K / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "symbols_per_s": round(nsym_all / elapsed, 1),
+            "config": {"workload": "C4 contiguous: one LRIT stream cut in n_gpus slices, edge-sample exchange over RCCL; "
+                                   "timed region includes the synthetic generator, chain construction and the halo",
+                       "samples_per_step_per_gpu": n_burst, "decimation": D, "halo_samples": halo,
+                       "halo_bytes_per_boundary": halo * 8, "parallelism": f"time-slice x{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +106,9 @@ def main():
     ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
     ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
     ap.add_argument("--slices", type=int, default=0, help="time slices per call (0 = library default, 1 = off)")
+    ap.add_argument("--contiguous", action="store_true",
+                    help="N ranks demodulate ONE stream cut in N slices, with RCCL edge-sample exchange "
+                         "(SURVEY.md 8(e); the default is N independent segments, no data-path collective)")
     args = ap.parse_args()
 
     import torch
@@ -69,6 +133,8 @@ def main():
     D = args.decimation
     fs_in = 1.25e6 * D
     K, W = args.steps, args.warmup
+    if args.contiguous:
+        return bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in)
     detail = not args.no_profile        # a second, untimed set of K steps with every kernel bracketed
     nb = K + W + (K if detail else 0)
 

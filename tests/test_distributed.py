@@ -52,3 +52,59 @@ def test_segment_seeds_do_not_collide():
     for s in seeds:
         assert s not in used and s + 1 not in used
         used.update((s, s + 1))
+
+
+# ---- contiguous stream split with edge-sample exchange ------------------------------------------
+def _split_worker(rank, world, port, q, same_lock):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle                       # the CPU tier plays the chain with the oracle; on GPUs it is the HIP chain
+    from xritdemod_amd import dist as xd, synth
+    d = xd.init("gloo")
+    n = 900000
+    # every rank holds only its own slice of ONE stream (the generator is counter based: any slice on its own)
+    body = synth.generate(synth.SynthParams(), n, start=rank * n)
+    halo_len = xd.halo_samples(1, 4.2534, 0, warm_symbols=24576)      # with this halo rank 1 locks pi away
+    make = lambda: oracle.Demod(oracle.config("lrit", 1.25e6, 1)).process
+    soft, offset = xd.demodulate_contiguous(make, body, d, rank, world, min(halo_len, n), same_lock=same_lock)
+    q.put((rank, offset, soft))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def _run_split(same_lock):
+    import oracle
+    from xritdemod_amd import synth
+    world, n = 2, 900000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90) + (7 if same_lock else 0)
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q, same_lock)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = oracle.Demod(oracle.config("lrit", 1.25e6, 1)).process(synth.generate(synth.SynthParams(), world * n))
+    got = np.concatenate([r[2] for r in res])
+    assert res[0][1] == 0 and res[1][1] == len(res[0][2])          # offsets = prefix sums of the counts
+    assert len(got) == len(ref)                                     # no symbol lost or doubled at the boundary
+    return got, ref, len(res[0][2])
+
+
+def test_contiguous_split_two_ranks_polarity_and_boundary():
+    got, ref, n0 = _run_split(same_lock=False)
+    assert np.array_equal(got[:n0], ref[:n0])                       # rank 0 is the uninterrupted stream
+    assert np.array_equal(np.sign(got), np.sign(ref))               # hard decisions: every symbol, right polarity
+    e = float(np.sqrt(np.mean((got[n0:] - ref[n0:]) ** 2)))
+    assert 3e-4 < e < 3e-3                                          # the other lock of the M&M loop: ~1e-3
+
+
+def test_contiguous_split_two_ranks_same_lock():
+    got, ref, n0 = _run_split(same_lock=True)
+    assert np.array_equal(got[:n0], ref[:n0])
+    assert np.array_equal(np.sign(got), np.sign(ref))
+    # rank 1 ran again on the other lock: it now follows the uninterrupted trajectory to the chaos level
+    assert float(np.sqrt(np.mean((got[n0:] - ref[n0:]) ** 2))) < 3e-4
