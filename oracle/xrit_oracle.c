@@ -390,7 +390,9 @@ int xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, flo
     long ii = 0;
     int oo = 0;
     float mu = m->mu, omega = m->omega;
-    while (ii < ni) {
+    /* a symbol consumes at least one sample in any sane configuration: the bound only stops a NaN state (an AGC
+     * driven outside its stable range upstream) from emitting symbols for ever into the caller's n + 64 buffer */
+    while (ii < ni && oo < n + XO_MM_FUDGE) {
         m->p_2t = m->p_1t;
         m->p_1t = m->p_0t;
         /* mmse_fir_interpolator_cc::interpolate */

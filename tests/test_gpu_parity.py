@@ -483,3 +483,30 @@ def test_contiguous_split_on_device(xa, same_lock):
     e1 = rms(got[len(s0):] - ref[len(s0):])
     assert rms(got[:len(s0)] - ref[:len(s0)]) < 4e-4            # rank 0: same chain, other chunking
     assert e1 < (6e-4 if same_lock else 3e-3)
+
+
+def test_agc_inside_the_matched_filter_fill_is_the_same_chain(xa, oracle_mod):
+    """With a decimator in front and nobody reading the AGC stage, the AGC never sweeps the stream itself: its
+    composed run maps come out of the decimator's epilogue and the matched filter applies the gains while it
+    fills its window.  Same arithmetic as the stand-alone AGC kernels -> the same symbols, bit for bit, also
+    across calls (history and gain are carried by the fused path's own tail kernel)."""
+    x = synth_signal(2500000, fs_in=6.25e6)
+    cuts = [0, 700001, 700001 + 5 * 123, 1900000, 2500000]
+    a = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    b = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    b.keep_stages(True)                       # forces the stand-alone AGC kernels
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ga, gb = a.process(x[lo:hi]), b.process(x[lo:hi])
+        assert np.array_equal(ga, gb)
+    # guard: samples with rate*|x| > 1 leave the monotone-map regime; the fused path must take the serial fallback
+    # (flag raised by the decimator's epilogue; the matched filter then reads the serially produced AGC output).
+    # The reference recurrence itself runs away once its gain has been driven negative, so the spike sits in the
+    # last samples of the call, where it cannot: what is checked is the plumbing of the fallback.
+    y = x[:900000].copy()
+    y[-60:] *= 1e5
+    ref = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, 5))
+    want = ref.process(y)
+    c = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    got = c.process(y)
+    assert c.stats().agc_serial_fallback == 1
+    check_symbols(got, want)

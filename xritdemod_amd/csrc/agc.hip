@@ -235,6 +235,32 @@ int AgcStage::fused_finish(const float2 *in, float2 *out, size_t n, int per_lane
     return XRIT_OK;
 }
 
+int AgcStage::fused_scan(const float2 *in, float2 *fallback, size_t n, int per_lane, hipStream_t s, Profiler *prof,
+                         AgcFill *fill)
+{
+    float *sin_ = state.as<float>() + 2 * cur;
+    float *sout = state.as<float>() + 2 * (cur ^ 1);
+    const size_t rl = (size_t)64 * per_lane;
+    const int nr = (int)((n + rl - 1) / rl);
+    {
+        ProfScope ps(prof, "agc_scan", s);
+        if (nr > 0) scan_aggs_launch(AgcRunF{}, aggs.as<AgcMap>(), nr, s);
+        hipLaunchKernelGGL(agc_serial_kernel, dim3(1), dim3(1), 0, s, in, fallback, sin_, sout, rate, ref, maxg,
+                           (long long)n, 0);
+    }
+    XR_HIP(hipGetLastError());
+    fill->x = in;
+    fill->pre_run = aggs.as<AgcMap>();
+    fill->state_in = sin_;
+    fill->state_out = sout;
+    fill->rate = rate;
+    fill->ref = ref;
+    fill->maxg = maxg;
+    fill->per_lane = per_lane;
+    cur ^= 1;
+    return XRIT_OK;
+}
+
 int AgcStage::gain(float *g, hipStream_t s)
 {
     XR_HIP(hipMemcpyAsync(g, state.as<float>() + 2 * cur, sizeof(float), hipMemcpyDeviceToHost, s));

@@ -51,7 +51,7 @@ struct xrit_demod {
     AgcStage agc;
     CostasStage costas;
     ClockStage clock;
-    DevBuf bufA[2], bufB[2], stat[2], in_dev, soft_dev, q_in, q_out;   // two sets: one per time slice in flight
+    DevBuf bufA[2], bufB[2], bufC[2], stat[2], in_dev, soft_dev, q_in, q_out;   // two sets: one per time slice in flight
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_in = nullptr, ev_fe[2] = {nullptr, nullptr}, ev_lp[2] = {nullptr, nullptr};
     bool keep_stages = false;
@@ -195,7 +195,7 @@ void xrit_demod_destroy(xrit_demod *d)
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->stat[i].release(); }
+    for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->bufC[i].release(); d->stat[i].release(); }
     d->in_dev.release(); d->soft_dev.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
     if (d->ev_in) (void)hipEventDestroy(d->ev_in);
@@ -255,7 +255,17 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
         cur = reinterpret_cast<const float2 *>(in);
     }
     XR_TRY(keep_stage(d, 0, cur, length, s));
-    if (agc_fused) XR_TRY(d->agc.fused_finish(cur, B, length, d->dec.RC, s, prof));   // :143
+    // ... and when nobody asks for the AGC output itself, the matched filter applies the gains while it fills its
+    // window: the AGC then costs the stream no sweep of its own at all
+    const bool agc_in_rrc = agc_fused && !d->keep_stages && d->rrc.agc_fill_supported(d->dec.RC);
+    AgcFill fill{};
+    float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
+    if (agc_in_rrc) {
+        XR_TRY(d->bufC[set].reserve((length + 8) * sizeof(float2)));
+        Cfb = d->bufC[set].as<float2>();
+        XR_TRY(d->agc.fused_scan(cur, Cfb, length, d->dec.RC, s, prof, &fill));                     // :143
+    }
+    else if (agc_fused) XR_TRY(d->agc.fused_finish(cur, B, length, d->dec.RC, s, prof));
     else XR_TRY(d->agc.run(cur, B, length, s, prof));
     XR_TRY(keep_stage(d, 1, B, length, s));
     // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
@@ -264,9 +274,12 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     const size_t K = (length + (size_t)L - 1) / (size_t)L;
     XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
     io->stat_ready = length > 0 && d->rrc.stat_supported(L);
-    XR_TRY(d->rrc.run(B, XRIT_SAMPLE_FLOATIQ, A, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L)); // :148
-    XR_TRY(keep_stage(d, 2, A, length, s));
-    io->rrc = A;
+    // (fused: A holds the decimator output, which the fill reads; the filter output goes to B's place instead)
+    float2 *rrc_out = agc_in_rrc ? B : A;
+    XR_TRY(d->rrc.run(agc_in_rrc ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
+                      nullptr, agc_in_rrc ? &fill : nullptr)); // :148
+    XR_TRY(keep_stage(d, 2, rrc_out, length, s));
+    io->rrc = rrc_out;
     return XRIT_OK;
 }
 

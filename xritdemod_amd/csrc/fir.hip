@@ -42,11 +42,70 @@ template <> struct SampleLoad<XRIT_SAMPLE_S8IQ> {
 // statistic the Costas guess needs -- so that no separate sweep over the filtered stream is required.
 // statL divides the outputs of a block, every run belongs to one block, and the partial sums are combined
 // in a fixed order (deterministic).
-template <int RC, bool PAD, int TYPE>
+// AGC applied inside the window fill (APL > 0: the AGC's runs are 64 * APL samples).  The runs that overlap
+// the block's window are dealt to the waves; a wave does for its run what agc_apply_runs_kernel does -- APL
+// samples per lane, the gain at the lane's first sample from the run's prefix map and a DPP scan over the
+// lanes, the recurrence replayed literally -- and drops the result into the LDS tile.
+template <int APL>
+__device__ __forceinline__ void fir_fill_through_agc(float2 *tile, const AgcFill &af, const float2 *__restrict__ hist,
+                                                     int T, long long tile_start, int tile_len, long long n_in)
+{
+    constexpr int RL = 64 * APL;
+    constexpr int MAXIT = 3;              // a window of <= 7 runs + two partial ones, four waves
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+    const long long t_end = tile_start + tile_len < n_in ? tile_start + tile_len : n_in;
+    const long long first_run = (tile_start > 0 ? tile_start : 0) / RL;
+    float2 v[MAXIT][APL];
+    int cnt[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const long long rr = first_run + wave + (long long)it * nwaves;
+        const long long i0 = rr * RL + (long long)lane * APL;
+        cnt[it] = 0;
+        if (rr * RL < t_end && i0 < n_in) cnt[it] = (int)((n_in - i0) < APL ? (n_in - i0) : APL);
+#pragma unroll
+        for (int k = 0; k < APL; ++k) v[it][k] = k < cnt[it] ? af.x[i0 + k] : make_float2(0.f, 0.f);
+    }
+    const float g0 = af.state_in[0];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const long long rr = first_run + wave + (long long)it * nwaves;
+        if (rr * RL >= t_end) break;                       // wave-uniform
+        AgcMap m = agc_identity();
+#pragma unroll
+        for (int k = 0; k < APL; ++k)
+            if (k < cnt[it]) m = agc_compose(m, agc_sample_map(v[it][k].x, v[it][k].y, af.rate, af.ref, af.maxg));
+        const AgcMap ex = agc_wave_exclusive(m);
+        float gg = agc_apply(agc_compose(af.pre_run[rr], ex), g0);
+        const long long i0 = rr * RL + (long long)lane * APL;
+#pragma unroll
+        for (int k = 0; k < APL; ++k) {
+            if (k < cnt[it]) {
+                float yr, yi;
+                agc_step(v[it][k].x, v[it][k].y, gg, af.rate, af.ref, af.maxg, yr, yi);
+                const long long idx = i0 + k - tile_start;
+                if (idx >= 0 && idx < tile_len) tile[idx] = make_float2(yr, yi);
+            }
+        }
+    }
+    // in front of the stream: the carried history (already AGC output); behind its end: zeros
+    for (int idx = tid; idx < tile_len; idx += nthr) {
+        const long long j = tile_start + idx;
+        if (j < 0) {
+            const long long hj = (T - 1) + j;
+            tile[idx] = hj >= 0 ? hist[hj] : make_float2(0.f, 0.f);
+        } else if (j >= n_in) {
+            tile[idx] = make_float2(0.f, 0.f);
+        }
+    }
+}
+
+template <int RC, bool PAD, int TYPE, int APL = 0>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
-                 int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc)
+                 int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
@@ -56,7 +115,9 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     const long long out_base = (long long)blockIdx.x * OB;
     const long long tile_start = out_base * D - (T - 1);
 
-    if (tile_start >= 0 && tile_start + tile_len <= n_in) {
+    if (APL > 0 && af.state_out[1] == 0.0f) {
+        fir_fill_through_agc<(APL > 0 ? APL : 1)>(tile, af, hist, T, tile_start, tile_len, n_in);
+    } else if (tile_start >= 0 && tile_start + tile_len <= n_in) {
         // interior block: no history, no end of input -> eight loads in flight per lane before the first store
         // (the guarded loop below waits for every single load: ~16 serial memory latencies per block)
         int idx = tid;
@@ -255,6 +316,54 @@ __global__ void fir_hist_kernel(const void *__restrict__ in, const float2 *__res
     hist_new[i] = v;
 }
 
+// Fused AGC: new history = the AGC OUTPUT of the last T-1 samples (or older history in front of a short call),
+// and the AGC's gain after the call.  One block; the waves take the last runs of the stream.
+template <int APL>
+__global__ void __launch_bounds__(256) fir_agc_hist_kernel(AgcFill af, const float2 *__restrict__ fallback,
+                                                           const float2 *__restrict__ hist_old,
+                                                           float2 *__restrict__ hist_new, int T, long long n)
+{
+    constexpr int RL = 64 * APL;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long h0 = n - (T - 1);                     // first stream index of the new history (may be < 0)
+    for (int i = tid; i < T - 1; i += blockDim.x) {
+        const long long j = h0 + i;
+        if (j < 0) {
+            const long long hj = (T - 1) + j;
+            hist_new[i] = hj >= 0 ? hist_old[hj] : make_float2(0.f, 0.f);
+        } else if (af.state_out[1] != 0.0f) {
+            hist_new[i] = fallback[j];                    // guard tripped: the serial kernel wrote output and gain
+        }
+    }
+    if (af.state_out[1] != 0.0f || n <= 0) return;
+    const long long last_run = (n - 1) / RL;
+    const long long first_run = (h0 > 0 ? h0 : 0) / RL;
+    for (long long rr = first_run + wave; rr <= last_run; rr += blockDim.x >> 6) {
+        const long long i0 = rr * RL + (long long)lane * APL;
+        int cnt = 0;
+        if (i0 < n) cnt = (int)((n - i0) < APL ? (n - i0) : APL);
+        float2 v[APL];
+#pragma unroll
+        for (int k = 0; k < APL; ++k) v[k] = k < cnt ? af.x[i0 + k] : make_float2(0.f, 0.f);
+        AgcMap m = agc_identity();
+#pragma unroll
+        for (int k = 0; k < APL; ++k)
+            if (k < cnt) m = agc_compose(m, agc_sample_map(v[k].x, v[k].y, af.rate, af.ref, af.maxg));
+        const AgcMap ex = agc_wave_exclusive(m);
+        float gg = agc_apply(agc_compose(af.pre_run[rr], ex), af.state_in[0]);
+#pragma unroll
+        for (int k = 0; k < APL; ++k) {
+            if (k < cnt) {
+                float yr, yi;
+                agc_step(v[k].x, v[k].y, gg, af.rate, af.ref, af.maxg, yr, yi);
+                const long long i = i0 + k - h0;
+                if (i >= 0 && i < T - 1) hist_new[i] = make_float2(yr, yi);
+            }
+        }
+        if (cnt > 0 && i0 + cnt == n) af.state_out[0] = gg;
+    }
+}
+
 int FirStage::init(const float *taps, int ntaps, int decim)
 {
     T = ntaps;
@@ -321,12 +430,13 @@ template <int RC, bool PAD>
 static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out, size_t n_out, size_t n_in,
                         hipStream_t s, float2 *stat, int statL, const AgcEpilogue &agc)
 {
+    const AgcFill af{};
     unsigned blocks = div_up(n_out, (size_t)f.threads * RC);
     const float2 *h = f.hist[f.cur].as<float2>();
     const float *g = f.g.as<float>();
 #define XR_FIR_GO(TY)                                                                                          \
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
-                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc)
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af)
     if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
@@ -335,9 +445,47 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     return XRIT_OK;
 }
 
-int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof, float2 *stat,
-                  int statL, const AgcEpilogue *agc_in)
+bool FirStage::agc_fill_supported(int per_lane) const
 {
+    // the window must be covered by three rounds of the block's waves, one run each
+    const long long runs = (tile_len + (long long)64 * per_lane - 1) / (64 * per_lane) + 1;
+    return D == 1 && !pad && threads % 64 == 0 && per_lane == 3 && RC == 5 && runs <= 3 * (threads / 64);
+}
+
+// matched filter with the AGC applied in its window fill; `in` is the fallback stream (AgcFill)
+static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof,
+                               float2 *stat, int statL, const AgcFill &af)
+{
+    const AgcEpilogue none{nullptr, nullptr, 0.f, 0.f, 0.f};
+    const unsigned blocks = div_up(n, (size_t)f.threads * 5);
+    {
+        ProfScope ps(prof, "fir_rrc", s);
+        hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
+                           in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
+                           (long long)n, f.tile_len, stat, statL, none, af);
+    }
+    {
+        ProfScope ps(prof, "fir_hist", s);
+        hipLaunchKernelGGL(fir_agc_hist_kernel<3>, dim3(1), dim3(256), 0, s, af, in, f.hist[f.cur].as<float2>(),
+                           f.hist[f.cur ^ 1].as<float2>(), f.T, (long long)n);
+    }
+    XR_HIP(hipGetLastError());
+    f.cur ^= 1;
+    return XRIT_OK;
+}
+
+int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof, float2 *stat,
+                  int statL, const AgcEpilogue *agc_in, const AgcFill *fill)
+{
+    if (fill) {
+        if (!agc_fill_supported(fill->per_lane) || type != XRIT_SAMPLE_FLOATIQ || T < 2) {
+            set_error("FIR: this filter cannot apply the AGC in its window fill");
+            return XRIT_E_INVALID;
+        }
+        if (stat && !stat_supported(statL)) stat = nullptr;
+        if (n_out == 0) return XRIT_OK;
+        return fir_launch_agc_fill(*this, reinterpret_cast<const float2 *>(in), out, n_out, s, prof, stat, statL, *fill);
+    }
     if (stat && !stat_supported(statL)) stat = nullptr;
     AgcEpilogue agc{nullptr, nullptr, 0.f, 0.f, 0.f};
     if (agc_in) {

@@ -19,14 +19,29 @@ struct FirStage {
     // consumes n_out*D samples of `in` (sample_type as in FrontendDevice.h:11-13)
     // stat (optional): sum z^2 per run of statL outputs, written when stat_supported(statL)
     // agc (optional): the AGC's composed gain map per run of 64 * RC outputs, see AgcStage::fused_begin
+    // fill (optional, D == 1): the input is the AGC's INPUT stream; the window fill applies the AGC on the fly
+    // (AgcStage::fused_scan fills the descriptor) -- the AGC output is never written
     int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof,
-            float2 *stat = nullptr, int statL = 0, const struct AgcEpilogue *agc = nullptr);
+            float2 *stat = nullptr, int statL = 0, const struct AgcEpilogue *agc = nullptr,
+            const struct AgcFill *fill = nullptr);
+    bool agc_fill_supported(int per_lane) const;
     bool stat_supported(int statL) const;
     bool agc_supported() const;
 };
 
 // What the decimator's epilogue needs to leave the AGC's first sweep behind (AgcStage::fused_begin fills it).
 constexpr int AGC_RUN_MAX_PER_LANE = 5;
+// What the matched filter's window fill needs to apply the AGC itself: the stream in front of the AGC, the
+// exclusive prefix of the run maps, the call's start gain.  If the guard flag is up the gains are not the
+// scan's: the kernel then reads `in`, which agc_serial_kernel has filled (never seen with normalised samples).
+struct AgcFill {
+    const float2 *x;
+    const struct AgcMap *pre_run;
+    const float *state_in;      // [0] gain at the start of the call
+    float *state_out;           // [0] gain after the call (written by the history kernel), [1] guard flag
+    float rate, ref, maxg;
+    int per_lane;               // a run = 64 * per_lane samples
+};
 struct AgcEpilogue {
     struct AgcMap *maps;     // one per run of 64 * RC outputs (the outputs of one wave of the FIR kernel)
     float *state_out;        // [1] guard flag
@@ -47,6 +62,9 @@ struct AgcStage {
     // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
     int fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi);      // per_lane: the producer's RC
     int fused_finish(const float2 *in, float2 *out, size_t n, int per_lane, hipStream_t s, Profiler *prof);
+    // instead of fused_finish(): scan only; the consumer (the matched filter) applies the gains in its window fill.
+    // `fallback` receives the serial result if the guard trips.
+    int fused_scan(const float2 *in, float2 *fallback, size_t n, int per_lane, hipStream_t s, Profiler *prof, AgcFill *fill);
     int gain(float *g, hipStream_t s);
     int fallback_flag(float *flag, hipStream_t s);
 };
