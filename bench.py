@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
     ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
     ap.add_argument("--slices", type=int, default=0, help="time slices per call (0 = library default, 1 = off)")
+    ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
+                    help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
+                         "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")
     ap.add_argument("--contiguous", action="store_true",
                     help="N ranks demodulate ONE stream cut in N slices, with RCCL edge-sample exchange "
                          "(SURVEY.md 8(e); the default is N independent segments, no data-path collective)")
@@ -131,7 +134,9 @@ def main():
 
     n_burst = 1 << args.burst_log2
     D = args.decimation
-    fs_in = 1.25e6 * D
+    mode = args.mode
+    fs_in = (1.25e6 if mode == "lrit" else 2.5e6) * D
+    sym_rate, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
     K, W = args.steps, args.warmup
     if args.contiguous:
         return bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in)
@@ -139,7 +144,7 @@ def main():
     nb = K + W + (K if detail else 0)
 
     # ---- synthetic stream: nb consecutive bursts of this rank's capture segment
-    sp = _capi.synth_params(fs_in=fs_in, seed=0x58524954 + 2 * rank)
+    sp = _capi.synth_params(fs_in=fs_in, symbol_rate=sym_rate, alpha=alpha, seed=0x58524954 + 2 * rank)
     bursts = torch.empty((nb, n_burst, 2), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
     for b in range(nb):
@@ -147,7 +152,7 @@ def main():
                                     stream=stream.cuda_stream)
     torch.cuda.synchronize(dev)
 
-    cfg = xa.Demodulator.config("lrit", fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
+    cfg = xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
                                 clock_chain_syms=args.clock_chain, slices=args.slices)
     dem = xa.Demodulator(cfg)
     sps = dem.sps
@@ -237,11 +242,13 @@ def main():
         # INSIDE the timed region; `achieved` prices it with SURVEY.md 8(d)'s chain figure (8 + 4/(D*sps) bytes
         # per input sample x samples per launch).  The loop passes, which take the larger share of the step in
         # total, are listed with their own algorithmic bytes in `kernels` and `by_total_time`.
-        fd = kernels["fir_decim"]
+        # (without a decimator -- C1's chain, C3 -- the longest single launch takes that place, from the detail pass)
+        dom_name = "fir_decim" if "fir_decim" in kernels else max(kernels, key=lambda n: kernels[n]["avg_launch_ms"])
+        fd = kernels[dom_name]
         avg_ms = fd["avg_launch_ms"]
         bytes_per_launch = b_alg * n_burst
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "fir_decim", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": fd["launches"] / K,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -253,9 +260,9 @@ def main():
                                      "achieved": kernels[tot[0]].get("achieved_gbs"),
                                      "frac": kernels[tot[0]].get("hbm_frac"),
                                      "algorithmic_bytes_per_launch": kernels[tot[0]].get("algorithmic_bytes_per_launch")}
-        dom = ("fir_decim",)
+        dom = (dom_name,)
         tpath = os.path.join(HERE, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and mode == "lrit" and D == 5:      # the committed PMC passes are C2's
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(dom[0])
@@ -270,8 +277,11 @@ def main():
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: LRIT BPSK chain (decimating LPF 151 taps d=%d -> AGC -> RRC 63 a=0.5 -> Costas -> M&M), "
-                               "%d Mi-sample cf32 burst per step per GPU, consecutive bursts of one stream" % (D, n_burst >> 20),
+        "config": {"workload": "%s: %s BPSK chain (%sAGC -> RRC 63 a=%.1f -> Costas -> M&M), "
+                               "%d Mi-sample cf32 burst per step per GPU, consecutive bursts of one stream"
+                               % ({("lrit", 5): "C2", ("lrit", 32): "C5", ("lrit", 1): "C1 chain", ("hrit", 1): "C3"}.get((mode, D), "custom"),
+                                  mode.upper(), ("decimating LPF %d taps d=%d -> " % (dem.decimator_ntaps, D)) if D > 1 else "",
+                                  alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
                    "segments": world, "costas_chain_len": 256, "clock_chain_syms": 64},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
@@ -289,7 +299,7 @@ def main():
         import oracle
         n_cpu = min(n_burst, 1 << args.cpu_sample_log2)
         host = bursts[0, :n_cpu].cpu().numpy().view(np.complex64).reshape(-1)
-        od = oracle.Demod(oracle.config("lrit", fs_in, D))
+        od = oracle.Demod(oracle.config(mode, fs_in, D))
         c0 = time.perf_counter()
         so = od.process(host)
         c1 = time.perf_counter()

@@ -49,11 +49,14 @@ def check_symbols(got, want, rms_tol=5e-4):
 
 
 # ------------------------------------------------------------------- stages
-@pytest.mark.parametrize("D,kind", [(1, "rrc"), (5, "lp5"), (32, "lp32"), (2, "rrc"), (3, "lp5"), (4, "short")])
+@pytest.mark.parametrize("D,kind", [(1, "rrc"), (5, "lp5"), (32, "lp32"), (2, "rrc"), (3, "lp5"), (4, "short"),
+                                    (16, "lp16"), (64, "lp64"), (32, "short"), (16, "lp32")])   # polyphase kernel: 16/32/64, also with
+                                                                                                # too many taps for it (fallback)
 def test_fir_stage(xa, oracle_mod, D, kind):
     o = oracle_mod
     taps = {"rrc": o.rrc_taps(1, 1.25e6, 293883, 0.5, 63), "lp5": o.lowpass_taps(1, 6.25e6, 625e3, 100e3),
-            "lp32": o.lowpass_taps(1, 40e6, 625e3, 100e3), "short": np.array([0.5, -0.25, 0.125], np.float32)}[kind]
+            "lp32": o.lowpass_taps(1, 40e6, 625e3, 100e3), "short": np.array([0.5, -0.25, 0.125], np.float32),
+            "lp16": o.lowpass_taps(1, 20e6, 625e3, 100e3), "lp64": o.lowpass_taps(1, 80e6, 625e3, 100e3)}[kind]
     rng = np.random.default_rng(D)
     n_out = [30000, 1, 777, 0, 12345]
     x = (rng.standard_normal(sum(n_out) * D) + 1j * rng.standard_normal(sum(n_out) * D)).astype(np.complex64)

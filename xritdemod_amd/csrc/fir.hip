@@ -299,6 +299,124 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     }
 }
 
+// ---- polyphase decimator for large decimations (DP = 16, 32 or 64 phases; BASELINE config 5: 963 taps, d = 32)
+// y[m] = sum_k h[k] x[m*DP - k] with k = q*DP + p:  y[m] = sum_p sum_q h_p[q] x[(m - q)*DP - p].  The kernel
+// above gives a lane consecutive OUTPUTS, which for DP = 32 means windows 256 B apart (every lane on the same
+// LDS bank unless the tile is skewed) and no reuse between a lane's outputs.  Here a lane owns one PHASE p of a
+// group of PR consecutive outputs: its NQ = ceil(T/DP) taps h_p[q] sit in registers for the whole kernel, the
+// samples it needs, x[(m - q)*DP - p], are DP apart in time -- so the lanes of a group read CONSECUTIVE LDS
+// addresses (no skew, no conflicts) -- and one LDS read feeds up to PR multiply-adds (the phase's own little FIR
+// slides over the outputs).  The DP partial sums of an output are then added across the lanes with DPP row
+// rotations.  64 / DP groups per wave, PR outputs per group.
+template <int DP, int PR, int NQ, int TYPE>
+__global__ void __launch_bounds__(256)
+fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
+                const float *__restrict__ hq /* [DP][NQ] */, int T, long long n_out, long long n_in, int tile_len)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(smem_raw);
+    constexpr int GPW = 64 / DP;                      // output groups per wave
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int OB = (nthr / DP) * PR;                  // outputs per block
+    // Neighbouring tiles share (NQ-1)/(NQ-1+OB/...) of their window -- a third at d = 32.  Workgroups go to the
+    // 8 XCDs round robin and every XCD has its own L2, so tile t = blockIdx would have that third fetched from
+    // HBM twice; instead XCD x walks the contiguous tile range [x*per, (x+1)*per) and finds the overlap in its L2.
+    const unsigned per = gridDim.x >> 3;              // the grid is a multiple of 8
+    const long long tb = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const long long out_base = tb * OB;
+    if (out_base >= n_out) return;
+    // one sample more than the oldest any lane touches: an even start keeps the 16-byte loads aligned
+    const long long tile_start = out_base * DP - (long long)(NQ * DP);
+
+    if (TYPE == XRIT_SAMPLE_FLOATIQ && tile_start >= 0 && tile_start + tile_len <= n_in && (tile_start & 1) == 0 &&
+        (reinterpret_cast<size_t>(in) & 15) == 0) {
+        const float4 *in4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in) + tile_start);
+        float4 *tile4 = reinterpret_cast<float4 *>(tile);
+        const int pairs = tile_len >> 1;
+        // the whole window in one batch of loads per thread (256 threads): one memory latency per block
+        constexpr int UF = (((NQ + (256 / DP) * PR - 1) * DP + 2) / 2 + 255) / 256;
+        for (int p0 = tid; p0 < pairs; p0 += UF * nthr) {
+            float4 v[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) v[u] = in4[min(p0 + u * nthr, pairs - 1)];
+#pragma unroll
+            for (int u = 0; u < UF; ++u)
+                if (p0 + u * nthr < pairs) tile4[p0 + u * nthr] = v[u];
+        }
+        if ((tile_len & 1) && tid == 0) tile[tile_len - 1] = SampleLoad<TYPE>::at(in, (size_t)(tile_start + tile_len - 1));
+    } else {
+        for (int idx = tid; idx < tile_len; idx += nthr) {
+            const long long j = tile_start + idx;
+            float2 v = make_float2(0.f, 0.f);
+            if (j < 0) {
+                const long long hj = (T - 1) + j;
+                if (hj >= 0) v = hist[hj];
+            } else if (j < n_in) {
+                v = SampleLoad<TYPE>::at(in, (size_t)j);
+            }
+            tile[idx] = v;
+        }
+    }
+    const int lane = tid & 63;
+    const int p = lane % DP;                          // phase of this lane
+    const int grp = tid / DP;                         // output group inside the block
+    float h[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) h[q] = hq[p * NQ + q];
+    lds_barrier();
+
+    // output c of the group (m = out_base + grp*PR + c), tap q: sample index (m - q)*DP - p
+    //   = tile_start + NQ*DP + (grp*PR + c - q)*DP - p, i.e. with u = c - q in [-(NQ-1), PR-1]:
+    const float2 *w = tile + NQ * DP + grp * PR * DP - p;
+    // (re, im) pairs as 2-vectors so that a multiply-add is one v_pk_fma_f32 (tap broadcast through op_sel)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f accv[PR];
+#pragma unroll
+    for (int c = 0; c < PR; ++c) accv[c] = (v2f){0.f, 0.f};
+#pragma unroll
+    for (int u = -(NQ - 1); u < PR; ++u) {
+        const float2 xs = w[u * DP];
+        const v2f x = {xs.x, xs.y};
+#pragma unroll
+        for (int c = 0; c < PR; ++c) {
+            const int q = c - u;
+            if (q >= 0 && q < NQ) accv[c] = __builtin_elementwise_fma((v2f){h[q], h[q]}, x, accv[c]);
+        }
+    }
+    float2 acc[PR];
+#pragma unroll
+    for (int c = 0; c < PR; ++c) acc[c] = make_float2(accv[c].x, accv[c].y);
+    // add the DP phases of every output: rotations inside the rows of 16 lanes, then across rows
+#pragma unroll
+    for (int c = 0; c < PR; ++c) {
+        float sr = acc[c].x, si = acc[c].y;
+        sr += agc_dpp<0x128>(0.f, sr); si += agc_dpp<0x128>(0.f, si);      // row_ror:8
+        sr += agc_dpp<0x124>(0.f, sr); si += agc_dpp<0x124>(0.f, si);      // row_ror:4
+        sr += agc_dpp<0x122>(0.f, sr); si += agc_dpp<0x122>(0.f, si);      // row_ror:2
+        sr += agc_dpp<0x121>(0.f, sr); si += agc_dpp<0x121>(0.f, si);      // row_ror:1
+        if (DP >= 32) {
+            // rows 1 and 3 take the sum of the row below them (lane 15 of it, broadcast): no LDS round trip
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x142, 0xA, 0xF, false));
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x142, 0xA, 0xF, false));
+        }
+        if (DP >= 64) {
+            // rows 2 and 3 take lane 31 (rows 0 + 1): row 3 then holds all four
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x143, 0xC, 0xF, false));
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x143, 0xC, 0xF, false));
+        }
+        acc[c] = make_float2(sr, si);
+    }
+    // the LAST row of 16 lanes of every group holds the group's sums: its lane c stores output c
+    const int pl = p - (DP - 16);
+    if (pl >= 0 && pl < PR) {
+        float2 v = acc[0];
+#pragma unroll
+        for (int c = 1; c < PR; ++c) v = (pl == c) ? acc[c] : v;
+        const long long m = out_base + (long long)grp * PR + pl;
+        if (m < n_out) out[m] = v;
+    }
+}
+
 // new history = last T-1 samples of (hist | in[0..n_in)), converted to float
 template <int TYPE>
 __global__ void fir_hist_kernel(const void *__restrict__ in, const float2 *__restrict__ hist_old,
@@ -371,6 +489,28 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
     if (D == 1) RC = 5;
     else RC = 3;
+    // large decimations whose phases map onto lanes take the polyphase kernel
+    poly = (D == 16 || D == 32 || D == 64) && (T + D - 1) / D <= POLY_NQ;
+    if (poly) {
+        threads = 256;
+        RC = 1;
+        pad = false;
+        const int OB = (threads / D) * POLY_PR;
+        tile_len = (POLY_NQ + OB - 1) * D + 2;
+        lds_bytes = (size_t)tile_len * sizeof(float2);
+        std::vector<float> hq((size_t)D * POLY_NQ, 0.0f);
+        for (int ph = 0; ph < D; ++ph)
+            for (int q = 0; q < POLY_NQ; ++q)
+                if (q * D + ph < T) hq[(size_t)ph * POLY_NQ + q] = taps[q * D + ph];
+        XR_TRY(g.reserve(hq.size() * sizeof(float)));
+        XR_HIP(hipMemcpy(g.p, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice));
+        XR_TRY(hist[0].reserve((size_t)(T > 1 ? T - 1 : 1) * sizeof(float2)));
+        XR_TRY(hist[1].reserve((size_t)(T > 1 ? T - 1 : 1) * sizeof(float2)));
+        XR_HIP(hipMemset(hist[0].p, 0, hist[0].bytes));
+        XR_HIP(hipMemset(hist[1].p, 0, hist[1].bytes));
+        cur = 0;
+        return XRIT_OK;
+    }
     pad = ((RC * D) % 2) == 0;
     W = T + (RC - 1) * D;
     Wpad = (W + 3) & ~3;
@@ -409,12 +549,13 @@ int FirStage::init(const float *taps, int ntaps, int decim)
 
 bool FirStage::agc_supported() const
 {
-    return !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs
+    return !poly && !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs
 }
 
 bool FirStage::stat_supported(int statL) const
 {
     // runs must not straddle blocks, and the two partial arrays must fit in the window tile
+    if (poly) return false;
     if (statL == 64 * RC && !pad && threads % 64 == 0) return true;      // one run per wave
     return statL > 0 && !pad && (threads * RC) % statL == 0 && statL >= RC && (size_t)2 * threads * sizeof(float2) <= lds_bytes;
 }
@@ -496,7 +637,27 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
         agc = *agc_in;
     }
     size_t n_in = n_out * (size_t)D;
-    if (n_out > 0) {
+    if (n_out > 0 && poly) {
+        ProfScope ps(prof, "fir_decim", s);
+        const int OB = (threads / D) * POLY_PR;
+        const unsigned blocks = (div_up(n_out, (size_t)OB) + 7u) & ~7u;          // XCD-contiguous tile ranges
+        const float2 *h = hist[cur].as<float2>();
+#define XR_POLY_GO(DPV, TY)                                                                                      \
+    hipLaunchKernelGGL((fir_poly_kernel<DPV, POLY_PR, POLY_NQ, TY>), dim3(blocks), dim3(threads), lds_bytes, s, in, h,  \
+                       out, g.as<float>(), T, (long long)n_out, (long long)n_in, tile_len)
+#define XR_POLY_TY(DPV)                                                         \
+    do {                                                                        \
+        if (type == XRIT_SAMPLE_FLOATIQ) XR_POLY_GO(DPV, XRIT_SAMPLE_FLOATIQ);  \
+        else if (type == XRIT_SAMPLE_S16IQ) XR_POLY_GO(DPV, XRIT_SAMPLE_S16IQ); \
+        else XR_POLY_GO(DPV, XRIT_SAMPLE_S8IQ);                                 \
+    } while (0)
+        if (D == 16) XR_POLY_TY(16);
+        else if (D == 32) XR_POLY_TY(32);
+        else XR_POLY_TY(64);
+#undef XR_POLY_TY
+#undef XR_POLY_GO
+        XR_HIP(hipGetLastError());
+    } else if (n_out > 0) {
         ProfScope ps(prof, D > 1 ? "fir_decim" : "fir_rrc", s);
         if (RC == 5 && !pad) XR_TRY((fir_launch_t<5, false>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
         else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));

@@ -11,8 +11,10 @@ namespace xrit {
 struct FirStage {
     int T = 0, D = 1, RC = 3, W = 0, Wpad = 0, threads = 256, tile_len = 0, cur = 0;
     bool pad = false;
+    bool poly = false;   // polyphase kernel (lanes = phases) for decimation 16 / 32 / 64
+    static constexpr int POLY_PR = 16, POLY_NQ = 32;     // outputs per lane group, taps per phase (T <= 32 * D)
     size_t lds_bytes = 0;
-    DevBuf g;        // RC x Wpad window taps
+    DevBuf g;        // RC x Wpad window taps (polyphase: D x POLY_NQ phase taps)
     DevBuf hist[2];  // T-1 samples of history (ping-pong)
     int init(const float *taps, int ntaps, int decim);
     void release();
