@@ -283,7 +283,8 @@ def main():
                                   mode.upper(), ("decimating LPF %d taps d=%d -> " % (dem.decimator_ntaps, D)) if D > 1 else "",
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
-                   "segments": world, "costas_chain_len": 256, "clock_chain_syms": 64},
+                   "segments": world, "costas_chain_len": args.costas_chain or 256,
+                   "clock_chain_syms": args.clock_chain or "auto: 64 at C2, up to 256 for calls with more symbols"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
         "algorithmic_bytes_per_sample": round(b_alg, 4),
         "loop_passes": {"costas": st.costas_passes, "clock": st.clock_passes,

@@ -664,6 +664,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     par.gain_mu = gain_mu;
     mu0 = mu;
     NS = chain_syms > 0 ? chain_syms : 64;
+    auto_ns = chain_syms <= 0;
     max_passes = max_passes_ > 0 ? max_passes_ : 48;
     min_passes = max_passes < 4 ? max_passes : 4;
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
@@ -818,6 +819,13 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     }
     // chain budget: the slowest admissible symbol clock plus slack
     const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
+    if (auto_ns) {
+        // 64 symbols per chain fill the chip at C2 (197 k chains = 3 waves per SIMD); calls with several times as many
+        // symbols (no decimator in front) take longer chains instead of more of them: the hand-off solves cost per
+        // chain (C3: 1.5 ms of 12.2 at 64, 0.44 at 256; beyond 256 the passes lose more than the solves gain)
+        NS = 64;
+        while (NS < 256 && (double)j.N / (min_omega * NS) > 262144.0) NS *= 2;
+    }
     const int K = (int)((double)j.N / (min_omega * NS)) + 3;
     j.K = K;
     const int BL = ext ? om_BL : CLK_OM_BLOCK;

@@ -111,7 +111,8 @@ struct CostasStage {
 struct ClockStage {
     ClockPar par{};
     float sps = 0, mu0 = 0.5f;
-    int NS = 64;            // symbols per chain
+    int NS = 64;            // symbols per chain (auto_ns: 64, 128 or 256, chosen per call from its size)
+    bool auto_ns = true;
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
