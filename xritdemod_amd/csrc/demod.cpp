@@ -258,12 +258,15 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     // ... and when nobody asks for the AGC output itself, the matched filter applies the gains while it fills its
     // window: the AGC then costs the stream no sweep of its own at all
     const bool agc_in_rrc = agc_fused && !d->keep_stages && d->rrc.agc_fill_supported(d->dec.RC);
+    // no decimator (C1, C3): the run maps come from one read-only sweep, the rest is the same
+    const bool agc_in_rrc_d1 = D == 1 && length > 0 && !d->keep_stages && d->rrc.agc_fill_supported(3);
     AgcFill fill{};
     float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
-    if (agc_in_rrc) {
+    if (agc_in_rrc || agc_in_rrc_d1) {
         XR_TRY(d->bufC[set].reserve((length + 8) * sizeof(float2)));
         Cfb = d->bufC[set].as<float2>();
-        XR_TRY(d->agc.fused_scan(cur, Cfb, length, d->dec.RC, s, prof, &fill));                     // :143
+        if (agc_in_rrc_d1) XR_TRY(d->agc.fused_reduce(cur, length, 3, s, prof));
+        XR_TRY(d->agc.fused_scan(cur, Cfb, length, agc_in_rrc ? d->dec.RC : 3, s, prof, &fill));    // :143
     }
     else if (agc_fused) XR_TRY(d->agc.fused_finish(cur, B, length, d->dec.RC, s, prof));
     else XR_TRY(d->agc.run(cur, B, length, s, prof));
@@ -275,9 +278,10 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
     io->stat_ready = length > 0 && d->rrc.stat_supported(L);
     // (fused: A holds the decimator output, which the fill reads; the filter output goes to B's place instead)
-    float2 *rrc_out = agc_in_rrc ? B : A;
-    XR_TRY(d->rrc.run(agc_in_rrc ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
-                      nullptr, agc_in_rrc ? &fill : nullptr)); // :148
+    const bool fill_on = agc_in_rrc || agc_in_rrc_d1;
+    float2 *rrc_out = fill_on ? B : A;
+    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
+                      nullptr, fill_on ? &fill : nullptr)); // :148
     XR_TRY(keep_stage(d, 2, rrc_out, length, s));
     io->rrc = rrc_out;
     return XRIT_OK;

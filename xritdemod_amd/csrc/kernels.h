@@ -64,6 +64,8 @@ struct AgcStage {
     // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
     int fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi);      // per_lane: the producer's RC
     int fused_finish(const float2 *in, float2 *out, size_t n, int per_lane, hipStream_t s, Profiler *prof);
+    // no producer with an epilogue in front: one read-only sweep composes the run maps (then fused_scan())
+    int fused_reduce(const float2 *in, size_t n, int per_lane, hipStream_t s, Profiler *prof);
     // instead of fused_finish(): scan only; the consumer (the matched filter) applies the gains in its window fill.
     // `fallback` receives the serial result if the guard trips.
     int fused_scan(const float2 *in, float2 *fallback, size_t n, int per_lane, hipStream_t s, Profiler *prof, AgcFill *fill);
