@@ -45,9 +45,9 @@ with open(os.path.join(dst, f"{tag}_c2_pmc_hbm.csv"), "w") as fo:
     fo.write("kernel,dispatches,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,hbm_bytes_corrected\n")
     for k, n, fv, wv in rows:
         fo.write(f"{k},{n},{fv:.1f},{wv:.1f},{(2 * fv + wv) * 1024:.0f}\n")
-names = {"fir_decim": "fir_decim_kernel<3, false, 0>", "clock_pass": "clock_pass_kernel<1, 32, 20>",
+names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0>", "clock_pass": "clock_pass_kernel<1, 32, 20>",
          "clock_pass_jac": "clock_pass_kernel<3, 32, 20>", "costas_pass": "costas_pass_kernel<false>",
-         "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0>",
+         "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0, 3>",
          "agc_apply": "agc_apply_runs_kernel<3>", "clock_output": "clock_output_kernel<32, 20>"}
 d = {r[0]: r for r in rows}
 out = {}
