@@ -113,7 +113,9 @@ float xrit_demod_sps(const xrit_demod *d);
 int   xrit_demod_decimator_ntaps(const xrit_demod *d);
 
 /* Diagnostics: enable=1 makes every later process call keep a copy of each
- * stage's output (costs D2D copies; off by default). */
+ * stage's output (costs D2D copies and un-fuses the stages; off by default).
+ * enable=2 keeps only stage 4, the complex symbols that DiagManager::addSamples
+ * taps (demodulator.cpp:161-163), at no other cost. */
 int xrit_demod_keep_stages(xrit_demod *d, int enable);
 /* Copies a stage's output of the LAST process call to host (tests/diagnostics):
  * 0 decimator, 1 agc, 2 rrc, 3 costas, 4 clock recovery (complex symbols).

@@ -523,3 +523,43 @@ def test_agc_inside_the_matched_filter_fill_is_the_same_chain(xa, oracle_mod):
     got = c.process(y)
     assert c.stats().agc_serial_fallback == 1
     check_symbols(got, want)
+
+
+def test_host_program_constellation_tap(xa, oracle_mod, tmp_path):
+    """--diag: DiagManager's UDP feed (1024 int8 = 512 complex symbols x128 per datagram, towards port 9000 in the
+    reference) from the complex symbols of the clock recovery, kept with xrit_demod_keep_stages(chain, 2)."""
+    import socket
+    import subprocess
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    n, block = 1200000, 300000
+    x = synth_signal(n)
+    f = tmp_path / "capture.cf32"
+    x.tofile(f)
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(20)
+    port = rx.getsockname()[1]
+    p = subprocess.Popen([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
+                          "--sink", "null", "--diag", f"udp://127.0.0.1:{port}", "--paced"], stderr=subprocess.PIPE)
+    # --paced: the blocks are released at the capture's sample rate (0.24 s apart), so every block's 1024 floats
+    # leave as their own datagram (the tap sends at most one per 10 ms)
+    grams = []
+    try:
+        while len(grams) < 2:
+            grams.append(rx.recv(4096))
+    finally:
+        p.wait(timeout=60)
+        rx.close()
+    assert p.returncode == 0 and all(len(g) == 1024 for g in grams)
+    # what the reference queues: per chain call min(symbols, 1024) FLOATS of the interleaved complex symbols
+    od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
+    queued = []
+    for i in range(0, n, block):
+        od.process(x[i:i + block])
+        c = od.stage("clock")
+        queued.append(c.view(np.float32)[:min(len(c), 1024)])
+    q = np.concatenate(queued)
+    want = np.clip(q * 128.0, -128, 127).astype(np.int8)      # C cast: truncation toward zero
+    got = np.frombuffer(b"".join(grams), np.int8)
+    d = np.abs(got.astype(np.int16) - want[:len(got)].astype(np.int16))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.97

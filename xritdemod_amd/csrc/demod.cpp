@@ -54,7 +54,8 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], stat[2], in_dev, soft_dev, q_in, q_out;   // two sets: one per time slice in flight
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_in = nullptr, ev_fe[2] = {nullptr, nullptr}, ev_lp[2] = {nullptr, nullptr};
-    bool keep_stages = false;
+    bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
+    bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
     DevBuf stage_buf[5];
     size_t stage_n[5] = {0, 0, 0, 0, 0};
     Profiler prof;
@@ -301,7 +302,7 @@ static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_
     // of hand-off passes each with a device-side stop test, final / output passes -- and the host waits once.
     // Only when a batch did not close (cold start, unlocked input) does it continue pass by pass.
     float2 *sym = nullptr;
-    if (d->keep_stages) {
+    if (d->keep_stages || d->keep_symbols) {
         XR_TRY(d->stage_buf[4].reserve((cap + 1) * sizeof(float2)));
         sym = d->stage_buf[4].as<float2>();
     }
@@ -320,7 +321,7 @@ static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_
     }
     XR_TRY(keep_stage(d, 3, slot, length, s));
     int rc = d->clock.finish(nsym, s, prof);
-    if (d->keep_stages) XR_HIP(hipStreamSynchronize(s));
+    if (d->keep_stages || d->keep_symbols) XR_HIP(hipStreamSynchronize(s));
     return rc;
 }
 
@@ -344,7 +345,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     // down, 3.4 ms -> 3.8 / 4.3 / 4.8 ms for 2 / 3 / 4 slices.
     const size_t quantum = (size_t)D * 5120;
     size_t slices = 1;
-    if (!d->keep_stages && d->cfg.slices > 1 && n >= ((size_t)1 << 22)) {
+    if (!d->keep_stages && !d->keep_symbols && d->cfg.slices > 1 && n >= ((size_t)1 << 22)) {
         slices = (size_t)d->cfg.slices;
         while (slices > 1 && n / slices < ((size_t)1 << 20)) --slices;
     }
@@ -439,7 +440,10 @@ int xrit_demod_process(xrit_demod *d, const void *samples, size_t n, int type, f
 int xrit_demod_read_stage(xrit_demod *d, int stage, float *out, size_t cap, size_t *n)
 {
     if (!d || stage < 0 || stage > 4 || !n) { set_error("bad argument"); return XRIT_E_INVALID; }
-    if (!d->keep_stages) { set_error("stage copies are off: call xrit_demod_keep_stages(d, 1) first"); return XRIT_E_INVALID; }
+    if (!d->keep_stages && !(d->keep_symbols && stage == 4)) {
+        set_error("stage copies are off: call xrit_demod_keep_stages(d, 1) first (2 keeps stage 4 only)");
+        return XRIT_E_INVALID;
+    }
     *n = d->stage_n[stage];
     if (!out) return XRIT_OK;
     if (*n > cap) { set_error("stage %d holds %zu elements, capacity %zu", stage, *n, cap); return XRIT_E_CAPACITY; }
@@ -452,7 +456,8 @@ int xrit_demod_read_stage(xrit_demod *d, int stage, float *out, size_t cap, size
 int xrit_demod_keep_stages(xrit_demod *d, int enable)
 {
     if (!d) return XRIT_E_INVALID;
-    d->keep_stages = enable != 0;
+    d->keep_stages = enable == 1;
+    d->keep_symbols = enable == 2;
     return XRIT_OK;
 }
 

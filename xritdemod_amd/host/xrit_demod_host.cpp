@@ -12,6 +12,10 @@
 //                               in pieces of at most 16384 bytes (SM_SOCKET_BUFFER_SIZE)
 //   * SymbolManager.cpp:23-35   the demodulator is the TCP *client*; it retries the
 //                               connection once per second until the decoder listens
+//   * DiagManager.cpp:24-62,    --diag: the constellation tap -- after every chain call up to 1024 floats of
+//     demodulator.cpp:161-163   the complex symbols (I, Q interleaved) are queued; whenever 1024 are queued and
+//                               10 ms have passed they go out as int8 (x128, clamp, truncation) in one UDP
+//                               datagram from port 9001 to HOST:9000
 // Only the C ABI of include/xritdemod_amd.h is used (no HIP headers): this file builds
 // with plain g++.
 #include <arpa/inet.h>
@@ -22,6 +26,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <deque>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +44,7 @@ struct Options {
     std::string input;
     std::string format = "cf32";
     std::string sink = "tcp://127.0.0.1:5000";
+    std::string diag;              // udp://HOST:PORT, empty = off
     double sample_rate = 2.5e6;
     unsigned decimation = 1;
     size_t block = 1u << 22;       // complex samples per chain call (>= 4 Mi when throughput matters)
@@ -53,7 +59,8 @@ void usage()
     std::fprintf(stderr,
                  "usage: xrit_demod_host --input FILE [--format cf32|s16|s8] [--mode lrit|hrit]\n"
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
-                 "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n");
+                 "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
+                 "         [--diag udp://HOST:PORT]\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -74,6 +81,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--block") { if (!(v = need("--block"))) return false; o.block = (size_t)std::atoll(v); }
         else if (a == "--device") { if (!(v = need("--device"))) return false; o.device = std::atoi(v); }
         else if (a == "--connect-tries") { if (!(v = need("--connect-tries"))) return false; o.connect_tries = std::atoi(v); }
+        else if (a == "--diag") { if (!(v = need("--diag"))) return false; o.diag = v; }
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
@@ -172,6 +180,59 @@ struct Sink {
     }
 };
 
+// ---- constellation tap (DiagManager) -----------------------------------------------------------------------
+struct Diag {
+    int fd = -1;
+    sockaddr_in to{};
+    std::deque<float> q;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now() - std::chrono::seconds(1);
+    static constexpr size_t CAP = 1u << 16;            // the reference's buffer simply stops taking samples when full
+
+    bool open(const std::string &spec)
+    {
+        if (spec.rfind("udp://", 0) != 0) { std::fprintf(stderr, "diag: udp://HOST:PORT expected\n"); return false; }
+        std::string hp = spec.substr(6);
+        size_t c = hp.rfind(':');
+        if (c == std::string::npos) return false;
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_INET;
+        hints.ai_socktype = SOCK_DGRAM;
+        if (getaddrinfo(hp.substr(0, c).c_str(), hp.c_str() + c + 1, &hints, &res) != 0 || !res) return false;
+        std::memcpy(&to, res->ai_addr, sizeof to);
+        freeaddrinfo(res);
+        fd = ::socket(AF_INET, SOCK_DGRAM, 0);
+        if (fd < 0) return false;
+        sockaddr_in from{};
+        from.sin_family = AF_INET;
+        from.sin_addr.s_addr = htonl(INADDR_ANY);
+        from.sin_port = htons(9001);                   // DiagManager.cpp:30; not fatal if somebody else holds it
+        (void)::bind(fd, reinterpret_cast<sockaddr *>(&from), sizeof from);
+        return true;
+    }
+    // demodulator.cpp:161-163: (float *)symbols, min(symbols, 1024) FLOATS
+    void add(const float *iq, size_t nsym)
+    {
+        size_t nf = nsym < 1024 ? nsym : 1024;
+        if (q.size() + nf > CAP) return;
+        q.insert(q.end(), iq, iq + nf);
+    }
+    void pump()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (q.size() < 1024 || now - last < std::chrono::milliseconds(10)) return;
+        char data[1024];
+        for (int i = 0; i < 1024; ++i) {
+            float v = q.front() * 128.f;
+            q.pop_front();
+            v = v > 127 ? 127 : v;
+            v = v < -128 ? -128 : v;
+            data[i] = static_cast<char>(v);
+        }
+        (void)::sendto(fd, data, sizeof data, 0, reinterpret_cast<const sockaddr *>(&to), sizeof to);
+        last = now;
+    }
+};
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -202,6 +263,16 @@ int main(int argc, char **argv)
     Sink sink;
     if (!sink.open(o.sink, o.connect_tries)) { std::fclose(in); xrit_demod_destroy(chain); return 1; }
 
+    Diag diag;
+    std::vector<float> diag_iq;
+    if (!o.diag.empty()) {
+        if (!diag.open(o.diag) || xrit_demod_keep_stages(chain, 2) != XRIT_OK) {
+            std::fprintf(stderr, "diag: cannot set up %s\n", o.diag.c_str());
+            sink.close_all(); std::fclose(in); xrit_demod_destroy(chain);
+            return 1;
+        }
+        diag_iq.resize(2 * 1024);
+    }
     std::vector<unsigned char> raw(o.block * bytes_per_sample);
     const size_t cap = o.block + 64;
     std::vector<float> soft(cap);
@@ -225,6 +296,16 @@ int main(int argc, char **argv)
         rc = xrit_quantize_i8(chain, soft.data(), q.data(), nsym);
         if (rc != XRIT_OK) { std::fprintf(stderr, "quantize: %s\n", xrit_last_error()); exit_code = 1; break; }
         if (!sink.send_all(q.data(), nsym)) { exit_code = 1; break; }
+        if (diag.fd >= 0 && nsym > 0) {
+            // the first symbols of the call, complex (stage 4); only what the tap can take is copied back
+            std::vector<float> all;
+            size_t have = 0;
+            if (xrit_demod_read_stage(chain, 4, nullptr, 0, &have) == XRIT_OK && have > 0) {
+                all.resize(2 * have);
+                if (xrit_demod_read_stage(chain, 4, all.data(), have, &have) == XRIT_OK) diag.add(all.data(), nsym);
+            }
+            diag.pump();
+        }
         total_in += n;
         total_sym += nsym;
     }
