@@ -152,6 +152,30 @@ int xrit_quantize_i8_device(const float *d_soft, int8_t *d_out, size_t n, int de
 int xrit_quantize_i8(xrit_demod *d, const float *soft, int8_t *out, size_t n);
 
 /* ------------------------------------------------------------------------
+ * Decoder front end ("next" row): frame synchronisation.
+ * Replaces SatHelper::Correlator as decoder/src/newdecoder.cpp uses it before
+ * Viterbi: addWord() of the encoded 64-bit sync words (:145-151; LRIT
+ * 0xfca2b63db00d9794 / 0x035d49c24ff2686b, HRIT 0xfc4ef4fd0cc2df89 /
+ * 0x25010b02f33d2076, :21-24), correlate(codedData, CODEDFRAMESIZE = 16384)
+ * and the three getters (:218-245).  For every consecutive window of `frame`
+ * int8 soft symbols: the word with the most agreeing hard bits (first word on a
+ * tie), the first position where it reaches that count, and the count
+ * (MINCORRELATIONBITS = 46 is the decoder's acceptance, parameters.h:31).
+ * word 0 = as sent, word 1 = inverted (PhaseShift::DEG_180, :232). */
+typedef struct xrit_sync_hit {
+    uint32_t word;
+    uint32_t position;
+    uint32_t correlation;
+    uint32_t reserved;
+} xrit_sync_hit;
+/* device pointers; hits has n_symbols / frame entries */
+int xrit_sync_correlate_device(const int8_t *d_symbols, size_t n_symbols, const uint64_t *words, int nwords,
+                               uint32_t frame, xrit_sync_hit *d_hits, int device, void *stream);
+/* host buffers (one H2D / D2H round trip) */
+int xrit_sync_correlate(const int8_t *symbols, size_t n_symbols, const uint64_t *words, int nwords, uint32_t frame,
+                        xrit_sync_hit *hits, int device);
+
+/* ------------------------------------------------------------------------
  * Stage objects -- the SatHelper classes one by one, for stage-level parity
  * and for callers that keep the reference's five-Work() structure.
  * in/out are HOST pointers unless the _device variant is used.

@@ -105,6 +105,8 @@ def lib():
         L.xo_demod_sps.restype = C.c_float
         L.xo_demod_sps.argtypes = [vp]
         L.xo_quantize_i8.argtypes = [vp, vp, C.c_size_t]
+        L.xo_sync_correlate.argtypes = [vp, C.c_uint32, vp, C.c_int, vp, vp, vp]
+        L.xo_sync_correlate.restype = None
         L.xo_convert_samples.argtypes = [vp, C.c_int, vp, C.c_size_t]
         _lib = L
     return _lib
@@ -278,4 +280,23 @@ def quantize_i8(x):
     x = np.ascontiguousarray(x, np.float32)
     out = np.zeros(len(x), np.int8)
     lib().xo_quantize_i8(_p(x), _p(out), len(x))
+    return out
+
+
+LRIT_UW0, LRIT_UW2 = 0xfca2b63db00d9794, 0x035d49c24ff2686b       # decoder/src/newdecoder.cpp:21-24
+HRIT_UW0, HRIT_UW2 = 0xfc4ef4fd0cc2df89, 0x25010b02f33d2076
+
+
+def sync_correlate(data, words=(LRIT_UW0, LRIT_UW2), frame=16384):
+    """SatHelper::Correlator::correlate over consecutive windows of `frame` soft bytes: (word, position,
+    correlation) per window, as decoder/src/newdecoder.cpp:218-245 reads them."""
+    d = np.ascontiguousarray(data, np.int8)
+    w = np.asarray(words, np.uint64)
+    nf = len(d) // frame
+    out = np.zeros((nf, 3), np.uint32)
+    a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    for f in range(nf):
+        seg = d[f * frame:(f + 1) * frame]
+        lib().xo_sync_correlate(_p(seg), frame, _p(w), len(w), C.byref(a), C.byref(b), C.byref(c))
+        out[f] = (a.value, b.value, c.value)
     return out

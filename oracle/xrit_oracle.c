@@ -606,3 +606,38 @@ void xo_quantize_i8(const float *in, int8_t *out, size_t n)
         out[i] = (int8_t)(char)(f);
     }
 }
+
+/* ---- decoder front end ("next" row): frame synchronisation ---------------------------
+ * What decoder/src/newdecoder.cpp does with SatHelper::Correlator before Viterbi (:145-151 addWord of the two
+ * rate-1/2 encoded 64-bit sync words, :218-245 correlate / getHighestCorrelationPosition / WordNumber /
+ * getHighestCorrelation, MINCORRELATIONBITS 46 at decoder/src/parameters.h:31).  The class lives in libSatHelper
+ * (absent, like the DSP blocks: parity unpinned); restated from its published behaviour: a word's bit k (MSB
+ * first) is stored as 0xFF / 0x00; a soft byte agrees with it when
+ *      (byte >= 127 && wordbyte == 0x00) || (byte < 127 && wordbyte == 0xFF)        -- bytes taken as UNSIGNED,
+ * i.e. int8 0..126 count as a one, 127 and every negative value as a zero; for every start position i in
+ * [0, length - 64) the agreeing bits are counted per word; per word the FIRST position with the highest count is
+ * kept (strict >), then the FIRST word with the highest count. */
+void xo_sync_correlate(const int8_t *data, uint32_t length, const uint64_t *words, int nwords,
+                       uint32_t *word_out, uint32_t *pos_out, uint32_t *corr_out)
+{
+    uint32_t best_c[8] = {0}, best_p[8] = {0};
+    if (nwords > 8) nwords = 8;
+    const int max_search = (int)length - 64;
+    for (int i = 0; i < max_search; i++) {
+        for (int n = 0; n < nwords; n++) {
+            uint32_t c = 0;
+            for (int k = 0; k < 64; k++) {
+                const uint8_t b = (uint8_t)data[i + k];
+                const uint8_t w = ((words[n] >> (63 - k)) & 1) ? 0xFF : 0x00;
+                c += (uint32_t)(((b >= 127) & (w == 0x00)) | ((b < 127) & (w == 0xFF)));
+            }
+            if (c > best_c[n]) { best_c[n] = c; best_p[n] = (uint32_t)i; }
+        }
+    }
+    uint32_t corr = 0, word = 0;
+    for (int n = 0; n < nwords; n++)
+        if (best_c[n] > corr) { word = (uint32_t)n; corr = best_c[n]; }
+    *word_out = word;
+    *pos_out = best_p[word];
+    *corr_out = corr;
+}

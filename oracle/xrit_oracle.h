@@ -117,6 +117,10 @@ float     xo_demod_sps(const xo_demod *d);
 
 /* SymbolManager::process quantiser, SymbolManager.cpp:43-46 */
 void xo_quantize_i8(const float *in, int8_t *out, size_t n);
+
+/* SatHelper::Correlator as the decoder uses it (decoder/src/newdecoder.cpp:145-151,218-245) */
+void xo_sync_correlate(const int8_t *data, uint32_t length, const uint64_t *words, int nwords,
+                       uint32_t *word_out, uint32_t *pos_out, uint32_t *corr_out);
 /* ingest conversion, demodulator.cpp:54-74 */
 void xo_convert_samples(const void *in, int sample_type, xo_cf *out, size_t n);
 

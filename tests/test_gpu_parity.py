@@ -563,3 +563,38 @@ def test_host_program_constellation_tap(xa, oracle_mod, tmp_path):
     got = np.frombuffer(b"".join(grams), np.int8)
     d = np.abs(got.astype(np.int16) - want[:len(got)].astype(np.int16))
     assert d.max() <= 1 and np.mean(d == 0) > 0.97
+
+
+def test_sync_correlator_bit_exact(xa, oracle_mod):
+    """Decoder front end on the device: integer work, so the bar is equality with the oracle -- random soft bytes,
+    planted words (both polarities, near the window edges, twice in a window), extreme byte values, odd frame
+    sizes, and the demodulated symbols of a real chain run."""
+    o = oracle_mod
+    rng = np.random.default_rng(5)
+    frame = 16384
+
+    def plant(buf, pos, word, amp=60):
+        for k in range(64):
+            buf[pos + k] = amp if (word >> (63 - k)) & 1 else -amp
+
+    d = rng.integers(-128, 128, size=40 * frame).astype(np.int8)
+    for f in range(0, 40, 3):
+        plant(d, f * frame + int(rng.integers(0, frame - 64)), o.LRIT_UW0 if f % 2 else o.LRIT_UW2, amp=int(rng.integers(1, 127)))
+    plant(d, 5 * frame + 0, o.LRIT_UW0)
+    plant(d, 7 * frame + frame - 65, o.LRIT_UW2)           # last searched position
+    plant(d, 8 * frame + frame - 64, o.LRIT_UW0)           # one further: not searched by the reference
+    plant(d, 9 * frame + 10, o.LRIT_UW0); plant(d, 9 * frame + 5000, o.LRIT_UW0)
+    d[11 * frame:12 * frame] = -1
+    d[12 * frame:13 * frame] = 127
+    want = o.sync_correlate(d)
+    got = xa.sync_correlate(d)
+    assert np.array_equal(got, want)
+    for words, fr in (((o.HRIT_UW0, o.HRIT_UW2), 16384), ((o.LRIT_UW0,), 1000), ((o.LRIT_UW0, o.LRIT_UW2, o.HRIT_UW0), 65),
+                      ((o.LRIT_UW0, o.LRIT_UW2), 4097)):
+        assert np.array_equal(xa.sync_correlate(d[:20 * fr + 17], words, fr), o.sync_correlate(d[:20 * fr + 17], words, fr))
+    # symbols out of the chain (no framing in the synthetic stream: the best of the noise, the same on both sides)
+    x = synth_signal(1 << 20)
+    q = xa.Demodulator(xa.Demodulator.config("lrit"))
+    s8 = q.quantize_i8(q.process(x))
+    assert np.array_equal(xa.sync_correlate(s8), o.sync_correlate(s8))
+    assert len(xa.sync_correlate(d[:100])) == 0

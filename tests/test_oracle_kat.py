@@ -257,3 +257,39 @@ def test_clock_recovery_is_chaotic_at_ulp_level(oracle_mod, lrit_1m):
     assert (np.sign(y0.real) == np.sign(y1.real)).all()
     assert 0 < flips < 0.02
     assert 1e-6 < e < 3e-4
+
+
+def test_sync_correlator_kats(oracle_mod):
+    """Decoder front end: planted sync words are found at their position with all 64
+    bits; the inverted word reports word 1 (180 degrees); ties keep the first position and the first word; the
+    byte rule is the unsigned one (127 and negatives are zeros)."""
+    o = oracle_mod
+    rng = np.random.default_rng(3)
+    frame = 16384
+    d = rng.integers(-100, 100, size=4 * frame).astype(np.int8)
+
+    def plant(buf, pos, word, amp=60):
+        for k in range(64):
+            buf[pos + k] = amp if (word >> (63 - k)) & 1 else -amp
+
+    plant(d, 5000, o.LRIT_UW0)
+    plant(d, frame + 77, o.LRIT_UW2)
+    plant(d, 2 * frame + 100, o.LRIT_UW0)
+    plant(d, 2 * frame + 9000, o.LRIT_UW0)          # same word twice: the first position wins
+    h = o.sync_correlate(d)
+    assert h[0].tolist() == [0, 5000, 64] and h[1].tolist() == [1, 77, 64] and h[2].tolist() == [0, 100, 64]
+    assert h[3][2] < 64                              # noise only: some best match below 64 bits
+    # UW2 is the complement of UW0: an inverted stream turns word 0 into word 1 at the same place
+    h2 = o.sync_correlate((-d.astype(np.int16)).clip(-128, 127).astype(np.int8))
+    assert h2[0].tolist() == [1, 5000, 64] and h2[1].tolist() == [0, 77, 64]
+    # 127 counts as a zero, 126 as a one; -128 as a zero
+    e = np.full(frame, -5, np.int8)
+    plant(e, 300, o.LRIT_UW0, amp=127)
+    assert o.sync_correlate(e)[0][2] < 64
+    plant(e, 300, o.LRIT_UW0, amp=126)
+    assert o.sync_correlate(e)[0].tolist() == [0, 300, 64]
+    # all zeros: correlation = number of zero bits of the better word, first position, first word on a tie
+    z = np.full(frame, -1, np.int8)
+    hz = o.sync_correlate(z)[0]
+    zeros0, zeros2 = 64 - bin(o.LRIT_UW0).count("1"), 64 - bin(o.LRIT_UW2).count("1")
+    assert hz[2] == max(zeros0, zeros2) and hz[1] == 0 and hz[0] == (0 if zeros0 >= zeros2 else 1)

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "xrit_quantize_i8_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "xrit_quantize_i8": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_sync_correlate_device": (C.c_int, [_vp, _sz, _vp, C.c_int, C.c_uint32, _vp, C.c_int, _vp]),
+    "xrit_sync_correlate": (C.c_int, [_vp, _sz, _vp, C.c_int, C.c_uint32, _vp, C.c_int]),
     "xrit_fir_create": (C.c_int, [C.c_uint, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "xrit_fir_work": (C.c_int, [_vp, _vp, _vp, _sz]),
     "xrit_fir_destroy": (None, [_vp]),
@@ -366,3 +368,28 @@ def synth_params(**over):
 def quantize_i8_device(d_soft_ptr, d_out_ptr, n, device=0, stream=None):
     _check(lib().xrit_quantize_i8_device(C.c_void_p(d_soft_ptr), C.c_void_p(d_out_ptr), n, device,
                                          C.c_void_p(stream) if stream else None))
+
+
+# ---- decoder front end: frame synchronisation (decoder/src/newdecoder.cpp:21-24,145-151,218-245) ----------------
+LRIT_UW0, LRIT_UW2 = 0xfca2b63db00d9794, 0x035d49c24ff2686b
+HRIT_UW0, HRIT_UW2 = 0xfc4ef4fd0cc2df89, 0x25010b02f33d2076
+CODED_FRAME_SIZE = 16384
+MIN_CORRELATION_BITS = 46
+
+
+def sync_correlate(symbols, words=(LRIT_UW0, LRIT_UW2), frame=CODED_FRAME_SIZE, device=0):
+    """SatHelper::Correlator over consecutive windows of `frame` int8 soft symbols: array of (word, position,
+    correlation) rows, one per window."""
+    d = np.ascontiguousarray(symbols, np.int8)
+    w = np.asarray(words, np.uint64)
+    nf = len(d) // frame
+    hits = np.zeros((nf, 4), np.uint32)
+    _check(lib().xrit_sync_correlate(_p(d), len(d), _p(w), len(w), frame, _p(hits), device))
+    return hits[:, :3].copy()
+
+
+def sync_correlate_device(d_symbols_ptr, n, d_hits_ptr, words=(LRIT_UW0, LRIT_UW2), frame=CODED_FRAME_SIZE, device=0,
+                          stream=None):
+    w = np.asarray(words, np.uint64)
+    _check(lib().xrit_sync_correlate_device(C.c_void_p(d_symbols_ptr), n, _p(w), len(w), frame, C.c_void_p(d_hits_ptr),
+                                            device, C.c_void_p(stream) if stream else None))

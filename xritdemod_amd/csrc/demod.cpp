@@ -499,6 +499,39 @@ int xrit_quantize_i8_device(const float *d_soft, int8_t *d_out, size_t n, int de
     return launch_quantize_i8(d_soft, d_out, n, (hipStream_t)stream);
 }
 
+int xrit_sync_correlate_device(const int8_t *d_symbols, size_t n, const uint64_t *words, int nwords, uint32_t frame,
+                               xrit_sync_hit *d_hits, int device, void *stream)
+{
+    if (!words || (n >= frame && (!d_symbols || !d_hits))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    return launch_sync_correlate(d_symbols, n, reinterpret_cast<const unsigned long long *>(words), nwords, frame, d_hits,
+                                 (hipStream_t)stream);
+}
+
+int xrit_sync_correlate(const int8_t *symbols, size_t n, const uint64_t *words, int nwords, uint32_t frame,
+                        xrit_sync_hit *hits, int device)
+{
+    if (!words || frame == 0 || (n >= frame && (!symbols || !hits))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    const size_t nf = n / frame;
+    if (nf == 0) return XRIT_OK;
+    DevBuf din, dh;
+    int rc = din.reserve(nf * frame);
+    if (rc == XRIT_OK) rc = dh.reserve(nf * sizeof(xrit_sync_hit));
+    if (rc == XRIT_OK && hipMemcpy(din.p, symbols, nf * frame, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); rc = XRIT_E_HIP; }
+    if (rc == XRIT_OK)
+        rc = launch_sync_correlate(din.as<int8_t>(), nf * frame, reinterpret_cast<const unsigned long long *>(words), nwords, frame,
+                                   dh.as<xrit_sync_hit>(), nullptr);
+    if (rc == XRIT_OK && (hipDeviceSynchronize() != hipSuccess ||
+                          hipMemcpy(hits, dh.p, nf * sizeof(xrit_sync_hit), hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("sync: device error");
+        rc = XRIT_E_HIP;
+    }
+    din.release();
+    dh.release();
+    return rc;
+}
+
 int xrit_quantize_i8(xrit_demod *d, const float *soft, int8_t *out, size_t n)
 {
     if (!d || (n && (!soft || !out))) { set_error("null argument"); return XRIT_E_INVALID; }
