@@ -1,0 +1,56 @@
+"""Randomised chain comparison against the oracle (GPU): random mode / decimation / length / chunking / ingest
+type.  Not collected by pytest; run by hand:  python tests/experiments/fuzz_chain.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import oracle
+import xritdemod_amd as xa
+from xritdemod_amd import synth
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for c in range(cases):
+    mode = "lrit" if rng.random() < 0.7 else "hrit"
+    D = int(rng.choice([1, 1, 2, 3, 5, 5, 8, 16, 32]))
+    base = 1.25e6 if mode == "lrit" else 2.5e6
+    fs = base * D
+    n = int(rng.integers(1, int(os.environ.get("FUZZ_MAX", "400000")))) * D + int(rng.integers(0, D))
+    typ = int(rng.choice([0, 0, 0, 1, 2]))
+    sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
+    amp = 0.1 if typ == 0 else 0.3
+    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=int(rng.integers(1, 1 << 30))), n)
+    if typ == 1:
+        xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    elif typ == 2:
+        xi = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
+    else:
+        xi = x
+    per = 1 if typ == 0 else 2
+    ncut = int(rng.integers(0, 4))
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, ncut)]))
+    keep = rng.random() < 0.3
+    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D))
+    gd.keep_stages(keep)
+    want, got = [], []
+    ok = True
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        seg = xi[per * lo:per * hi]
+        w, g = od.process(seg, typ), gd.process(seg, typ)
+        want.append(w); got.append(g)
+        if len(w) != len(g):
+            ok = False
+    w, g = np.concatenate(want), np.concatenate(got)
+    msg = ""
+    if ok and len(w):
+        big = np.abs(w) > 1e-3
+        sgn = int(np.sum(np.sign(w[big]) != np.sign(g[big])))
+        r = float(np.sqrt(np.mean((w - g) ** 2)))
+        if sgn or r > 6e-4:
+            ok = False
+        msg = f"rms {r:.2e} sign {sgn}"
+    print(("ok  " if ok else "FAIL"), c, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg, flush=True)
+    bad += 0 if ok else 1
+print("failures:", bad)
+sys.exit(1 if bad else 0)
