@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
     ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
     ap.add_argument("--slices", type=int, default=0, help="time slices per call (0 = library default, 1 = off)")
+    ap.add_argument("--cpu-threads", type=int, default=1,
+                    help="also time the oracle on this many host threads, one independent stream segment each "
+                         "(SURVEY.md 8(d)(ii)); the single-thread figure stays the cpu_baseline")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
                     help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
                          "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")
@@ -309,6 +312,23 @@ def main():
                                "sample": "first %d Mi samples of burst 0, oracle/xrit_oracle.c single thread "
                                          "(gcc -O3 -mavx2 -ffp-contract=off)" % (n_cpu >> 20),
                                "seconds": round(c1 - c0, 3)}
+        if args.cpu_threads > 1:
+            # N independent segments on N threads (the C call releases the GIL): what the node's cores do together
+            import threading
+            T = args.cpu_threads
+            n_t = min(n_cpu, 1 << 25)
+            segs = [bursts[min(i, bursts.shape[0] - 1), :n_t].cpu().numpy().view(np.complex64).reshape(-1) for i in range(T)]
+            dems = [oracle.Demod(oracle.config(mode, fs_in, D)) for _ in range(T)]
+            th = [threading.Thread(target=dems[i].process, args=(segs[i],)) for i in range(T)]
+            m0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            m1 = time.perf_counter()
+            out["cpu_baseline"]["all_threads"] = {"value": round(T * n_t / (m1 - m0) / 1e6, 3), "unit": "Msamples/s",
+                                                  "cores": T, "host_cores": os.cpu_count(),
+                                                  "sample": "%d segments of %d Mi samples" % (T, n_t >> 20)}
         if soft0 is not None:
             g = soft0[:len(so)].cpu().numpy()
             n = min(len(g), len(so))
