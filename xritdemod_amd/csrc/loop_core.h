@@ -52,10 +52,23 @@ XR_HD AgcMap agc_compose(const AgcMap &lo, const AgcMap &hi)
 
 XR_HD float agc_apply(const AgcMap &m, float g) { return fminf(m.a * g + m.b, m.c); }
 
+// |x| on the device: v_sqrt_f32 (1 ulp) instead of the ~16-instruction correctly rounded sqrtf.  The matched
+// filter's AGC fill takes two square roots per sample and was VALU bound on them (1256 VALU per wave, a quarter of
+// it sqrtf refinement); the AGC loop is contractive, so a last-bit difference in |x| does not accumulate (stage
+// parity against the oracle unchanged at ~1e-6).
+XR_HD float agc_sqrt(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(v);
+#else
+    return sqrtf(v);
+#endif
+}
+
 // map of one sample: g += rate*(ref - |x| g); clamp to max (max<=0: no clamp)
 XR_HD AgcMap agc_sample_map(float xr, float xi, float rate, float ref, float maxg)
 {
-    float mag = sqrtf(xr * xr + xi * xi);
+    float mag = agc_sqrt(xr * xr + xi * xi);
     AgcMap m;
     m.a = 1.0f - rate * mag;
     m.b = rate * ref;
@@ -68,7 +81,7 @@ XR_HD void agc_step(float xr, float xi, float &g, float rate, float ref, float m
 {
     yr = xr * g;
     yi = xi * g;
-    g += rate * (ref - sqrtf(yr * yr + yi * yi));
+    g += rate * (ref - agc_sqrt(yr * yr + yi * yi));
     if (maxg > 0.0f && g > maxg) g = maxg;
 }
 
