@@ -709,8 +709,8 @@ double2 *ClockStage::om_slot(int nb, int BL, double offset)
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
     (void)s;
-    XR_TRY(xbuf.reserve((carry + n + 64) * sizeof(float2)));
-    *slot = xbuf.as<float2>() + carry;
+    XR_TRY(xbuf.reserve((carry + n + 64 + 16) * sizeof(float2)));
+    *slot = xbase() + carry;
     return XRIT_OK;
 }
 
@@ -725,7 +725,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
     ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, nullptr,
                     0.75f, 0.01f, tol_t, tol_w, min_passes};
     const unsigned gridK = div_up((size_t)j.K, 64);
-    const float2 *x = xbuf.as<float2>();
+    const float2 *x = xbase();
     for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
         const int p = job.enqueued;
         {
@@ -761,7 +761,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
 {
     const Job &j = job;
-    const float2 *x = xbuf.as<float2>();
+    const float2 *x = xbase();
     const ClockState *st_in = st.as<ClockState>() + cur;
     ClockState *st_out = st.as<ClockState>() + (cur ^ 1);
     float2 *tail_out = tail.as<float2>() + 1024 * (cur ^ 1);
@@ -800,8 +800,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.N = (long long)(carry + n);
     j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
     if (j.N >= (1LL << 31)) { set_error("clock recovery: more than 2^31 samples in one call"); return XRIT_E_INVALID; }
-    XR_TRY(xbuf.reserve((size_t)(j.N + 64) * sizeof(float2)));
-    float2 *x = xbuf.as<float2>();
+    XR_TRY(xbuf.reserve((size_t)(j.N + 64 + 16) * sizeof(float2)));
+    float2 *x = xbase();
     if (carry)
         hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, s, tail.as<float2>() + 1024 * cur, x, (int)carry);
     const bool ext = om_ext;          // statistic supplied by the producer of the samples (Costas final pass)

@@ -118,7 +118,10 @@ struct ClockStage {
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
-    DevBuf xbuf;            // [carry | new] input samples of the call
+    DevBuf xbuf;            // [pad | carry | new] input samples of the call
+    // The new samples (the Costas loop's output rows of 128 bytes) start on a 128-byte boundary: the carried tail
+    // sits right-aligned in front of it.  Unaligned, every output row straddled two lines (partial-line writes).
+    float2 *xbase() const { return xbuf.as<float2>() + (16 - carry % 16) % 16; }
     DevBuf st;              // carried ClockState + carry count
     DevBuf S, E, J, om, work, counters, sym, dlin, flags;
     DevBuf tail;                      // 2 x 1024 samples left unread by a call (ping-pong with the state)
