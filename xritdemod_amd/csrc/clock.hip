@@ -18,6 +18,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include "scan.h"
 #include "newton.h"
 
@@ -279,11 +280,17 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 // SS symbols of one lane.  Fast path: every running lane of the wave stays inside its ring for the whole
 // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only.  Otherwise the wave
 // computes the sub-step from global memory with the guards.  orow (output pass): where the symbols go.
-template <int WP, bool OUT>
+// the output tile holds complex symbols, or only their real parts when nobody asks for the complex ones
+__device__ __forceinline__ void clock_put(float2 &d, const cf32 &p) { d = make_float2(p.x, p.y); }
+__device__ __forceinline__ void clock_put(float &d, const cf32 &p) { d = p.x; }
+__device__ __forceinline__ float2 clock_get(const float2 &v) { return v; }
+__device__ __forceinline__ float2 clock_get(const float &v) { return make_float2(v, 0.f); }
+
+template <int WP, bool OUT, typename OutT>
 __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *__restrict__ x, int WS, int lane,
                                               int origin, int cum, int lim, int SS, int A, long long ni,
                                               const ClockPar &par, ClockState &s, int &off, bool &alive,
-                                              int &produced, float2 *orow)
+                                              int &produced, OutT *orow)
 {
     const int rel = off - cum;
     const bool safe = !alive || (lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
@@ -293,7 +300,7 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
             const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
             for (int i = 0; i < SS; ++i) {
                 cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
-                if (OUT) orow[i] = make_float2(p.x, p.y);
+                if (OUT) clock_put(orow[i], p);
             }
             s.ii = (long long)origin + off;
             produced += SS;
@@ -303,7 +310,7 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
             if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
             if (alive) {
                 cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
-                if (OUT) orow[i] = make_float2(p.x, p.y);
+                if (OUT) clock_put(orow[i], p);
                 ++produced;
             }
         }
@@ -412,7 +419,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
     const int nsub = (NS + SS - 1) / SS;
     clock_pipeline<NV, WP, (NCM + NV - 1) / NV>(t, x, N, WS, nsub, STEP, [&](int j, int cum) {
         clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                 produced, nullptr);
+                                 produced, (float *)nullptr);
     });
     if (NV > 1) {
         // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__res
 // CLK_OT symbols per chain and written out row-wise (4 lanes x 16 B per chain row).
 constexpr int CLK_OT = 16;
 
-template <int WP, int NCM>
+template <int WP, int NCM, bool SYM>
 __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
@@ -453,7 +460,9 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                                                           int STEP)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float2 otile[64][CLK_OT + 1];
+    // soft output only (SYM false): the tile holds real parts -- half the LDS, one more block per CU
+    typedef typename std::conditional<SYM, float2, float>::type OutT;
+    __shared__ OutT otile[64][CLK_OT + 1];
     __shared__ int made[64];
     const ClockTile t = clock_tile_carve(smem);
     clock_table_to_lds<64>(t.table, table_g);
@@ -488,11 +497,12 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
             const int have = made[c];
             const unsigned long long o = (unsigned long long)(kbase + c) * NS + i0 + q0;
             if (kbase + c < K && q0 < have && q0 < olim) {
-                float2 v0 = otile[c][q0], v1 = otile[c][q0 + 1], v2 = otile[c][q0 + 2], v3 = otile[c][q0 + 3];
+                const float2 v0 = clock_get(otile[c][q0]), v1 = clock_get(otile[c][q0 + 1]),
+                             v2 = clock_get(otile[c][q0 + 2]), v3 = clock_get(otile[c][q0 + 3]);
                 const int nv = min(min(have, olim) - q0, 4);
                 if (nv == 4 && o + 3 < cap && (NS & 3) == 0) {
                     if (soft) *reinterpret_cast<float4 *>(soft + o) = make_float4(v0.x, v1.x, v2.x, v3.x);
-                    if (sym) {
+                    if (SYM && sym) {
                         *reinterpret_cast<float4 *>(sym + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
                         *reinterpret_cast<float4 *>(sym + o + 2) = make_float4(v2.x, v2.y, v3.x, v3.y);
                     }
@@ -500,7 +510,7 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
 #define XR_PUT(Q, V)                                   \
     if (Q < nv && o + Q < cap) {                       \
         if (soft) soft[o + Q] = V.x;                   \
-        if (sym) sym[o + Q] = V;                       \
+        if (SYM && sym) sym[o + Q] = V;                \
     }
                     XR_PUT(0, v0) XR_PUT(1, v1) XR_PUT(2, v2) XR_PUT(3, v3)
 #undef XR_PUT
@@ -769,14 +779,20 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
     {
         ProfScope ps(prof, "clock_output", s);
         hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
-#define XR_CLK_OUT(WPV, NCM)                                                                                          \
-    hipLaunchKernelGGL((clock_output_kernel<WPV, NCM>), dim3(gridK), dim3(64), j.tile_bytes, s, x, table.as<float>(), \
-                       S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym, (unsigned long long)j.cap,   \
-                       j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP)
+#define XR_CLK_OUT_S(WPV, NCM, SYMV)                                                                                  \
+    hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(gridK), dim3(64), j.tile_bytes, s, x,              \
+                       table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym,            \
+                       (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP)
+#define XR_CLK_OUT(WPV, NCM)                              \
+    do {                                                  \
+        if (j.sym) XR_CLK_OUT_S(WPV, NCM, true);          \
+        else XR_CLK_OUT_S(WPV, NCM, false);               \
+    } while (0)
         const bool narrow = (j.STEP >> 16) + 1 <= 20;
         if (!j.wide && narrow) XR_CLK_OUT(32, 20);
         else if (!j.wide) XR_CLK_OUT(32, 32);
         else XR_CLK_OUT(64, 64);
+#undef XR_CLK_OUT_S
 #undef XR_CLK_OUT
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
                            st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
