@@ -360,7 +360,8 @@ def test_full_size_burst_properties(xa):
     assert st.costas_unconverged == 0
 
 
-def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_path):
+@pytest.mark.parametrize("fmt", ["cf32", "s16", "s8"])
+def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_path, fmt):
     """xrit_demod_host = the reference's plumbing around the library (CFileFrontend -> processSamples ->
     SymbolManager): a cf32 capture file goes through the chain block by block and arrives at a listening
     'decoder' socket as int8 soft symbols (x127, clamp, truncation; pieces of <= 16384 bytes)."""
@@ -370,9 +371,17 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
     host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
     assert os.path.exists(host_bin)
     n, block = 1500000, 400000
-    x = synth_signal(n)
-    f = tmp_path / "capture.cf32"
-    x.tofile(f)
+    x = synth_signal(n, amplitude=0.1 if fmt == "cf32" else 0.3)
+    f = tmp_path / ("capture." + fmt)
+    # raw captures as the frontends deliver them (FrontendDevice.h:11-13): cf32, or interleaved int16 / int8 IQ
+    typ = {"cf32": 0, "s16": 1, "s8": 2}[fmt]
+    if fmt == "s16":
+        raw = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    elif fmt == "s8":
+        raw = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
+    else:
+        raw = x
+    raw.tofile(f)
     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     srv.bind(("127.0.0.1", 0))
     srv.listen(1)
@@ -390,13 +399,15 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
 
     th = threading.Thread(target=serve)
     th.start()
-    r = subprocess.run([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
-                        "--sink", f"tcp://127.0.0.1:{port}", "--stats"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([host_bin, "--input", str(f), "--format", fmt, "--mode", "lrit", "--sample-rate", "1250000",
+                        "--block", str(block), "--sink", f"tcp://127.0.0.1:{port}", "--stats"], capture_output=True,
+                       text=True, timeout=120)
     th.join(timeout=30)
     srv.close()
     assert r.returncode == 0, r.stderr
     od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
-    want = np.concatenate([od.process(x[i:i + block]) for i in range(0, n, block)])
+    per = 1 if fmt == "cf32" else 2
+    want = np.concatenate([od.process(raw[per * i:per * (i + block)], typ) for i in range(0, n, block)])
     wq = oracle_mod.quantize_i8(want)
     gq = np.frombuffer(bytes(got), np.int8)
     assert len(gq) == len(wq)
