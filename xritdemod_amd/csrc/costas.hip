@@ -100,13 +100,13 @@ __global__ void costas_guess_kernel(const double *__restrict__ th2, float2 *__re
 // Chain-level model of the loop over the first chains of the call, where the
 // true trajectory may still be acquiring: averaged detector = Im(e^{-2j phi} c_k)/2.
 __global__ void costas_head_kernel(const float2 *__restrict__ stat, float2 *__restrict__ S,
-                                   const float2 *__restrict__ state, int K, int L, CostasGains g)
+                                   const float2 *__restrict__ state, int K, int L, CostasGains g, int head)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float2 s0 = state[0];
     S[0] = s0;
     double phi = s0.x, fr = s0.y;
-    int H = min(COSTAS_HEAD, K - 1);
+    int H = min(head, K - 1);
     for (int k = 0; k < H; ++k) {
         double pm = phi + fr * L * 0.5;
         double sn, cs;
@@ -458,6 +458,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
 int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof,
                        const float2 *stat_ext, double2 *om, long long om_off, double inv_sps)
 {
+    const bool locked = passes > 0 && passes <= 3 && unconverged == 0;      // how the previous call went
     passes = 0;
     unconverged = 0;
     max_residual = 0;
@@ -495,7 +496,10 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
             hipLaunchKernelGGL(scan_apply_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(costas_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, th2, S.as<float2>(), K, L);
-            hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains);
+            // the sequential head model (64 dependent steps, ~20 us) is for calls that start unlocked; a call that
+            // follows one which closed in the minimum number of passes starts on a tracking loop: plain guesses do
+            hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
+                               locked ? 0 : COSTAS_HEAD);
             hipLaunchKernelGGL(fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, flags.as<int>(), 1, K);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
