@@ -119,12 +119,13 @@ __device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double
 __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, double sps, ClockState *__restrict__ S,
                                    const ClockState *__restrict__ carried, int K, int NS, float omega0,
                                    const float2 *__restrict__ x, const float *__restrict__ table, long long ni,
-                                   double off, int BL)
+                                   double off, int BL, int *__restrict__ dirty, int *__restrict__ ctl)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    dirty[k] = 1;                       // every chain runs in the first pass
     ClockState s0 = carried[0];
-    if (k == 0) { S[0] = s0; return; }
+    if (k == 0) { S[0] = s0; ctl[5] = 1; return; }     // first solve: gated
     double t0 = (double)s0.ii + (double)s0.mu;
     // the M&M read position t = ii+mu sits 3 samples before the interpolation instant
     double ca = clk_count_at(cnt, nb, sps, t0, off, BL) + 3.0 / sps;
@@ -881,7 +882,6 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
-    hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, clock_ctl(counters) + 5, 1, 1);   // first solve: gated
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
@@ -895,8 +895,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
             hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
-                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL);
-            hipLaunchKernelGGL(clk_fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, j.dirty, 1, K);
+                               S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL, j.dirty,
+                               clock_ctl(counters));
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {

@@ -86,10 +86,13 @@ struct UnwrapF {
     }
 };
 
-__global__ void costas_guess_kernel(const double *__restrict__ th2, float2 *__restrict__ S, int K, int L)
+__global__ void costas_guess_kernel(const double *__restrict__ th2, float2 *__restrict__ S, int K, int L,
+                                    int *__restrict__ dirty, int *__restrict__ ctl)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K || k == 0) return;
+    if (k >= K) return;
+    dirty[k] = 1;                       // every chain runs in the first pass
+    if (k == 0) { ctl[5] = 1; return; } // first solve: gated (chain 0 starts from the carried state)
     // boundary k lies between chain centres k-1 and k
     double thb = 0.25 * (th2[k - 1] + th2[k]);
     int a = max(0, k - 2), b = min(K - 1, k + 1);
@@ -365,12 +368,6 @@ __global__ void __launch_bounds__(256) costas_verify_kernel(CostasPolicy p, long
     }
 }
 
-__global__ void fill_int_kernel(int *p, int v, int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 {
     gains = costas_gains(loop_bw);
@@ -479,7 +476,6 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 2) * 8 * sizeof(unsigned), s));
-    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(1), 0, s, costas_ctl(counters) + 5, 1, 1);   // first solve: gated
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
@@ -495,12 +491,12 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
             hipLaunchKernelGGL(scan_aggs_kernel<UnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbK);
             hipLaunchKernelGGL(scan_apply_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
-            hipLaunchKernelGGL(costas_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, th2, S.as<float2>(), K, L);
+            hipLaunchKernelGGL(costas_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, th2, S.as<float2>(), K, L,
+                               flags.as<int>(), costas_ctl(counters));
             // the sequential head model (64 dependent steps, ~20 us) is for calls that start unlocked; a call that
             // follows one which closed in the minimum number of passes starts on a tracking loop: plain guesses do
             hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
                                locked ? 0 : COSTAS_HEAD);
-            hipLaunchKernelGGL(fill_int_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, flags.as<int>(), 1, K);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {
