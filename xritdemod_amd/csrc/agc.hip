@@ -109,7 +109,6 @@ void AgcStage::release()
 {
     state.release();
     aggs.release();
-    starts.release();
 }
 
 int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)

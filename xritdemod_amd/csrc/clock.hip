@@ -13,8 +13,8 @@
 // lanes that run the chain from (t+h_t, omega) and (t, omega+h_w).  A residual of
 // m whole symbols at a boundary is carried as a symbol slip that shifts all later
 // chains, not "corrected".  The arm quantisation makes the recurrence chaotic at
-// the 1e-5 level in mu, so the passes stop at a fixed
-// budget rather than at bitwise closure.
+// the 1e-5 level in mu, so the passes stop when the residuals
+// stop falling (device-side test in ClockPolicy::decide) rather than at bitwise closure.
 #include "kernels.h"
 
 #include <cstdlib>

@@ -55,7 +55,6 @@ struct AgcStage {
     float rate = 0, ref = 0, maxg = 0;
     DevBuf state;    // two (gain, guard flag) slots, ping-pong across calls
     DevBuf aggs;     // per-block composed maps
-    DevBuf starts;
     int cur = 0;
     int init(float rate, float reference, float gain, float max_gain);
     void release();
