@@ -259,8 +259,9 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     // ... and when nobody asks for the AGC output itself, the matched filter applies the gains while it fills its
     // window: the AGC then costs the stream no sweep of its own at all
     const bool agc_in_rrc = agc_fused && !d->keep_stages && d->rrc.agc_fill_supported(d->dec.RC);
-    // no decimator (C1, C3): the run maps come from one read-only sweep, the rest is the same
-    const bool agc_in_rrc_d1 = D == 1 && length > 0 && !d->keep_stages && d->rrc.agc_fill_supported(3);
+    // no decimator (C1, C3), or one whose kernel has no such epilogue (the polyphase one, C5): the run maps come
+    // from one read-only sweep, the rest is the same
+    const bool agc_in_rrc_d1 = !agc_fused && length > 0 && !d->keep_stages && d->rrc.agc_fill_supported(3);
     AgcFill fill{};
     float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
     if (agc_in_rrc || agc_in_rrc_d1) {
