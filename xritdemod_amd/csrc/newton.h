@@ -71,13 +71,14 @@ __device__ __forceinline__ AffMap aff_combine(const AffMap &lo, const AffMap &hi
     return r;
 }
 
-// inclusive scan over the block; returns this thread's inclusive value, buf[] holds all of them
+// inclusive scan over the block of NB threads; returns this thread's inclusive value, buf[] holds all of them
+template <int NB = NEWTON_BLOCK>
 __device__ __forceinline__ AffMap aff_block_scan(AffMap v, AffMap *buf)
 {
     const int t = threadIdx.x;
     buf[t] = v;
     __syncthreads();
-    for (int off = 1; off < NEWTON_BLOCK; off <<= 1) {
+    for (int off = 1; off < NB; off <<= 1) {
         AffMap lo = aff_identity();
         const bool has = t >= off;
         if (has) lo = buf[t - off];
@@ -263,6 +264,91 @@ __device__ __forceinline__ unsigned newton_cnt_load(const unsigned *c)
     return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- small calls: the whole solve in ONE workgroup, one launch.  The reference hands the chain 32 Ki - 512 Ki
+// samples per call (demodulator.cpp:113): a few thousand chain boundaries, for which the three launches above are
+// three times a kernel's fixed cost with one or two blocks each.  Same phases, same arithmetic, same order of
+// composition inside a thread's run; the block prefixes that the look-back provides there are simply absent.
+constexpr int NEWTON_SMALL_BLOCK = 1024;
+constexpr int NEWTON_SMALL_MAX = NEWTON_SMALL_BLOCK * NEWTON_IPT;
+
+template <typename P>
+__global__ void __launch_bounds__(NEWTON_SMALL_BLOCK) newton_small_kernel(P p, long long n, int *ctl)
+{
+    if (ctl[0]) return;
+    __shared__ AffMap buf[NEWTON_SMALL_BLOCK];
+    __shared__ NewtonStat wst[NEWTON_SMALL_BLOCK / 64];
+    const long long i0 = (long long)threadIdx.x * NEWTON_IPT;
+    const bool gated = ctl[5] != 0;
+    typename P::Elem el[NEWTON_IPT];
+    newton_fetch(p, i0, n, el);
+    AffMap e[NEWTON_IPT];
+    AffMap v = aff_identity();
+#pragma unroll
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        e[q] = (i0 + q < n) ? newton_element(p, el[q], false) : aff_identity();
+        v = aff_combine(v, e[q]);
+    }
+    aff_block_scan<NEWTON_SMALL_BLOCK>(v, buf);
+    AffMap pre = threadIdx.x > 0 ? buf[threadIdx.x - 1] : aff_identity();
+    __syncthreads();
+    if (gated) {
+        // delta_lin at the start of this thread's run is the offset of the un-gated prefix (delta[0] = 0)
+        float d1 = pre.b1, d2 = pre.b2;
+        AffMap g = aff_identity();
+#pragma unroll
+        for (int q = 0; q < NEWTON_IPT; ++q) {
+            if (i0 + q < n) {
+                const bool cut = p.outside_trust(d1, d2);
+                const float n1 = e[q].a11 * d1 + e[q].a12 * d2 + e[q].b1;
+                const float n2 = e[q].a21 * d1 + e[q].a22 * d2 + e[q].b2;
+                d1 = n1; d2 = n2;
+                if (cut) { e[q].a11 = e[q].a12 = e[q].a21 = e[q].a22 = 0.f; }
+                g = aff_combine(g, e[q]);
+            }
+        }
+        aff_block_scan<NEWTON_SMALL_BLOCK>(g, buf);
+        pre = threadIdx.x > 0 ? buf[threadIdx.x - 1] : aff_identity();
+        __syncthreads();
+    }
+    float d1 = pre.b1, d2 = pre.b2;
+    int aux = pre.aux;
+    NewtonStat st{0u, 0u, 0u, 0.f, 0ull};
+#pragma unroll
+    for (int q = 0; q < NEWTON_IPT; ++q) {
+        const long long k = i0 + q;
+        if (k >= n) break;
+        float j1 = e[q].a11 * d1 + e[q].a12 * d2;
+        float j2 = e[q].a21 * d1 + e[q].a22 * d2;
+        float n1 = e[q].b1 + j1, n2 = e[q].b2 + j2;
+        p.update(k, el[q], j1, j2, n1, n2, aux, e[q].aux, e[q].b1, st);
+        d1 = n1; d2 = n2;
+        aux += e[q].aux;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        st.changed += __shfl_down(st.changed, off, 64);
+        st.open_ += __shfl_down(st.open_, off, 64);
+        st.large += __shfl_down(st.large, off, 64);
+        st.max_r = fmaxf(st.max_r, __shfl_down(st.max_r, off, 64));
+        st.sum_sq += (unsigned long long)__shfl_down((long long)st.sum_sq, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) wst[threadIdx.x >> 6] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        NewtonStat t = wst[0];
+        for (int w = 1; w < NEWTON_SMALL_BLOCK / 64; ++w) {
+            t.changed += wst[w].changed; t.open_ += wst[w].open_; t.large += wst[w].large;
+            t.max_r = fmaxf(t.max_r, wst[w].max_r); t.sum_sq += wst[w].sum_sq;
+        }
+        p.cnt[0] = t.changed;
+        p.cnt[1] = t.open_;
+        p.cnt[2] = t.open_ ? __float_as_uint(t.max_r) : 0u;
+        p.cnt[3] = t.large;
+        *reinterpret_cast<unsigned long long *>(&p.cnt[4]) = t.open_ ? t.sum_sq : 0ull;
+        __threadfence();
+        p.decide(ctl);
+    }
+}
+
 static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
 
 // agg storage: 2 * (blocks + 1) AffMaps; dlin: n + 1 float2
@@ -270,6 +356,10 @@ template <typename P>
 static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dlin, int *ctl, hipStream_t s)
 {
     if (n <= 0) return 0;
+    if (n <= NEWTON_SMALL_MAX) {
+        hipLaunchKernelGGL(newton_small_kernel<P>, dim3(1), dim3(NEWTON_SMALL_BLOCK), 0, s, p, n, ctl);
+        return 0;
+    }
     const int nb = newton_blocks(n);
     if (nb > NEWTON_MAX_BLOCKS) return -1;
     AffMap *agg0 = aggs, *agg1 = aggs + nb + 1;
