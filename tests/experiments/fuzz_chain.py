@@ -11,6 +11,7 @@ from xritdemod_amd import synth
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+only = set(int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v)
 for c in range(cases):
     mode = "lrit" if rng.random() < 0.7 else "hrit"
     D = int(rng.choice([1, 1, 2, 3, 5, 5, 8, 16, 32]))
@@ -20,7 +21,13 @@ for c in range(cases):
     typ = int(rng.choice([0, 0, 0, 1, 2]))
     sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
     amp = 0.1 if typ == 0 else 0.3
-    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=int(rng.integers(1, 1 << 30))), n)
+    seed = int(rng.integers(1, 1 << 30))
+    ncut = int(rng.integers(0, 4))
+    cutv = [int(v) for v in rng.integers(0, n + 1, ncut)]
+    keep = rng.random() < 0.3
+    if only and c not in only:
+        continue
+    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=seed), n)
     if typ == 1:
         xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
     elif typ == 2:
@@ -28,9 +35,7 @@ for c in range(cases):
     else:
         xi = x
     per = 1 if typ == 0 else 2
-    ncut = int(rng.integers(0, 4))
-    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, ncut)]))
-    keep = rng.random() < 0.3
+    cuts = sorted(set([0, n] + cutv))
     od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D))
     gd.keep_stages(keep)
     want, got = [], []
@@ -43,6 +48,9 @@ for c in range(cases):
             ok = False
     w, g = np.concatenate(want), np.concatenate(got)
     msg = ""
+    if os.environ.get("FUZZ_DUMP") and only:
+        np.save(f"/tmp/fuzz_case{c}.npy", xi)
+        print("   seed", seed, "stats", gd.stats().costas_passes, gd.stats().clock_passes, gd.stats().costas_unconverged, gd.stats().clock_unconverged, gd.stats().agc_serial_fallback)
     if ok and len(w):
         big = np.abs(w) > 1e-3
         sgn = int(np.sum(np.sign(w[big]) != np.sign(g[big])))

@@ -609,3 +609,20 @@ def test_sync_correlator_bit_exact(xa, oracle_mod):
     s8 = q.quantize_i8(q.process(x))
     assert np.array_equal(xa.sync_correlate(s8), o.sync_correlate(s8))
     assert len(xa.sync_correlate(d[:100])) == 0
+
+
+@pytest.mark.parametrize("D,n,seed", [(5, 53434, 955084003), (16, 247568, 15839011), (8, 98774, 864741509)])
+def test_cold_started_short_calls_close(xa, oracle_mod, D, n, seed):
+    """Found by tests/experiments/fuzz_chain.py: short cold-started s16 captures on which the Costas hand-off did
+    not close in 32 passes -- a Newton step through the loop's unstable equilibrium (a quarter turn from lock) left
+    boundaries swapping sides with 1.5 rad residuals, and hard-decision errors in the output.  Boundaries whose own
+    residual is that large now get the plain hand-off (CostasPolicy::distrust)."""
+    fs = 1.25e6 * D
+    x = synth.generate(synth.SynthParams(fs_in=fs, amplitude=0.3, seed=seed), n)
+    xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    want = oracle_mod.Demod(oracle_mod.config("lrit", fs, D)).process(xi, 1)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    got = dem.process(xi, 1)
+    st = dem.stats()
+    assert st.costas_unconverged == 0 and st.costas_passes < 16
+    check_symbols(got, want)

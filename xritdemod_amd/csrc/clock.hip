@@ -608,6 +608,9 @@ struct ClockPolicy {
     {
         return !(fabsf(d1) <= trust_t) || !(fabsf(d2) <= trust_w);
     }
+    // same idea as the Costas policy: a timing residual of a good part of a sample is an acquisition or slip
+    // transient, not something the finite-difference Jacobian describes
+    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.5f); }
     __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int slip, int slip_k,
                            float r1, NewtonStat &st) const
     {

@@ -301,6 +301,12 @@ struct CostasPolicy {
     {
         return !(fabsf(d1) <= trust_p) || !(fabsf(d2) <= trust_f);
     }
+    // The loop's lock points are pi apart with an unstable equilibrium half way.  A residual beyond ~pi/8 means the
+    // next chain was started nearer to that than the tangent is good for (there it is expansive, and a Newton
+    // step through it lands on either side: boundaries then swap sides for ever -- seen on cold-started short
+    // calls, 1.5 rad residuals after 32 passes).  Such a boundary gets the plain hand-off; the correction that
+    // reaches it from upstream is dropped, and the region closes chain by chain.
+    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.4f); }
     __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int aux_prefix,
                            int aux_k, float r1, NewtonStat &st) const
     {

@@ -24,6 +24,9 @@
 //   void   P::residual(el, float& r1, float& r2, int& aux)
 //   float4 P::jac(el)                     (a11, a12, a21, a22)
 //   bool   P::outside_trust(d1, d2)
+//   bool   P::distrust(r1, r2)            this boundary's own residual is outside the range in which the chain's
+//                                         linearisation means anything (Costas: closer to the unstable
+//                                         equilibrium a quarter turn away than to the lock point): plain hand-off
 //   void   P::update(k, el, jd1, jd2, nd1, nd2, aux_prefix, aux_k, r1, NewtonStat&)   apply to S[k+1]
 //   unsigned* P::cnt                      this pass's counter slot
 //   void   P::decide(int* ctl)            stop test from the pass's counters; run by one thread of the block
@@ -118,7 +121,7 @@ __device__ __forceinline__ AffMap newton_element(const P &p, const typename P::E
     float r1, r2;
     int aux;
     p.residual(el, r1, r2, aux);
-    if (cut) { m.a11 = m.a12 = m.a21 = m.a22 = 0.f; }
+    if (cut || p.distrust(r1, r2)) { m.a11 = m.a12 = m.a21 = m.a22 = 0.f; }
     else {
         float4 j = p.jac(el);
         m.a11 = j.x; m.a12 = j.y; m.a21 = j.z; m.a22 = j.w;
