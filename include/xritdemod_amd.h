@@ -81,7 +81,9 @@ typedef struct xrit_demod_config {
     /* time-slice tiling of the feedback loops (0 = library default) */
     int32_t  costas_chain_len;  /* samples per Costas chain */
     int32_t  clock_chain_syms;  /* symbols per clock-recovery chain */
-    int32_t  max_passes;        /* hand-off passes before giving up (per loop) */
+    int32_t  max_passes;        /* hand-off passes before giving up (per loop); 0 = 192: a locked signal needs 2 + 5,
+                                 * a cold start within the loops' lock-in range ~15, a pull-in with cycle slips
+                                 * a pass or two per chain of the slipping stretch */
     int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED instead of accepting the residual */
     int32_t  clock_min_passes;  /* clock hand-off passes always run (0 = default); max_passes caps both loops */
     int32_t  slices;            /* > 1: cut a large call into that many time slices so that the front end of one

@@ -22,12 +22,16 @@ for c in range(cases):
     sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
     amp = 0.1 if typ == 0 else 0.3
     seed = int(rng.integers(1, 1 << 30))
+    wide = os.environ.get("FUZZ_WIDE")
+    extra = dict(esn0_db=float(rng.uniform(8, 20)), carrier_hz=float(rng.uniform(-1200, 1200)),
+                 clock_ppm=float(rng.uniform(-100, 100)), timing_offset=float(rng.uniform(0, 1)),
+                 phase0=float(rng.uniform(-3.1, 3.1))) if wide else {}
     ncut = int(rng.integers(0, 4))
     cutv = [int(v) for v in rng.integers(0, n + 1, ncut)]
     keep = rng.random() < 0.3
     if only and c not in only:
         continue
-    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=seed), n)
+    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=seed, **extra), n)
     if typ == 1:
         xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
     elif typ == 2:
@@ -36,7 +40,7 @@ for c in range(cases):
         xi = x
     per = 1 if typ == 0 else 2
     cuts = sorted(set([0, n] + cutv))
-    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D))
+    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0"))))
     gd.keep_stages(keep)
     want, got = [], []
     ok = True
@@ -58,7 +62,8 @@ for c in range(cases):
         if sgn or r > 6e-4:
             ok = False
         msg = f"rms {r:.2e} sign {sgn}"
-    print(("ok  " if ok else "FAIL"), c, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg, flush=True)
+    print(("ok  " if ok else "FAIL"), c, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg,
+          {k: round(v, 2) for k, v in extra.items()}, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged, flush=True)
     bad += 0 if ok else 1
 print("failures:", bad)
 sys.exit(1 if bad else 0)

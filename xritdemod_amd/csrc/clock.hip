@@ -679,7 +679,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     mu0 = mu;
     NS = chain_syms > 0 ? chain_syms : 64;
     auto_ns = chain_syms <= 0;
-    max_passes = max_passes_ > 0 ? max_passes_ : 48;
+    max_passes = max_passes_ > 0 ? max_passes_ : 192;      // see CostasStage::init
     min_passes = max_passes < 4 ? max_passes : 4;
     std::vector<float> tb((XR_MM_NSTEPS + 1) * XR_MM_NTAPS);
     design_mmse_table(tb.data());

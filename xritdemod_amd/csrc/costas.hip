@@ -379,7 +379,9 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;
     L = (L + COSTAS_CT - 1) / COSTAS_CT * COSTAS_CT;   // whole LDS tiles per chain
-    max_passes = max_passes_ > 0 ? max_passes_ : 32;
+    // a cold start far outside the lock-in range pulls in over many chains with cycle slips, and such a region closes
+    // at a chain or two per pass: 32 passes left hard-decision errors on captures with > 1 kHz offset (fuzz), 192 do not
+    max_passes = max_passes_ > 0 ? max_passes_ : 192;
     XR_TRY(state.reserve(2 * sizeof(float2)));
     XR_HIP(hipMemset(state.p, 0, 2 * sizeof(float2)));
     XR_TRY(counters.reserve((size_t)(max_passes + 4) * 8 * sizeof(unsigned)));
