@@ -43,7 +43,11 @@ for c in range(cases):
         xi = x
     per = 1 if typ == 0 else 2
     cuts = sorted(set([0, n] + cutv))
-    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0"))))
+    knobs = {}
+    if os.environ.get("FUZZ_CFG"):
+        knobs = dict(costas_chain_len=int(rng.choice([0, 64, 128, 256, 320, 512])), clock_chain_syms=int(rng.choice([0, 16, 24, 64, 100, 256])),
+                     slices=int(rng.choice([0, 1, 2, 3])))
+    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), **knobs))
     gd.keep_stages(keep)
     want, got = [], []
     ok = True
@@ -66,7 +70,7 @@ for c in range(cases):
             ok = False
         msg = f"rms {r:.2e} sign {sgn}"
     print(("ok  " if ok else "FAIL"), c, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg,
-          {k: round(v, 2) for k, v in extra.items()}, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged, flush=True)
+          {k: round(v, 2) for k, v in extra.items()}, knobs, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged, flush=True)
     bad += 0 if ok else 1
 print("failures:", bad)
 sys.exit(1 if bad else 0)
