@@ -693,6 +693,13 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     XR_TRY(tail.reserve(2 * 1024 * sizeof(float2)));
     XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_res, 128));
+    {
+        int dev = 0, v = 0;
+        XR_HIP(hipGetDevice(&dev));
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu_count = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v >= 65536)
+            lds_per_cu = v;
+    }
     cur = 0;
     carry = 0;
     return XRIT_OK;
@@ -839,12 +846,41 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     }
     // chain budget: the slowest admissible symbol clock plus slack
     const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
+    // sample rings (see ClockTile).  Over SS symbols the read index advances by A at most; a ring of R samples
+    // must hold CLK_M below the schedule, CLK_SLACK above it, the advance and the 8 interpolator taps.  SS
+    // divides the output tile (16 symbols).
+    const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
+    static const int tries[6][2] = {{32, 4}, {32, 2}, {32, 1}, {64, 4}, {64, 2}, {64, 1}};
+    int SS = 1, A = 0, R = 64;
+    for (int q = 0; q < 6; ++q) {
+        R = tries[q][0];
+        SS = tries[q][1];
+        A = (int)ceil(SS * max_adv) + 1;
+        if (CLK_M + CLK_SLACK + A + XR_MM_NTAPS <= R) break;    // else: very large sps, sub-steps run from global memory
+    }
+    j.wide = R > 32;
+    j.SS = SS; j.W = R; j.A = A;
+    j.STEP = (int)floor((double)SS * (double)par.omega_mid * 65536.0);
+    j.WS = R + 1;
+    j.tile_bytes = clock_tile_bytes(j.WS);
     if (auto_ns) {
-        // 64 symbols per chain fill the chip at C2 (197 k chains = 3 waves per SIMD); calls with several times as many
-        // symbols (no decimator in front) take longer chains instead of more of them: the hand-off solves cost per
-        // chain (C3: 1.5 ms of 12.2 at 64, 0.44 at 256; beyond 256 the passes lose more than the solves gain)
+        // One wave = 64 chains, and a wave's time is its chain length times a serial per-symbol latency: a pass
+        // costs (generations of resident waves) x NS.  So the chain length is chosen from what the chip holds --
+        // LDS decides: CUs x floor(LDS / ring tile) waves -- such that the call's waves fill a whole number g of
+        // generations: NS = symbols / (g x resident chains), with the smallest g that keeps NS <= 256 (longer
+        // chains lose more in the passes than their fewer hand-offs gain).  C2: 1792 resident waves, g = 1,
+        // NS = 112 (the former 64 gave 1.66 generations = 2 x 64 symbol times per pass, and 190 k hand-offs
+        // instead of 113 k).  Small calls keep 64.
+        const long long tile = ((long long)j.tile_bytes + 1279) / 1280 * 1280;
+        const long long resident = (long long)cu_count * (lds_per_cu / tile > 0 ? lds_per_cu / tile : 1);   // waves
+        const double symbols = (double)j.N / min_omega;
         NS = 64;
-        while (NS < 256 && (double)j.N / (min_omega * NS) > 262144.0) NS *= 2;
+        for (int g = 1; g <= 64; ++g) {
+            const double chains = (double)(g * resident * 64 - 4);          // K = symbols / NS + 3 must fit
+            int ns = (int)ceil(symbols / chains);
+            ns = (ns + 15) & ~15;                                            // whole output tiles, 64-byte rows
+            if (ns <= 256) { NS = ns < 64 ? 64 : ns; break; }
+        }
     }
     const int K = (int)((double)j.N / (min_omega * NS)) + 3;
     j.K = K;
@@ -866,23 +902,6 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.terminal = flags.as<int>() + 3 * K;
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
-    // sample rings (see ClockTile).  Over SS symbols the read index advances by A at most; a ring of R samples
-    // must hold CLK_M below the schedule, CLK_SLACK above it, the advance and the 8 interpolator taps.  SS
-    // divides the output tile (16 symbols).
-    const double max_adv = (double)par.omega_mid + (double)par.omega_lim + 0.004;
-    static const int tries[6][2] = {{32, 4}, {32, 2}, {32, 1}, {64, 4}, {64, 2}, {64, 1}};
-    int SS = 1, A = 0, R = 64;
-    for (int q = 0; q < 6; ++q) {
-        R = tries[q][0];
-        SS = tries[q][1];
-        A = (int)ceil(SS * max_adv) + 1;
-        if (CLK_M + CLK_SLACK + A + XR_MM_NTAPS <= R) break;    // else: very large sps, sub-steps run from global memory
-    }
-    j.wide = R > 32;
-    j.SS = SS; j.W = R; j.A = A;
-    j.STEP = (int)floor((double)SS * (double)par.omega_mid * 65536.0);
-    j.WS = R + 1;
-    j.tile_bytes = clock_tile_bytes(j.WS);
     const ClockState *st_in = st.as<ClockState>() + cur;
     XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
     if (K > 1) {

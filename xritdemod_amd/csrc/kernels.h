@@ -112,7 +112,9 @@ struct CostasStage {
 struct ClockStage {
     ClockPar par{};
     float sps = 0, mu0 = 0.5f;
-    int NS = 64;            // symbols per chain (auto_ns: 64, 128 or 256, chosen per call from its size)
+    int NS = 64;            // symbols per chain (auto_ns: chosen per call so that its waves fill whole generations)
+    int cu_count = 256;     // what the chip holds at once decides the chain length, see ClockStage::begin
+    long long lds_per_cu = 160 * 1024;
     bool auto_ns = true;
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
