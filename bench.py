@@ -287,7 +287,7 @@ def main():
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
                    "segments": world, "costas_chain_len": args.costas_chain or 256,
-                   "clock_chain_syms": args.clock_chain or "auto: 64 at C2, up to 256 for calls with more symbols"},
+                   "clock_chain_syms": args.clock_chain or "auto: whole generations of resident waves (112 at C2), 64..256"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
         "algorithmic_bytes_per_sample": round(b_alg, 4),
         "loop_passes": {"costas": st.costas_passes, "clock": st.clock_passes,
