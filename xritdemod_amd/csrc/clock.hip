@@ -299,9 +299,19 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
     if (__all(safe)) {
         if (alive) {
             const cf32 *rowp = reinterpret_cast<const cf32 *>(t.tile + lane * WS);
-            for (int i = 0; i < SS; ++i) {
-                cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
-                if (OUT) clock_put(orow[i], p);
+            if (SS == 4) {
+                // the usual sub-step, unrolled: the symbol-to-symbol hand-over of (p0, p1, c0, c1) becomes
+                // register renaming instead of a dozen moves per symbol
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
+                    if (OUT) clock_put(orow[i], p);
+                }
+            } else {
+                for (int i = 0; i < SS; ++i) {
+                    cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
+                    if (OUT) clock_put(orow[i], p);
+                }
             }
             s.ii = (long long)origin + off;
             produced += SS;

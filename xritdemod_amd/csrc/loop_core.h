@@ -178,6 +178,36 @@ struct ClockState {
     cf32 c0, c1;   // their 0/1 slicer decisions
 };
 
+// The 8-tap interpolation, acc += tap * sample with separately rounded multiply and add (the build has
+// -ffp-contract=off, like the CPU chain).  On the device the (re, im) pair is one 2-vector, i.e. v_pk_mul_f32 +
+// v_pk_add_f32 per tap; the loop kernels are compiled without SLP vectorisation, which otherwise pairs up
+// unrelated scalars of the M&M update and pays for it in register moves.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XR_MM_INTERPOLATE(ROW, W, AR, AI)                                        \
+    do {                                                                         \
+        typedef float __attribute__((ext_vector_type(2))) xr_f2_;                \
+        xr_f2_ a_ = {0.0f, 0.0f};                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < XR_MM_NTAPS; ++k_) {             \
+            const float tp_ = (float)(ROW)[XR_MM_NTAPS - 1 - k_];                \
+            const cf32 v_ = (W)[k_];                                             \
+            const xr_f2_ vv_ = {v_.x, v_.y};                                     \
+            a_ = a_ + vv_ * tp_;                                                 \
+        }                                                                        \
+        AR = a_.x;                                                               \
+        AI = a_.y;                                                               \
+    } while (0)
+#else
+#define XR_MM_INTERPOLATE(ROW, W, AR, AI)                                        \
+    do {                                                                         \
+        for (int k_ = 0; k_ < XR_MM_NTAPS; ++k_) {                               \
+            const float tp_ = (float)(ROW)[XR_MM_NTAPS - 1 - k_];                \
+            const cf32 v_ = (W)[k_];                                             \
+            AR += tp_ * v_.x;                                                    \
+            AI += tp_ * v_.y;                                                    \
+        }                                                                        \
+    } while (0)
+#endif
+
 // One symbol.  w points at the 8-sample window x[ii .. ii+7] (global memory or an
 // LDS copy of it), table at the 129x8 MMSE taps.
 template <typename TableT>
@@ -189,13 +219,7 @@ XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const
     if (arm_out) *arm_out = imu;
     const TableT *row = table + imu * XR_MM_NTAPS;
     float ar = 0.0f, ai = 0.0f;
-#pragma unroll
-    for (int k = 0; k < XR_MM_NTAPS; ++k) {
-        float tp = (float)row[XR_MM_NTAPS - 1 - k];
-        cf32 v = w[k];
-        ar += tp * v.x;
-        ai += tp * v.y;
-    }
+    XR_MM_INTERPOLATE(row, w, ar, ai);
     cf32 p0{ar, ai};
     cf32 c0{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
     float dcr = c0.x - c2.x, dci = c0.y - c2.y;
@@ -208,7 +232,7 @@ XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const
     omega = par.omega_mid + bclip(omega - par.omega_mid, par.omega_lim);
     float mu = s.mu + omega + par.gain_mu * mm;
     float fl = floorf(mu);
-    s.ii += (int64_t)fl;
+    s.ii += (int)fl;            // |mu + omega| is a few samples: the 32-bit conversion is exact and one instruction
     s.mu = mu - fl;
     s.omega = omega;
     s.p1 = p1; s.p0 = p0;
@@ -227,13 +251,7 @@ XR_HD cf32 clock_step_rel(const cf32 *row, int &off, const TableT *table, ClockS
     const TableT *trow = table + imu * XR_MM_NTAPS;
     const cf32 *w = row + off;
     float ar = 0.0f, ai = 0.0f;
-#pragma unroll
-    for (int k = 0; k < XR_MM_NTAPS; ++k) {
-        float tp = (float)trow[XR_MM_NTAPS - 1 - k];
-        cf32 v = w[k];
-        ar += tp * v.x;
-        ai += tp * v.y;
-    }
+    XR_MM_INTERPOLATE(trow, w, ar, ai);
     cf32 p0{ar, ai};
     cf32 c0{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
     float dcr = c0.x - c2.x, dci = c0.y - c2.y;
