@@ -611,6 +611,28 @@ def test_sync_correlator_bit_exact(xa, oracle_mod):
     assert len(xa.sync_correlate(d[:100])) == 0
 
 
+@pytest.mark.parametrize("fs,D,chunk", [(1.25e6, 1, 0), (6.25e6, 5, 0), (1.25e6, 1, 262144)])
+def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
+    """The external criterion: coded CCSDS-style frames -> IQ -> chain on the GPU ->
+    int8 -> the decoder's correlator (on the GPU) finds the sync marker in every frame, where and as strongly as
+    through the oracle chain.  Also fed in the reference's chunk size."""
+    from test_oracle_kat import _framed_burst, check_frame_lock
+    o = oracle_mod
+    x, sym = _framed_burst(16, fs=fs)
+    q = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    if chunk:
+        soft = np.concatenate([q.process(x[i:i + chunk]) for i in range(0, len(x), chunk)])
+    else:
+        soft = q.process(x)
+    s8 = q.quantize_i8(soft)
+    hits = xa.sync_correlate(s8)
+    word, pos, worst = check_frame_lock(hits)
+    assert worst >= 50
+    want = o.sync_correlate(o.quantize_i8(o.Demod(o.config("lrit", fs, D)).process(x)))
+    assert np.array_equal(np.asarray(hits)[3:, :2], want[3:, :2])
+    assert np.abs(np.asarray(hits)[3:, 2].astype(int) - want[3:, 2].astype(int)).max() <= 1
+
+
 @pytest.mark.parametrize("D,n,seed", [(5, 53434, 955084003), (16, 247568, 15839011), (8, 98774, 864741509)])
 def test_cold_started_short_calls_close(xa, oracle_mod, D, n, seed):
     """Found by tests/experiments/fuzz_chain.py: short cold-started s16 captures on which the Costas hand-off did

@@ -79,8 +79,9 @@ def rrc_pulse(t, alpha):
     return out
 
 
-def generate(p: SynthParams, n: int, start: int = 0, chunk: int = 1 << 18):
-    """cf32 samples [start, start+n) of the burst described by p."""
+def generate(p: SynthParams, n: int, start: int = 0, chunk: int = 1 << 18, symbols=None):
+    """cf32 samples [start, start+n) of the burst described by p.  symbols (optional): array of +1/-1 that
+    replaces the pseudo-random symbols k = 0 .. len-1 (a framed, coded bit stream, see ccsds_frames)."""
     out = np.empty(n, dtype=np.complex64)
     rate = p.symbol_rate * (1.0 + p.clock_ppm * 1e-6) / p.fs_in
     sigma = p.sigma
@@ -92,7 +93,11 @@ def generate(p: SynthParams, n: int, start: int = 0, chunk: int = 1 << 18):
         acc = np.zeros(c1 - c0, dtype=np.float64)
         for j in range(-SPAN + 1, SPAN + 1):
             k = k0 + j
-            acc += symbol_bits(p.seed, k) * rrc_pulse(u - k, p.alpha)
+            b = symbol_bits(p.seed, k)
+            if symbols is not None:
+                inside = (k >= 0) & (k < len(symbols))
+                b = np.where(inside, symbols[np.clip(k, 0, len(symbols) - 1)], b)
+            acc += b * rrc_pulse(u - k, p.alpha)
         ph = (2.0 * np.pi * p.carrier_hz / p.fs_in) * idx.astype(np.float64) + p.phase0
         sig = p.amplitude * acc * np.exp(1j * ph)
         if sigma > 0:
@@ -107,3 +112,35 @@ def generate(p: SynthParams, n: int, start: int = 0, chunk: int = 1 << 18):
 
 def transmitted_symbols(p: SynthParams, k0: int, n: int):
     return symbol_bits(p.seed, np.arange(k0, k0 + n, dtype=np.int64))
+
+
+# ---- a framed, convolutionally coded symbol stream (what the reference's decoder locks to) ---------------
+CCSDS_ASM = 0x1ACFFC1D          # attached sync marker of a 1024-byte CADU
+CODED_FRAME_SYMBOLS = 16384     # 8192 bits, rate 1/2 (decoder/src/parameters.h:28-31)
+
+
+def conv_encode_k7(bits):
+    """Rate-1/2, k=7 convolutional code, generators 0x4F / 0x6D on a register that takes the new bit at its low end,
+    G1 symbol first, start state 0.  With this convention the coded sync marker is the reference decoder's
+    LRIT_UW2 (newdecoder.cpp:24) and its complement LRIT_UW0 (the 180-degree lock)."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    padded = np.concatenate([np.zeros(6, np.uint8), bits])
+    n = len(bits)
+    out = np.zeros(2 * n, dtype=np.uint8)
+    for tap in range(7):                       # register bit `tap` holds the bit that arrived `tap` steps ago
+        d = padded[6 - tap:6 - tap + n]
+        if (0x4F >> tap) & 1:
+            out[0::2] ^= d
+        if (0x6D >> tap) & 1:
+            out[1::2] ^= d
+    return out
+
+
+def ccsds_frames(n_frames, seed=1):
+    """+1/-1 symbols of n_frames coded frames: sync marker + pseudo-random payload, encoded as one stream."""
+    rng = np.random.default_rng(seed)
+    asm = np.array([(CCSDS_ASM >> (31 - i)) & 1 for i in range(32)], dtype=np.uint8)
+    frames = [np.concatenate([asm, rng.integers(0, 2, CODED_FRAME_SYMBOLS // 2 - 32).astype(np.uint8)])
+              for _ in range(n_frames)]
+    coded = conv_encode_k7(np.concatenate(frames))
+    return np.where(coded == 1, 1.0, -1.0)
