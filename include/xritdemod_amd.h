@@ -177,6 +177,20 @@ int xrit_sync_correlate_device(const int8_t *d_symbols, size_t n_symbols, const 
 int xrit_sync_correlate(const int8_t *symbols, size_t n_symbols, const uint64_t *words, int nwords, uint32_t frame,
                         xrit_sync_hit *hits, int device);
 
+/* Frame alignment and phase fix, the two steps between the correlator and Viterbi
+ * (newdecoder.cpp:239-270): for window f the frame that starts at the correlation
+ * position, symbols[f*frame + position .. + frame) -- the reference shifts its chunk
+ * down and reads `position` more bytes -- with every byte XOR 0xFF when word != 0
+ * (PacketFixer::fixPacket(..., DEG_180, false), :232,:265-267; LRIT only: HRIT is
+ * differentially coded and skips it, so pass hits with word forced to 0 there).
+ * A window whose correlation is below min_correlation (MINCORRELATIONBITS, :239-242)
+ * or whose frame would run past n_symbols gives no frame: zeros, valid[f] = 0.
+ * frames: (n_symbols / frame) * frame bytes; valid: n_symbols / frame bytes. */
+int xrit_sync_fix_frames_device(const int8_t *d_symbols, size_t n_symbols, const xrit_sync_hit *d_hits, uint32_t frame,
+                                uint32_t min_correlation, int8_t *d_frames, uint8_t *d_valid, int device, void *stream);
+int xrit_sync_fix_frames(const int8_t *symbols, size_t n_symbols, const xrit_sync_hit *hits, uint32_t frame,
+                         uint32_t min_correlation, int8_t *frames, uint8_t *valid, int device);
+
 /* ------------------------------------------------------------------------
  * Stage objects -- the SatHelper classes one by one, for stage-level parity
  * and for callers that keep the reference's five-Work() structure.

@@ -107,6 +107,8 @@ def lib():
         L.xo_quantize_i8.argtypes = [vp, vp, C.c_size_t]
         L.xo_sync_correlate.argtypes = [vp, C.c_uint32, vp, C.c_int, vp, vp, vp]
         L.xo_sync_correlate.restype = None
+        L.xo_sync_fix_frames.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+        L.xo_sync_fix_frames.restype = None
         L.xo_convert_samples.argtypes = [vp, C.c_int, vp, C.c_size_t]
         _lib = L
     return _lib
@@ -300,3 +302,15 @@ def sync_correlate(data, words=(LRIT_UW0, LRIT_UW2), frame=16384):
         lib().xo_sync_correlate(_p(seg), frame, _p(w), len(w), C.byref(a), C.byref(b), C.byref(c))
         out[f] = (a.value, b.value, c.value)
     return out
+
+
+def sync_fix_frames(data, hits, frame=16384, min_correlation=46):
+    """Frame alignment + phase fix as decoder/src/newdecoder.cpp:239-270 does them: (frames, valid)."""
+    d = np.ascontiguousarray(data, np.int8)
+    nf = len(d) // frame
+    h = np.asarray(hits, np.uint32)[:nf]
+    word, pos, corr = (np.ascontiguousarray(h[:, i]) for i in range(3))
+    frames = np.zeros((nf, frame), np.int8)
+    valid = np.zeros(nf, np.uint8)
+    lib().xo_sync_fix_frames(_p(d), len(d), _p(word), _p(pos), _p(corr), frame, min_correlation, _p(frames), _p(valid))
+    return frames, valid

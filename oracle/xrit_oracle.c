@@ -641,3 +641,28 @@ void xo_sync_correlate(const int8_t *data, uint32_t length, const uint64_t *word
     *pos_out = best_p[word];
     *corr_out = corr;
 }
+
+/* Frame alignment and phase fix as the decoder does them between the correlator and Viterbi
+ * (decoder/src/newdecoder.cpp:239-270): below the acceptance the chunk is skipped (:239-242); otherwise the
+ * frame starts at the correlation position (the chunk is shifted down and `pos` more bytes are read, :245-258)
+ * and, for the 180-degree word, PacketFixer::fixPacket(..., DEG_180, false) inverts every byte (:232,:265-267). */
+void xo_sync_fix_frames(const int8_t *data, size_t n, const uint32_t *word, const uint32_t *pos, const uint32_t *corr,
+                        uint32_t frame, uint32_t min_corr, int8_t *frames, uint8_t *valid)
+{
+    const size_t nf = n / frame;
+    for (size_t f = 0; f < nf; f++) {
+        const size_t src = f * frame + pos[f];
+        int8_t *dst = frames + f * frame;
+        if (corr[f] < min_corr || src + frame > n) {
+            valid[f] = 0;
+            for (uint32_t i = 0; i < frame; i++) dst[i] = 0;
+            continue;
+        }
+        valid[f] = 1;
+        for (uint32_t i = 0; i < frame; i++) {
+            uint8_t b = (uint8_t)data[src + i];
+            if (word[f] != 0) b ^= 0xFF;
+            dst[i] = (int8_t)b;
+        }
+    }
+}

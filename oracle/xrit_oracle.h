@@ -121,6 +121,9 @@ void xo_quantize_i8(const float *in, int8_t *out, size_t n);
 /* SatHelper::Correlator as the decoder uses it (decoder/src/newdecoder.cpp:145-151,218-245) */
 void xo_sync_correlate(const int8_t *data, uint32_t length, const uint64_t *words, int nwords,
                        uint32_t *word_out, uint32_t *pos_out, uint32_t *corr_out);
+/* frame alignment + phase fix between correlator and Viterbi (decoder/src/newdecoder.cpp:239-270) */
+void xo_sync_fix_frames(const int8_t *data, size_t n, const uint32_t *word, const uint32_t *pos, const uint32_t *corr,
+                        uint32_t frame, uint32_t min_corr, int8_t *frames, uint8_t *valid);
 /* ingest conversion, demodulator.cpp:54-74 */
 void xo_convert_samples(const void *in, int sample_type, xo_cf *out, size_t n);
 

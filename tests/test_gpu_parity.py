@@ -631,6 +631,32 @@ def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
     want = o.sync_correlate(o.quantize_i8(o.Demod(o.config("lrit", fs, D)).process(x)))
     assert np.array_equal(np.asarray(hits)[3:, :2], want[3:, :2])
     assert np.abs(np.asarray(hits)[3:, 2].astype(int) - want[3:, 2].astype(int)).max() <= 1
+    # alignment + phase fix on the device: the oracle's frames bit for bit; every frame then starts with the
+    # marker as sent
+    frames, valid = xa.sync_fix_frames(s8, hits)
+    fo, vo = o.sync_fix_frames(s8, hits)
+    assert np.array_equal(frames, fo) and np.array_equal(valid, vo) and valid[3:].all()
+    again = xa.sync_correlate(frames[3:].reshape(-1))
+    assert (again[:, 0] == 0).all() and (again[:, 1] == 0).all()
+
+
+def test_sync_fix_frames_bit_exact(xa, oracle_mod):
+    """Integer work: equality with the oracle -- random bytes, every alignment of source and frame size, both
+    polarities, rejected and truncated frames."""
+    o = oracle_mod
+    rng = np.random.default_rng(12)
+    for fr, extra in ((16384, 40), (100, 13), (65, 0), (4097, 5), (1024, 1023), (4096, 3)):
+        nf = 9
+        d = rng.integers(-128, 128, nf * fr + extra).astype(np.int8)
+        hits = np.stack([rng.integers(0, 2, nf), rng.integers(0, fr - 64, nf), rng.integers(40, 65, nf)], 1).astype(np.uint32)
+        hits[0] = (0, 0, 64)
+        hits[-1, 1] = extra + 1 if extra + 1 < fr - 64 else 0       # one byte past the end
+        hits[-2, 1] = min(extra, fr - 65)                             # ends exactly at the end of the buffer when extra fits
+        a, va = xa.sync_fix_frames(d, hits, frame=fr, min_correlation=46)
+        b, vb = o.sync_fix_frames(d, hits, frame=fr, min_correlation=46)
+        assert np.array_equal(va, vb), (fr, va, vb)
+        assert np.array_equal(a, b), fr
+    assert xa.sync_fix_frames(np.zeros(10, np.int8), np.zeros((0, 3), np.uint32))[0].shape == (0, 16384)
 
 
 @pytest.mark.parametrize("D,n,seed", [(5, 53434, 955084003), (16, 247568, 15839011), (8, 98774, 864741509)])

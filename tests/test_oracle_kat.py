@@ -335,3 +335,30 @@ def test_framed_stream_locks_through_the_oracle_chain(oracle_mod):
     word, pos, worst = check_frame_lock(hits)
     # 52 of the 64 coded marker symbols are fixed, the first 12 depend on the previous frame's last six bits
     assert worst >= 50, worst
+    # alignment + phase fix: every accepted frame now starts with the marker as sent (word 0 at position 0), and
+    # its hard decisions are the coded bits that were transmitted
+    s8 = o.quantize_i8(soft)
+    frames, valid = o.sync_fix_frames(s8, hits)
+    assert valid[3:].all()
+    again = o.sync_correlate(frames[3:].reshape(-1))
+    assert (again[:, 0] == 0).all() and (again[:, 1] == 0).all()
+    from xritdemod_amd import synth
+    sent = synth.ccsds_frames(16, seed=3).reshape(16, -1) < 0          # coded bit 1 -> -1
+    got = frames[3:] < 0
+    errs = [min((got[i] != sent[j]).mean() for j in range(16)) for i in range(len(got))]
+    assert max(errs) < 0.02, errs                                      # Es/N0 12 dB: raw symbol errors are rare
+
+
+def test_sync_fix_frames_kats(oracle_mod):
+    o = oracle_mod
+    rng = np.random.default_rng(11)
+    fr = 100
+    d = rng.integers(-128, 128, 7 * fr + 13).astype(np.int8)
+    hits = np.array([[0, 0, 64], [1, 5, 50], [0, 99, 46], [1, 3, 45], [0, 7, 46], [1, 0, 64], [0, 14, 64]], np.uint32)
+    frames, valid = o.sync_fix_frames(d, hits, frame=fr, min_correlation=46)
+    assert valid.tolist() == [1, 1, 1, 0, 1, 1, 0]        # below the acceptance; past the end (6*100+14+100 > 713)
+    assert np.array_equal(frames[0], d[:fr])
+    assert np.array_equal(frames[1], ~d[fr + 5:2 * fr + 5])            # x ^ 0xFF
+    assert np.array_equal(frames[2], d[2 * fr + 99:3 * fr + 99])
+    assert not frames[3].any() and not frames[6].any()
+    assert np.array_equal(frames[5], ~d[5 * fr:6 * fr])

@@ -13,5 +13,5 @@ from ._capi import (  # noqa: F401
     XritError, lib, lib_path, build, device_count, version,
     SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ,
     Filters, FirFilter, AGC, CostasLoop, ClockRecovery, Demodulator, DemodConfig, DemodStats,
-    SynthParams as DeviceSynthParams, synth_generate_device, quantize_i8_device, sync_correlate, sync_correlate_device,
+    SynthParams as DeviceSynthParams, synth_generate_device, quantize_i8_device, sync_correlate, sync_correlate_device, sync_fix_frames, sync_fix_frames_device,
 )

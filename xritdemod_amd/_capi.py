@@ -70,6 +70,8 @@ _SIGNATURES = {
     "xrit_quantize_i8": (C.c_int, [_vp, _vp, _vp, _sz]),
     "xrit_sync_correlate_device": (C.c_int, [_vp, _sz, _vp, C.c_int, C.c_uint32, _vp, C.c_int, _vp]),
     "xrit_sync_correlate": (C.c_int, [_vp, _sz, _vp, C.c_int, C.c_uint32, _vp, C.c_int]),
+    "xrit_sync_fix_frames_device": (C.c_int, [_vp, _sz, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int, _vp]),
+    "xrit_sync_fix_frames": (C.c_int, [_vp, _sz, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int]),
     "xrit_fir_create": (C.c_int, [C.c_uint, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "xrit_fir_work": (C.c_int, [_vp, _vp, _vp, _sz]),
     "xrit_fir_destroy": (None, [_vp]),
@@ -386,6 +388,27 @@ def sync_correlate(symbols, words=(LRIT_UW0, LRIT_UW2), frame=CODED_FRAME_SIZE, 
     hits = np.zeros((nf, 4), np.uint32)
     _check(lib().xrit_sync_correlate(_p(d), len(d), _p(w), len(w), frame, _p(hits), device))
     return hits[:, :3].copy()
+
+
+def sync_fix_frames(symbols, hits, frame=CODED_FRAME_SIZE, min_correlation=MIN_CORRELATION_BITS, device=0):
+    """Frame alignment + phase fix between correlator and Viterbi (newdecoder.cpp:239-270): (frames, valid) --
+    frames[f] starts at hits[f]'s position, inverted when the 180-degree word won; valid[f] = 0 (zeros) below the
+    acceptance or past the end of the buffer.  hits: rows of (word, position, correlation)."""
+    d = np.ascontiguousarray(symbols, np.int8)
+    nf = len(d) // frame
+    h = np.zeros((nf, 4), np.uint32)
+    h[:, :3] = np.asarray(hits, np.uint32)[:nf, :3]
+    frames = np.zeros((nf, frame), np.int8)
+    valid = np.zeros(nf, np.uint8)
+    _check(lib().xrit_sync_fix_frames(_p(d), len(d), _p(h), frame, min_correlation, _p(frames), _p(valid), device))
+    return frames, valid
+
+
+def sync_fix_frames_device(d_symbols_ptr, n, d_hits_ptr, d_frames_ptr, d_valid_ptr, frame=CODED_FRAME_SIZE,
+                           min_correlation=MIN_CORRELATION_BITS, device=0, stream=None):
+    _check(lib().xrit_sync_fix_frames_device(C.c_void_p(d_symbols_ptr), n, C.c_void_p(d_hits_ptr), frame, min_correlation,
+                                             C.c_void_p(d_frames_ptr), C.c_void_p(d_valid_ptr), device,
+                                             C.c_void_p(stream) if stream else None))
 
 
 def sync_correlate_device(d_symbols_ptr, n, d_hits_ptr, words=(LRIT_UW0, LRIT_UW2), frame=CODED_FRAME_SIZE, device=0,

@@ -533,6 +533,44 @@ int xrit_sync_correlate(const int8_t *symbols, size_t n, const uint64_t *words, 
     return rc;
 }
 
+int xrit_sync_fix_frames_device(const int8_t *d_symbols, size_t n, const xrit_sync_hit *d_hits, uint32_t frame,
+                                uint32_t min_correlation, int8_t *d_frames, uint8_t *d_valid, int device, void *stream)
+{
+    if (frame == 0 || (n >= frame && (!d_symbols || !d_hits || !d_frames || !d_valid))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    return launch_sync_fix(d_symbols, n, d_hits, frame, min_correlation, d_frames, d_valid, (hipStream_t)stream);
+}
+
+int xrit_sync_fix_frames(const int8_t *symbols, size_t n, const xrit_sync_hit *hits, uint32_t frame,
+                         uint32_t min_correlation, int8_t *frames, uint8_t *valid, int device)
+{
+    if (frame == 0 || (n >= frame && (!symbols || !hits || !frames || !valid))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    const size_t nf = n / frame;
+    if (nf == 0) return XRIT_OK;
+    DevBuf din, dh, dout, dv;
+    int rc = din.reserve(n + 8);
+    if (rc == XRIT_OK) rc = dh.reserve(nf * sizeof(xrit_sync_hit));
+    if (rc == XRIT_OK) rc = dout.reserve(nf * frame);
+    if (rc == XRIT_OK) rc = dv.reserve(nf);
+    if (rc == XRIT_OK && (hipMemcpy(din.p, symbols, n, hipMemcpyHostToDevice) != hipSuccess ||
+                          hipMemcpy(dh.p, hits, nf * sizeof(xrit_sync_hit), hipMemcpyHostToDevice) != hipSuccess)) {
+        set_error("hipMemcpy failed");
+        rc = XRIT_E_HIP;
+    }
+    if (rc == XRIT_OK)
+        rc = launch_sync_fix(din.as<int8_t>(), n, dh.as<xrit_sync_hit>(), frame, min_correlation, dout.as<int8_t>(),
+                             dv.as<unsigned char>(), nullptr);
+    if (rc == XRIT_OK && (hipDeviceSynchronize() != hipSuccess ||
+                          hipMemcpy(frames, dout.p, nf * frame, hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(valid, dv.p, nf, hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("sync: device error");
+        rc = XRIT_E_HIP;
+    }
+    din.release(); dh.release(); dout.release(); dv.release();
+    return rc;
+}
+
 int xrit_quantize_i8(xrit_demod *d, const float *soft, int8_t *out, size_t n)
 {
     if (!d || (n && (!soft || !out))) { set_error("null argument"); return XRIT_E_INVALID; }

@@ -164,6 +164,8 @@ struct ClockStage {
 // ---- helpers ---------------------------------------------------------------
 int launch_sync_correlate(const int8_t *data, size_t n, const unsigned long long *words, int nwords, unsigned frame,
                           xrit_sync_hit *hits, hipStream_t s);
+int launch_sync_fix(const int8_t *data, size_t n, const xrit_sync_hit *hits, unsigned frame, unsigned min_corr,
+                    int8_t *frames, unsigned char *valid, hipStream_t s);
 int launch_quantize_i8(const float *in, int8_t *out, size_t n, hipStream_t s);
 int launch_convert(const void *in, int type, float2 *out, size_t n, hipStream_t s);
 int launch_synth(const xrit_synth_params &p, uint64_t start, size_t n, float2 *out, hipStream_t s);

@@ -105,6 +105,52 @@ __global__ void __launch_bounds__(SYNC_THREADS) sync_correlate_kernel(const int8
     }
 }
 
+// Frame alignment and phase fix (newdecoder.cpp:239-270): window f's frame starts at the correlation position --
+// the reference shifts the chunk down by `pos` and reads `pos` more bytes -- and every byte is inverted when the
+// 180-degree word won (PacketFixer::fixPacket(codedData, CODEDFRAMESIZE, DEG_180, false)).  Below the acceptance
+// (:239-242 `continue`) or past the end of the buffer: no frame (zeros, valid = 0).  Four output bytes per lane
+// from two aligned dwords and a funnel shift; bytes where the dword path would read or write outside.
+__global__ void __launch_bounds__(256) sync_fix_kernel(const int8_t *__restrict__ data, size_t n, const xrit_sync_hit *__restrict__ hits,
+                                                       unsigned frame, unsigned min_corr, int8_t *__restrict__ out,
+                                                       unsigned char *__restrict__ valid)
+{
+    const unsigned f = blockIdx.y;
+    const xrit_sync_hit h = hits[f];
+    const size_t src0 = (size_t)f * frame + h.position;
+    const bool ok = h.correlation >= min_corr && src0 + frame <= n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) valid[f] = ok ? 1 : 0;
+    const unsigned inv = (h.word != 0) ? 0xFFFFFFFFu : 0u;
+    int8_t *dst = out + (size_t)f * frame;
+    const bool words_ok = ((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(data)) & 3) == 0;
+    for (unsigned i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < frame; i += gridDim.x * 1024u) {
+        const size_t src = src0 + i;
+        const size_t base = src & ~(size_t)3;
+        if (ok && words_ok && i + 4 <= frame && base + 8 <= n) {
+            const unsigned lo = *reinterpret_cast<const unsigned *>(data + base);
+            const unsigned hi = *reinterpret_cast<const unsigned *>(data + base + 4);
+            const unsigned v = __funnelshift_r(lo, hi, (unsigned)(src & 3) * 8u);
+            *reinterpret_cast<unsigned *>(dst + i) = v ^ inv;
+        } else {
+            for (unsigned k = 0; k < 4 && i + k < frame; ++k)
+                dst[i + k] = ok ? (int8_t)(data[src + k] ^ (int8_t)inv) : (int8_t)0;
+        }
+    }
+}
+
+int launch_sync_fix(const int8_t *data, size_t n, const xrit_sync_hit *hits, unsigned frame, unsigned min_corr,
+                    int8_t *frames, unsigned char *valid, hipStream_t s)
+{
+    if (frame < 65 || frame > (1u << 20)) { set_error("sync: 65..2^20 bytes per frame"); return XRIT_E_INVALID; }
+    const size_t nf = n / frame;
+    if (nf == 0) return XRIT_OK;
+    if (nf > 65535) { set_error("sync: at most 65535 frames per call"); return XRIT_E_INVALID; }
+    const unsigned bx = (frame / 4 + 255) / 256 > 16 ? 16 : (frame / 4 + 255) / 256;
+    hipLaunchKernelGGL(sync_fix_kernel, dim3(bx ? bx : 1, (unsigned)nf), dim3(256), 0, s, data, n, hits, frame, min_corr, frames,
+                       valid);
+    XR_HIP(hipGetLastError());
+    return XRIT_OK;
+}
+
 int launch_sync_correlate(const int8_t *data, size_t n, const unsigned long long *words, int nwords, unsigned frame,
                           xrit_sync_hit *hits, hipStream_t s)
 {

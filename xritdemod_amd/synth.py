@@ -137,10 +137,12 @@ def conv_encode_k7(bits):
 
 
 def ccsds_frames(n_frames, seed=1):
-    """+1/-1 symbols of n_frames coded frames: sync marker + pseudo-random payload, encoded as one stream."""
+    """+1/-1 symbols of n_frames coded frames: sync marker + pseudo-random payload, encoded as one stream.
+    Coded bit 0 -> +1, 1 -> -1: with the correlator's hard decision (non-negative soft byte = one) a chain locked
+    at 0 degrees then finds the decoder's word 0 (LRIT_UW0, DEG_0) and one locked at 180 degrees its word 1."""
     rng = np.random.default_rng(seed)
     asm = np.array([(CCSDS_ASM >> (31 - i)) & 1 for i in range(32)], dtype=np.uint8)
     frames = [np.concatenate([asm, rng.integers(0, 2, CODED_FRAME_SYMBOLS // 2 - 32).astype(np.uint8)])
               for _ in range(n_frames)]
     coded = conv_encode_k7(np.concatenate(frames))
-    return np.where(coded == 1, 1.0, -1.0)
+    return np.where(coded == 1, -1.0, 1.0)
