@@ -616,7 +616,7 @@ def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
     """The external criterion: coded CCSDS-style frames -> IQ -> chain on the GPU ->
     int8 -> the decoder's correlator (on the GPU) finds the sync marker in every frame, where and as strongly as
     through the oracle chain.  Also fed in the reference's chunk size."""
-    from test_oracle_kat import _framed_burst, check_frame_lock
+    from test_oracle_kat import _framed_burst, check_frame_lock, check_decoded_payload
     o = oracle_mod
     x, sym = _framed_burst(16, fs=fs)
     q = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
@@ -638,6 +638,8 @@ def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
     assert np.array_equal(frames, fo) and np.array_equal(valid, vo) and valid[3:].all()
     again = xa.sync_correlate(frames[3:].reshape(-1))
     assert (again[:, 0] == 0).all() and (again[:, 1] == 0).all()
+    # Viterbi (numpy, test side) over the GPU's frames: marker and payload of every frame, no bit errors
+    assert check_decoded_payload(frames[3:]) == 3
 
 
 def test_sync_fix_frames_bit_exact(xa, oracle_mod):

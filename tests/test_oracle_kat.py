@@ -305,6 +305,60 @@ def _framed_burst(n_frames, fs=1.25e6, seed=3, **kw):
     return synth.generate(p, n, symbols=sym), sym
 
 
+def viterbi_decode_k7(soft):
+    """Soft-decision Viterbi for synth.conv_encode_k7 (test infrastructure, numpy): soft[2t], soft[2t+1] are the
+    received symbols of bit t, positive = coded bit 0.  Unknown start state, traceback from the best end state."""
+    soft = np.asarray(soft, np.float64)
+    n = len(soft) // 2
+    ns = np.arange(64)
+    par = np.array([bin(v).count("1") & 1 for v in range(128)])
+    regs = np.stack([ns, ns | 64])                                  # the two registers that end in state ns
+    ea = 1.0 - 2.0 * par[regs & 0x4F]                               # expected symbols
+    ec = 1.0 - 2.0 * par[regs & 0x6D]
+    prev = regs >> 1                                                # predecessor states
+    pm = np.zeros(64)
+    choice = np.zeros((n, 64), np.uint8)
+    for t in range(n):
+        cand = pm[prev] + soft[2 * t] * ea + soft[2 * t + 1] * ec   # (2, 64)
+        c = cand[1] > cand[0]
+        choice[t] = c
+        pm = np.where(c, cand[1], cand[0])
+        pm -= pm.max()
+    bits = np.zeros(n, np.uint8)
+    st = int(pm.argmax())
+    for t in range(n - 1, -1, -1):
+        bits[t] = st & 1
+        st = (st >> 1) | (32 if choice[t, st] else 0)
+    return bits
+
+
+def frame_bits(n_frames, seed):
+    """The uncoded bits synth.ccsds_frames(n_frames, seed) encodes, one row per frame."""
+    from xritdemod_amd import synth
+    rng = np.random.default_rng(seed)
+    asm = np.array([(synth.CCSDS_ASM >> (31 - i)) & 1 for i in range(32)], np.uint8)
+    return np.stack([np.concatenate([asm, rng.integers(0, 2, synth.CODED_FRAME_SYMBOLS // 2 - 32).astype(np.uint8)])
+                     for _ in range(n_frames)])
+
+
+def check_decoded_payload(frames, n_frames=16, seed=3, guard=48):
+    """Viterbi over the aligned, phase-fixed frames (one contiguous symbol stream) gives back the transmitted
+    bits: sync marker and payload of every frame, no errors (the ends of the stream aside)."""
+    sent = frame_bits(n_frames, seed)
+    got = viterbi_decode_k7(frames.reshape(-1).astype(np.float64)).reshape(len(frames), -1)
+    asm = sent[0, :32]
+    first = next(j for j in range(n_frames) if np.array_equal(got[1], sent[j]))     # which frame the stream starts at
+    for i in range(len(got)):
+        a = got[i].copy()
+        b = sent[first - 1 + i]
+        lo = guard if i == 0 else 0
+        hi = len(a) - guard if i == len(got) - 1 else len(a)
+        assert np.array_equal(a[lo:hi], b[lo:hi]), (i, int((a[lo:hi] != b[lo:hi]).sum()))
+        if i:
+            assert np.array_equal(a[:32], asm)
+    return first - 1
+
+
 def check_frame_lock(hits, first=3, min_corr=46):
     """What the reference decoder needs from the symbol stream (decoder/src/newdecoder.cpp:218-245): in every
     16384-symbol window the same sync word at the same position, correlation >= 46 of 64."""
@@ -347,6 +401,8 @@ def test_framed_stream_locks_through_the_oracle_chain(oracle_mod):
     got = frames[3:] < 0
     errs = [min((got[i] != sent[j]).mean() for j in range(16)) for i in range(len(got))]
     assert max(errs) < 0.02, errs                                      # Es/N0 12 dB: raw symbol errors are rare
+    # ... and Viterbi over them returns marker and payload of every frame without a bit error
+    assert check_decoded_payload(frames[3:]) == 3
 
 
 def test_sync_fix_frames_kats(oracle_mod):
