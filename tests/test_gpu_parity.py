@@ -360,6 +360,36 @@ def test_full_size_burst_properties(xa):
     assert st.costas_unconverged == 0
 
 
+def _host_to_socket(host_bin, capture, fmt, block):
+    """Run xrit_demod_host on a capture file with a listening 'decoder' socket as its sink; what arrived."""
+    import socket
+    import subprocess
+    import threading
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+    got = bytearray()
+
+    def serve():
+        conn, _ = srv.accept()
+        while True:
+            b = conn.recv(65536)
+            if not b:
+                break
+            got.extend(b)
+        conn.close()
+
+    th = threading.Thread(target=serve)
+    th.start()
+    r = subprocess.run([host_bin, "--input", str(capture), "--format", fmt, "--mode", "lrit", "--sample-rate", "1250000",
+                        "--block", str(block), "--sink", f"tcp://127.0.0.1:{port}", "--stats"], capture_output=True,
+                       text=True, timeout=120)
+    th.join(timeout=30)
+    srv.close()
+    return r, got
+
+
 @pytest.mark.parametrize("fmt", ["cf32", "s16", "s8"])
 def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_path, fmt):
     """xrit_demod_host = the reference's plumbing around the library (CFileFrontend -> processSamples ->
@@ -382,28 +412,7 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
     else:
         raw = x
     raw.tofile(f)
-    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-    srv.bind(("127.0.0.1", 0))
-    srv.listen(1)
-    port = srv.getsockname()[1]
-    got = bytearray()
-
-    def serve():
-        conn, _ = srv.accept()
-        while True:
-            b = conn.recv(65536)
-            if not b:
-                break
-            got.extend(b)
-        conn.close()
-
-    th = threading.Thread(target=serve)
-    th.start()
-    r = subprocess.run([host_bin, "--input", str(f), "--format", fmt, "--mode", "lrit", "--sample-rate", "1250000",
-                        "--block", str(block), "--sink", f"tcp://127.0.0.1:{port}", "--stats"], capture_output=True,
-                       text=True, timeout=120)
-    th.join(timeout=30)
-    srv.close()
+    r, got = _host_to_socket(host_bin, f, fmt, block)
     assert r.returncode == 0, r.stderr
     od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
     per = 1 if fmt == "cf32" else 2
@@ -414,6 +423,25 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
     d = np.abs(gq.astype(np.int16) - wq.astype(np.int16))
     assert d.max() <= 1 and np.mean(d == 0) > 0.99          # soft symbols agree to ~2e-4: a truncation edge now and then
     assert np.array_equal(np.sign(gq[np.abs(wq) > 2]), np.sign(wq[np.abs(wq) > 2]))
+
+
+def test_host_program_output_locks_in_the_decoder(xa, tmp_path):
+    """The whole plumbing against the decoder's own criteria: a capture of coded frames -> xrit_demod_host (the
+    reference's 512 Ki-sample chunks) -> TCP -> what a decoder on the socket would do: correlate, align, fix the
+    phase, Viterbi -- every frame's marker and payload come back without a bit error."""
+    from test_oracle_kat import _framed_burst, check_frame_lock, check_decoded_payload
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    x, sym = _framed_burst(16)
+    f = tmp_path / "frames.cf32"
+    x.tofile(f)
+    r, got = _host_to_socket(host_bin, f, "cf32", 524288)
+    assert r.returncode == 0, r.stderr
+    s8 = np.frombuffer(bytes(got), np.int8)
+    hits = xa.sync_correlate(s8)
+    check_frame_lock(hits)
+    frames, valid = xa.sync_fix_frames(s8, hits)
+    assert valid[3:].all()
+    assert check_decoded_payload(frames[3:]) == 3
 
 
 class _ThreadComm:
