@@ -639,14 +639,15 @@ def test_sync_correlator_bit_exact(xa, oracle_mod):
     assert len(xa.sync_correlate(d[:100])) == 0
 
 
-@pytest.mark.parametrize("fs,D,chunk", [(1.25e6, 1, 0), (6.25e6, 5, 0), (1.25e6, 1, 262144)])
-def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
+@pytest.mark.parametrize("fs,D,chunk,esn0", [(1.25e6, 1, 0, 12.0), (6.25e6, 5, 0, 12.0), (1.25e6, 1, 262144, 12.0),
+                                              (1.25e6, 1, 0, 4.0)])
+def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk, esn0):
     """The external criterion: coded CCSDS-style frames -> IQ -> chain on the GPU ->
     int8 -> the decoder's correlator (on the GPU) finds the sync marker in every frame, where and as strongly as
     through the oracle chain.  Also fed in the reference's chunk size."""
     from test_oracle_kat import _framed_burst, check_frame_lock, check_decoded_payload
     o = oracle_mod
-    x, sym = _framed_burst(16, fs=fs)
+    x, sym = _framed_burst(16, fs=fs, esn0_db=esn0)          # 4 dB: ~1.3 % raw symbol errors, the code's working range
     q = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
     if chunk:
         soft = np.concatenate([q.process(x[i:i + chunk]) for i in range(0, len(x), chunk)])
@@ -655,7 +656,7 @@ def test_framed_stream_locks(xa, oracle_mod, fs, D, chunk):
     s8 = q.quantize_i8(soft)
     hits = xa.sync_correlate(s8)
     word, pos, worst = check_frame_lock(hits)
-    assert worst >= 50
+    assert worst >= (50 if esn0 > 10 else 46)
     want = o.sync_correlate(o.quantize_i8(o.Demod(o.config("lrit", fs, D)).process(x)))
     assert np.array_equal(np.asarray(hits)[3:, :2], want[3:, :2])
     assert np.abs(np.asarray(hits)[3:, 2].astype(int) - want[3:, 2].astype(int)).max() <= 1
