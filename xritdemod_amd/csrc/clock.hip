@@ -905,7 +905,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
-    XR_TRY(work.reserve((size_t)(2 * nbmax + 6) * sizeof(AffMap)));
+    const int nbN = newton_blocks(K) > nbmax ? newton_blocks(K) : nbmax;
+    XR_TRY(work.reserve((size_t)(3 * nbN + 8) * sizeof(AffMap)));
     j.dirty = flags.as<int>();
     j.counts = flags.as<int>() + K;
     j.nrun = flags.as<int>() + 2 * K;

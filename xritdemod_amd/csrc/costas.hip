@@ -479,7 +479,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     XR_TRY(stat.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(flags.reserve((size_t)K * sizeof(int)));
     const int nbK = scan_blocks(K);
-    const size_t agg_bytes = (((size_t)(2 * newton_blocks(K) + 4) * sizeof(AffMap)) + 15) & ~(size_t)15;
+    const size_t agg_bytes = (((size_t)(3 * newton_blocks(K) + 6) * sizeof(AffMap)) + 15) & ~(size_t)15;
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);

@@ -315,7 +315,6 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
-    constexpr int GPW = 64 / DP;                      // output groups per wave
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int OB = (nthr / DP) * PR;                  // outputs per block
     // Neighbouring tiles share (NQ-1)/(NQ-1+OB/...) of their window -- a third at d = 32.  Workgroups go to the

@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_gate_kernel(P p, long lon
 
 template <typename P>
 __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long long n, const AffMap *agg0,
-                                                                    const AffMap *agg1, const float2 *dlin, int *ctl)
+                                                                    const AffMap *agg1, const float2 *dlin, int *ctl,
+                                                                    NewtonStat *slots)
 {
     if (ctl[0]) return;
     __shared__ AffMap buf[NEWTON_BLOCK];
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
         st.sum_sq += (unsigned long long)__shfl_down((long long)st.sum_sq, off, 64);
     }
     __shared__ NewtonStat wst[NEWTON_BLOCK / 64];
+    __shared__ int is_last;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) wst[threadIdx.x >> 6] = st;
     __syncthreads();
@@ -247,17 +249,44 @@ __global__ void __launch_bounds__(NEWTON_BLOCK) newton_apply_kernel(P p, long lo
             t.changed += wst[w].changed; t.open_ += wst[w].open_; t.large += wst[w].large;
             t.max_r = fmaxf(t.max_r, wst[w].max_r); t.sum_sq += wst[w].sum_sq;
         }
-        if (t.changed) atomicAdd(&p.cnt[0], t.changed);
-        if (t.open_) {
-            atomicAdd(&p.cnt[1], t.open_);
-            atomicMax(&p.cnt[2], __float_as_uint(t.max_r));
-            atomicAdd(reinterpret_cast<unsigned long long *>(&p.cnt[4]), t.sum_sq);
+        // The block's statistics go to its own slot; the block that finishes last adds the slots up and takes the
+        // stop decision (nobody reads ctl any more in this launch) -- no separate decision launch, and one atomic
+        // per block instead of six on one cache line (release: this block's slot; acquire: everybody's).
+        slots[blockIdx.x] = t;
+        is_last = __hip_atomic_fetch_add(&p.cnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave of this block reads the others' slots
+    NewtonStat t{0u, 0u, 0u, 0.f, 0ull};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += NEWTON_BLOCK) {
+        const NewtonStat o = slots[b];
+        t.changed += o.changed; t.open_ += o.open_; t.large += o.large;
+        t.max_r = fmaxf(t.max_r, o.max_r); t.sum_sq += o.sum_sq;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        t.changed += __shfl_down(t.changed, off, 64);
+        t.open_ += __shfl_down(t.open_, off, 64);
+        t.large += __shfl_down(t.large, off, 64);
+        t.max_r = fmaxf(t.max_r, __shfl_down(t.max_r, off, 64));
+        t.sum_sq += (unsigned long long)__shfl_down((long long)t.sum_sq, off, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wst[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t = wst[0];
+        for (int w = 1; w < NEWTON_BLOCK / 64; ++w) {
+            t.changed += wst[w].changed; t.open_ += wst[w].open_; t.large += wst[w].large;
+            t.max_r = fmaxf(t.max_r, wst[w].max_r); t.sum_sq += wst[w].sum_sq;
         }
-        if (t.large) atomicAdd(&p.cnt[3], t.large);
-        // release: this block's statistics; acquire: the block that finishes last sees everybody's and takes
-        // the stop decision (nobody reads ctl any more in this launch) -- no separate decision launch
-        if (__hip_atomic_fetch_add(&p.cnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
-            p.decide(ctl);
+        p.cnt[0] = t.changed;
+        p.cnt[1] = t.open_;
+        p.cnt[2] = t.open_ ? __float_as_uint(t.max_r) : 0u;
+        p.cnt[3] = t.large;
+        *reinterpret_cast<unsigned long long *>(&p.cnt[4]) = t.open_ ? t.sum_sq : 0ull;
+        __threadfence();
+        p.decide(ctl);
     }
 }
 
@@ -354,7 +383,7 @@ __global__ void __launch_bounds__(NEWTON_SMALL_BLOCK) newton_small_kernel(P p, l
 
 static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
 
-// agg storage: 2 * (blocks + 1) AffMaps; dlin: n + 1 float2
+// agg storage: 3 * (blocks + 1) AffMaps (two sets of block aggregates, one statistics slot per block); dlin: n + 1 float2
 template <typename P>
 static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dlin, int *ctl, hipStream_t s)
 {
@@ -368,7 +397,9 @@ static inline int newton_solve(const P &p, long long n, AffMap *aggs, float2 *dl
     AffMap *agg0 = aggs, *agg1 = aggs + nb + 1;
     hipLaunchKernelGGL(newton_reduce_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, ctl);
     hipLaunchKernelGGL(newton_gate_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin, ctl);
-    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin, ctl);
+    static_assert(sizeof(NewtonStat) <= sizeof(AffMap), "a statistics slot fits an AffMap");
+    NewtonStat *slots = reinterpret_cast<NewtonStat *>(aggs + 2 * (nb + 1));
+    hipLaunchKernelGGL(newton_apply_kernel<P>, dim3(nb), dim3(NEWTON_BLOCK), 0, s, p, n, agg0, agg1, dlin, ctl, slots);
     return 0;
 }
 
