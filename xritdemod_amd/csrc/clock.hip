@@ -956,7 +956,8 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         return XRIT_OK;
     }
     const int *hctl = reinterpret_cast<const int *>(h_res);
-    if (!closed()) {
+    const bool in_batch = closed();
+    if (!in_batch) {
         while (hctl[0] == 0 && job.enqueued < max_passes) {
             XR_TRY(enqueue_passes(2, s, prof));
             XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -966,7 +967,14 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         XR_HIP(hipStreamSynchronize(s));
     }
     passes = job.K > 1 ? hctl[1] : 0;
-    if (job.K > 1) batch = passes + 1 < 5 ? 5 : (passes + 1 > 8 ? 8 : passes + 1);
+    if (job.K > 1) {
+        // one spare pass beyond what this call needed, dropped after three calls in a row that closed inside their
+        // batch with the same count (CostasStage::finish)
+        stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
+        last_passes = passes;
+        const int want = passes + (stable >= 3 ? 0 : 1);
+        batch = want < 4 ? 4 : (want > 8 ? 8 : want);
+    }
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
     memcpy(&max_residual, &hctl[3], sizeof(float));
     if (getenv("XRIT_TRACE") && job.K > 1) {

@@ -525,7 +525,8 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
 {
     if (redone) *redone = false;
     if (job.n == 0) return XRIT_OK;
-    if (!closed()) {
+    const bool in_batch = closed();
+    if (!in_batch) {
         if (redone) *redone = true;
         while (h_counters[0] == 0 && job.enqueued < max_passes) {
             XR_TRY(enqueue_passes(2, s, prof));
@@ -536,7 +537,16 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         XR_HIP(hipStreamSynchronize(s));
     }
     passes = job.K > 1 ? (int)h_counters[1] : 0;
-    if (job.K > 1) batch = passes + 1 < 3 ? 3 : (passes + 1 > 6 ? 6 : passes + 1);
+    if (job.K > 1) {
+        // passes to enqueue next time before the host looks: what this call needed plus one spare -- four launches
+        // that do nothing when the prediction holds.  After three calls in a row that closed inside their batch with
+        // the same count the spare is dropped; the first call that then needs more (it continues from the host
+        // and rewrites its output, see above) brings it back.
+        stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
+        last_passes = passes;
+        const int want = passes + (stable >= 3 ? 0 : 1);
+        batch = want < 2 ? 2 : (want > 6 ? 6 : want);
+    }
     unconverged = job.K > 1 && h_counters[0] == 0 ? h_counters[2] : 0;
     uint32_t bits = h_counters[3];
     memcpy(&max_residual, &bits, sizeof(float));

@@ -103,7 +103,8 @@ struct CostasStage {
         const float2 *in = nullptr; float2 *out = nullptr; size_t n = 0; int K = 0; int enqueued = 0;
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
     } job;
-    int batch = 4;          // passes enqueued before the host looks: one more than the previous call needed
+    int batch = 4;          // passes enqueued before the host looks: what the previous call needed + a spare one
+    int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
                             // (2 on a locked signal); every surplus pass is ~4 no-op launches of ~5 us
     int get_state(float *phase, float *freq, hipStream_t s);
 };
@@ -157,7 +158,8 @@ struct ClockStage {
         size_t tile_bytes = 0;
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
-    int batch = 7;          // passes enqueued before the host looks: one more than the previous call needed
+    int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
+    int stable = 0, last_passes = -1;
                             // (5-6 in steady state)
 };
 
