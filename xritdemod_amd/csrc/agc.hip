@@ -101,6 +101,8 @@ int AgcStage::init(float rate_, float reference, float gain0, float max_gain)
     XR_TRY(state.reserve(4 * sizeof(float)));
     float h[4] = {gain0, 0.0f, gain0, 0.0f};   // two (gain, flag) slots, ping-pong
     XR_HIP(hipMemcpy(state.p, h, sizeof h, hipMemcpyHostToDevice));
+    if (!h_flag) XR_HIP(hipHostMalloc((void **)&h_flag, 64));
+    *h_flag = 0.0f;
     cur = 0;
     return XRIT_OK;
 }
@@ -109,6 +111,13 @@ void AgcStage::release()
 {
     state.release();
     aggs.release();
+    if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; }
+}
+
+int AgcStage::request_flag(hipStream_t s)
+{
+    XR_HIP(hipMemcpyAsync(h_flag, state.as<float>() + 2 * cur + 1, sizeof(float), hipMemcpyDeviceToHost, s));
+    return XRIT_OK;
 }
 
 int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)

@@ -678,6 +678,13 @@ __global__ void clk_fill_int_kernel(int *p, int v, int n)
     if (i < n) p[i] = v;
 }
 
+// start of a call: the pass counters cleared and "no chain has run out of input yet", in one launch
+__global__ void __launch_bounds__(256) clock_reset_kernel(unsigned *counters, int words, int *terminal)
+{
+    for (int i = threadIdx.x; i < words; i += 256) counters[i] = 0u;
+    if (threadIdx.x == 0) *terminal = 0x7fffffff;
+}
+
 int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
                      int max_passes_)
 {
@@ -789,7 +796,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
     return XRIT_OK;
 }
 
-int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
+int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
 {
     const Job &j = job;
     const float2 *x = xbase();
@@ -799,7 +806,8 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof)
     const unsigned gridK = div_up((size_t)j.K, 64);
     {
         ProfScope ps(prof, "clock_output", s);
-        hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
+        // (the first output pass of a call finds the marker set by clock_reset_kernel)
+        if (again) hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
 #define XR_CLK_OUT_S(WPV, NCM, SYMV)                                                                                  \
     hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(gridK), dim3(64), j.tile_bytes, s, x,              \
                        table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym,            \
@@ -914,7 +922,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     const ClockState *st_in = st.as<ClockState>() + cur;
-    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), (max_passes + 4) * 8, j.terminal);
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
@@ -963,7 +971,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
         }
-        XR_TRY(enqueue_output(s, prof));
+        XR_TRY(enqueue_output(s, prof, true));
         XR_HIP(hipStreamSynchronize(s));
     }
     passes = job.K > 1 ? hctl[1] : 0;

@@ -56,6 +56,7 @@ struct xrit_demod {
     hipEvent_t ev_in = nullptr, ev_fe[2] = {nullptr, nullptr}, ev_lp[2] = {nullptr, nullptr};
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
     bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
+    bool agc_fallback_seen = false;   // this call: the AGC's guard sent a slice down the serial path
     DevBuf stage_buf[5];
     size_t stage_n[5] = {0, 0, 0, 0, 0};
     Profiler prof;
@@ -311,7 +312,9 @@ static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_
     const float2 *stat = io.stat_ready ? d->stat[set].as<float2>() : nullptr;
     XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
     XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
+    if (length) XR_TRY(d->agc.request_flag(s));        // the AGC's guard flag rides along: no wait of its own
     XR_HIP(hipStreamSynchronize(s));
+    if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
     bool redone = false;
     XR_TRY(d->costas.finish(s, prof, &redone));
     if (redone) {
@@ -354,6 +357,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
 
     size_t total_sym = 0, total_len = 0;
     int rc = XRIT_OK;
+    d->agc_fallback_seen = false;
     int worst_cp = 0, worst_kp = 0;
     unsigned unc_c = 0, unc_k = 0;
     float res_c = 0, res_k = 0;
@@ -407,10 +411,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.clock_unconverged = unc_k;
     d->stats.costas_max_residual = res_c;
     d->stats.clock_max_residual = res_k;
-    {
-        float flag = 0.f;   // the streams are idle here
-        if (total_len && d->agc.fallback_flag(&flag, s) == XRIT_OK) d->stats.agc_serial_fallback = flag == 2.0f;
-    }
+    d->stats.agc_serial_fallback = d->agc_fallback_seen;
     *n_out = total_sym;
     if (rc != XRIT_OK) return rc;
     if (d->cfg.strict && unc_c) {

@@ -70,6 +70,11 @@ struct AgcStage {
     int fused_scan(const float2 *in, float2 *fallback, size_t n, int per_lane, hipStream_t s, Profiler *prof, AgcFill *fill);
     int gain(float *g, hipStream_t s);
     int fallback_flag(float *flag, hipStream_t s);
+    // the same without a wait of its own: the copy goes into a pinned word behind whatever is queued on s, and
+    // the caller reads it after its next synchronise
+    int request_flag(hipStream_t s);
+    float requested_flag() const { return h_flag ? *h_flag : 0.0f; }
+    float *h_flag = nullptr;
 };
 
 // ---- CostasLoop (demodulator.cpp:448; Work at :152) -----------------------
@@ -151,7 +156,7 @@ struct ClockStage {
     bool closed() const;
     int finish(size_t *n_out, hipStream_t s, Profiler *prof);
     int enqueue_passes(int count, hipStream_t s, Profiler *prof);
-    int enqueue_output(hipStream_t s, Profiler *prof);
+    int enqueue_output(hipStream_t s, Profiler *prof, bool again = false);
     struct Job {
         size_t n = 0, cap = 0; float *soft = nullptr; float2 *sym = nullptr;
         long long N = 0, ni = 0; int K = 0, enqueued = 0, SS = 0, W = 0, WS = 0, A = 0, STEP = 0; bool wide = false, short_input = false;
