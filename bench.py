@@ -96,8 +96,8 @@ def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--burst-log2", type=int, default=28, help="log2 of samples per burst (28 = 256 Mi)")
     ap.add_argument("--decimation", type=int, default=5)
     ap.add_argument("--cpu-sample-log2", type=int, default=27, help="log2 of samples timed on the CPU oracle")

@@ -976,11 +976,11 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     }
     passes = job.K > 1 ? hctl[1] : 0;
     if (job.K > 1) {
-        // one spare pass beyond what this call needed, dropped after three calls in a row that closed inside their
+        // one spare pass beyond what this call needed, dropped after two calls in a row that closed inside their
         // batch with the same count (CostasStage::finish)
         stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
         last_passes = passes;
-        const int want = passes + (stable >= 3 ? 0 : 1);
+        const int want = passes + (stable >= 2 ? 0 : 1);
         batch = want < 4 ? 4 : (want > 8 ? 8 : want);
     }
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;

@@ -539,12 +539,12 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
     passes = job.K > 1 ? (int)h_counters[1] : 0;
     if (job.K > 1) {
         // passes to enqueue next time before the host looks: what this call needed plus one spare -- four launches
-        // that do nothing when the prediction holds.  After three calls in a row that closed inside their batch with
+        // that do nothing when the prediction holds.  After two calls in a row that closed inside their batch with
         // the same count the spare is dropped; the first call that then needs more (it continues from the host
         // and rewrites its output, see above) brings it back.
         stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
         last_passes = passes;
-        const int want = passes + (stable >= 3 ? 0 : 1);
+        const int want = passes + (stable >= 2 ? 0 : 1);
         batch = want < 2 ? 2 : (want > 6 ? 6 : want);
     }
     unconverged = job.K > 1 && h_counters[0] == 0 ? h_counters[2] : 0;
