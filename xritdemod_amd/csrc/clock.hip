@@ -976,12 +976,13 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     }
     passes = job.K > 1 ? hctl[1] : 0;
     if (job.K > 1) {
-        // one spare pass beyond what this call needed, dropped after two calls in a row that closed inside their
-        // batch with the same count (CostasStage::finish)
-        stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
+        // one spare pass beyond what this call needed.  Unlike the Costas loop's, it is never dropped: the stall
+        // rule ends the passes one earlier or later from burst to burst (measured: one C2 burst in ten needs six
+        // instead of five), and a call that runs out of enqueued passes costs a host round trip, two more passes
+        // and a second output pass -- 0.5 ms against the 19 us the four idle launches take.
         last_passes = passes;
-        const int want = passes + (stable >= 2 ? 0 : 1);
-        batch = want < 4 ? 4 : (want > 8 ? 8 : want);
+        const int want = passes + 1;
+        batch = want < 5 ? 5 : (want > 8 ? 8 : want);
     }
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
     memcpy(&max_residual, &hctl[3], sizeof(float));

@@ -164,7 +164,7 @@ struct ClockStage {
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
-    int stable = 0, last_passes = -1;
+    int last_passes = -1;
                             // (5-6 in steady state)
 };
 
