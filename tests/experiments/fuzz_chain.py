@@ -32,6 +32,10 @@ for c in range(cases):
     ncut = int(rng.integers(0, 4))
     cutv = [int(v) for v in rng.integers(0, n + 1, ncut)]
     keep = rng.random() < 0.3
+    knobs = {}
+    if os.environ.get("FUZZ_CFG"):
+        knobs = dict(costas_chain_len=int(rng.choice([0, 64, 128, 256, 320, 512])), clock_chain_syms=int(rng.choice([0, 16, 24, 64, 100, 256])),
+                     slices=int(rng.choice([0, 1, 2, 3])))
     if only and c not in only:
         continue
     x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=seed, **extra), n)
@@ -43,10 +47,6 @@ for c in range(cases):
         xi = x
     per = 1 if typ == 0 else 2
     cuts = sorted(set([0, n] + cutv))
-    knobs = {}
-    if os.environ.get("FUZZ_CFG"):
-        knobs = dict(costas_chain_len=int(rng.choice([0, 64, 128, 256, 320, 512])), clock_chain_syms=int(rng.choice([0, 16, 24, 64, 100, 256])),
-                     slices=int(rng.choice([0, 1, 2, 3])))
     od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), **knobs))
     gd.keep_stages(keep)
     want, got = [], []

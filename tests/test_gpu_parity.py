@@ -705,3 +705,22 @@ def test_cold_started_short_calls_close(xa, oracle_mod, D, n, seed):
     st = dem.stats()
     assert st.costas_unconverged == 0 and st.costas_passes < 16
     check_symbols(got, want)
+
+
+def test_pull_in_across_short_calls_stays_on_the_serial_trajectory(xa, oracle_mod):
+    """Found by tests/experiments/fuzz_chain.py: a cold start at -516 Hz (inside the lock-in range, the loop pulls in
+    over ~10^4 samples) cut in three short calls.  While it pulls in the Costas loop is expansive for stretches, so
+    what one call's hand-off leaves within its tolerance the next call multiplies: with 1e-5 rad everywhere the
+    de-rotated stream of the second call was 6e-4 off the serial loop and the third had two hard decisions flipped.
+    Calls in which some chain sees the loop expansive now hand off three times tighter (CostasPolicy::scale)."""
+    fs, D = 6.25e6, 5
+    p = synth.SynthParams(fs_in=fs, seed=979994813, esn0_db=13.557320079903644, carrier_hz=-515.6697006430716,
+                          clock_ppm=-91.22217827126428, timing_offset=0.6378724653927026, phase0=-0.9852106075732925)
+    x = synth.generate(p, 20511)
+    od, gd = oracle_mod.Demod(oracle_mod.config("lrit", fs, D)), xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    gd.keep_stages(True)
+    for lo, hi in ((0, 4014), (4014, 13764), (13764, 20511)):
+        w, g = od.process(x[lo:hi]), gd.process(x[lo:hi])
+        assert gd.stats().costas_unconverged == 0
+        assert np.abs(gd.stage("costas") - od.stage("costas")).max() < 1.5e-4
+        check_symbols(g, w, rms_tol=5e-5)
