@@ -129,6 +129,9 @@ __global__ void costas_head_kernel(const float2 *__restrict__ stat, float2 *__re
 // each lane walks its own chain: row stride COSTAS_CT+1 float2 = 18 dwords keeps the
 // per-lane ds_read_b64 conflict free.  FINAL: write the de-rotated samples (through
 // the same kind of tile), no tangent.
+#ifndef XR_AMP_THR
+#define XR_AMP_THR 1.02f
+#endif
 constexpr int COSTAS_CT = 8;
 constexpr int COSTAS_OT = 16 / COSTAS_CT;    // input tiles per output row of 16 samples (one 128-byte line)
 
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
         J[k] = make_float4(t.pp, t.pf, t.fp, t.ff);
         // a chain in which the loop is expansive for a while (pull-in, a cycle slip: never in lock, where amp is
         // exactly 1) puts the whole call on the tight tolerances, see CostasPolicy::scale
-        if (amp > 1.02f && ctl[7] == 0) ctl[7] = 1;
+        if (amp > XR_AMP_THR && ctl[7] == 0) ctl[7] = 1;
         dirty[k] = 0;
     }
 }
