@@ -23,7 +23,8 @@ for c in range(cases):
     amp = 0.1 if typ == 0 else 0.3
     seed = int(rng.integers(1, 1 << 30))
     wide = os.environ.get("FUZZ_WIDE")
-    extra = dict(esn0_db=float(rng.uniform(8, 20)), carrier_hz=float(rng.uniform(-600, 600)),       # inside the Costas lock-in range (~0.7 kHz at 1.25 Msps);
+    snr_lo, snr_hi = (float(v) for v in os.environ.get("FUZZ_SNR", "8,20").split(","))
+    extra = dict(esn0_db=float(rng.uniform(snr_lo, snr_hi)), carrier_hz=float(rng.uniform(-600, 600)),       # inside the Costas lock-in range (~0.7 kHz at 1.25 Msps);
                  # beyond it the loop pulls in with cycle slips for 1e5 samples and more, the hand-off closes a chain or
                  # two per pass there (FUZZ_PASSES=1000 then still reproduces the oracle), the default budget does not
 
@@ -47,7 +48,7 @@ for c in range(cases):
         xi = x
     per = 1 if typ == 0 else 2
     cuts = sorted(set([0, n] + cutv))
-    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), **knobs))
+    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), clock_min_passes=int(os.environ.get("FUZZ_CLOCK_MIN", "0")), **knobs))
     gd.keep_stages(keep)
     want, got = [], []
     ok = True
