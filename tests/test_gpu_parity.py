@@ -724,3 +724,25 @@ def test_pull_in_across_short_calls_stays_on_the_serial_trajectory(xa, oracle_mo
         assert gd.stats().costas_unconverged == 0
         assert np.abs(gd.stage("costas") - od.stage("costas")).max() < 1.5e-4
         check_symbols(g, w, rms_tol=5e-5)
+
+
+@pytest.mark.parametrize("D,n,seed,cuts,kw", [
+    (3, 34446, 1072154349, [10319, 18114, 32121],
+     dict(esn0_db=4.149501316827086, carrier_hz=-59.681582418256426, clock_ppm=-71.82099790149488,
+          timing_offset=0.9305784956560058, phase0=-1.9836256042211595)),
+    (32, 543176, 407593023, [463255],
+     dict(esn0_db=3.1185208503741633, carrier_hz=-8.064286904162259, clock_ppm=59.036872831281784,
+          timing_offset=0.18463879778632597, phase0=-0.13783750154530994))])
+def test_noisy_hrit_calls_of_a_few_hundred_chains_close(xa, oracle_mod, D, n, seed, cuts, kw):
+    """Found by tests/experiments/fuzz_chain.py at Es/N0 3..4 dB: HRIT calls of 7..100 clock chains that the stall
+    test stopped at 2e-3 sample of hand-off residual (1.4e-3 / 9e-3 rms from the oracle, 2 / 24 hard decisions
+    flipped) although they close exactly given the passes.  Below 4096 open boundaries the stall must now show
+    twice in a row, and passes go on while boundaries still freeze (ClockPolicy::decide)."""
+    fs = 2.5e6 * D
+    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=927000.0, alpha=0.3, seed=seed, **kw), n)
+    od, gd = oracle_mod.Demod(oracle_mod.config("hrit", fs, D)), xa.Demodulator(xa.Demodulator.config("hrit", fs, D))
+    want, got = [], []
+    for lo, hi in zip([0] + cuts, cuts + [n]):
+        want.append(od.process(x[lo:hi]))
+        got.append(gd.process(x[lo:hi]))
+    check_symbols(np.concatenate(got), np.concatenate(want), rms_tol=1e-4)
