@@ -83,8 +83,9 @@ typedef struct xrit_demod_config {
     int32_t  clock_chain_syms;  /* symbols per clock-recovery chain; 0 = chosen per call (64..256) so that the call's
                                  * waves fill whole generations of what the chip holds.  Every chain boundary is a
                                  * place where the recovered clock may differ from the serial loop's by the loop's
-                                 * own chaos level, so very short chains cost parity: 16..24 symbols measured
-                                 * 6.5e-4 rms against 2.2e-4 at the default, hard decisions unchanged */
+                                 * own chaos level, so short chains cost parity; values below
+                                 * 32 are raised to 32 (16-symbol chains measured 6.5e-4 rms against 2.2e-4 at
+                                 * the default and were seen to mis-resolve a symbol slip at Es/N0 < 4 dB) */
     int32_t  max_passes;        /* hand-off passes before giving up (per loop); 0 = 192: a locked signal needs 2 + 5,
                                  * a cold start within the loops' lock-in range ~15, a pull-in with cycle slips
                                  * a pass or two per chain of the slipping stretch */

@@ -712,7 +712,9 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     par.gain_omega = gain_omega;
     par.gain_mu = gain_mu;
     mu0 = mu;
-    NS = chain_syms > 0 ? chain_syms : 64;
+    // (fewer than 32 symbols per chain are not taken: 16-symbol chains were seen to mis-resolve a symbol slip on
+    // noisy input -- one symbol more or less in the output -- and gain nothing where they were meant to)
+    NS = chain_syms > 0 ? (chain_syms < 32 ? 32 : chain_syms) : 64;
     auto_ns = chain_syms <= 0;
     max_passes = max_passes_ > 0 ? max_passes_ : 192;      // see CostasStage::init
     min_passes = max_passes < 4 ? max_passes : 4;
