@@ -746,3 +746,23 @@ def test_noisy_hrit_calls_of_a_few_hundred_chains_close(xa, oracle_mod, D, n, se
         want.append(od.process(x[lo:hi]))
         got.append(gd.process(x[lo:hi]))
     check_symbols(np.concatenate(got), np.concatenate(want), rms_tol=1e-4)
+
+
+def test_mid_stream_jump_after_the_spare_pass_was_dropped(xa, oracle_mod):
+    """After two calls that closed inside their batch with the same count the Costas stage stops enqueueing its spare
+    pass.  A carrier / phase / timing jump in a later call then needs more passes than are queued: the call goes on
+    from the host, rewrites the de-rotated stream and runs the clock recovery again -- with a carried tail and
+    history this time (on a cold start, the usual place for that path, there is none)."""
+    fs, D, n = 6.25e6, 5, 400000
+    a = synth.generate(synth.SynthParams(fs_in=fs), 5 * n)
+    b = synth.generate(synth.SynthParams(fs_in=fs, carrier_hz=-350.0, phase0=2.1, timing_offset=0.77, seed=77), 3 * n)
+    x = np.concatenate([a, b])
+    od, gd = oracle_mod.Demod(oracle_mod.config("lrit", fs, D)), xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    passes = []
+    for i in range(8):
+        w, g = od.process(x[i * n:(i + 1) * n]), gd.process(x[i * n:(i + 1) * n])
+        st = gd.stats()
+        passes.append(st.costas_passes)
+        assert st.costas_unconverged == 0
+        check_symbols(g, w, rms_tol=5e-4 if i != 5 else 2e-3)     # call 5 re-acquires: pull-in, the loop is expansive
+    assert passes[2] == passes[3] == passes[4] == 2 and passes[5] > 2, passes
