@@ -23,9 +23,13 @@ for c in range(max(want) + 1):
                  clock_ppm=float(rng.uniform(-100, 100)), timing_offset=float(rng.uniform(0, 1)), phase0=float(rng.uniform(-3.1, 3.1)))
     ncut = int(rng.integers(0, 4)); cutv = [int(v) for v in rng.integers(0, n + 1, ncut)]
     keep = rng.random() < 0.3
+    if os.environ.get("FUZZ_CFG"):
+        rng.choice([0, 64, 128, 256, 320, 512]); rng.choice([0, 32, 48, 64, 100, 256]); rng.choice([0, 1, 2, 3])
     if c not in want:
         continue
     x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=seed, **extra), n)
+    if typ == 1:      # what the s16 ingest makes of it, as floats
+        x = (np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767) / 32768.0).astype(np.float32).view(np.complex64)
     a = oracle.Demod(oracle.config(mode, fs, D)).process(x)
     res = []
     for trial in range(3):
