@@ -766,3 +766,47 @@ def test_mid_stream_jump_after_the_spare_pass_was_dropped(xa, oracle_mod):
         assert st.costas_unconverged == 0
         check_symbols(g, w, rms_tol=5e-4 if i != 5 else 2e-3)     # call 5 re-acquires: pull-in, the loop is expansive
     assert passes[2] == passes[3] == passes[4] == 2 and passes[5] > 2, passes
+
+
+def test_randomised_chains(xa, oracle_mod):
+    """A fixed-seed slice of tests/experiments/fuzz_chain.py (which found every regression case above): random mode,
+    decimation, length, chunking, ingest type, Es/N0 6..20 dB, carrier inside the lock-in range, clock error, kept or
+    fused stages -- same symbol count, hard decisions identical, soft rms <= 6e-4 on every case."""
+    rng = np.random.default_rng(20260929)
+    worst = 0.0
+    for c in range(48):
+        mode = "lrit" if rng.random() < 0.6 else "hrit"
+        D = int(rng.choice([1, 2, 3, 5, 8, 16, 32]))
+        fs = (1.25e6 if mode == "lrit" else 2.5e6) * D
+        n = int(rng.integers(1, 12000)) * D + int(rng.integers(0, D))
+        typ = int(rng.choice([0, 0, 1, 2]))
+        sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
+        p = synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=0.1 if typ == 0 else 0.3,
+                              seed=int(rng.integers(1, 1 << 30)), esn0_db=float(rng.uniform(6, 20)),
+                              carrier_hz=float(rng.uniform(-600, 600)), clock_ppm=float(rng.uniform(-100, 100)),
+                              timing_offset=float(rng.uniform(0, 1)), phase0=float(rng.uniform(-3.1, 3.1)))
+        cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 4)))]))
+        keep = bool(rng.random() < 0.3)
+        x = synth.generate(p, n)
+        if typ == 1:
+            xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+        elif typ == 2:
+            xi = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
+        else:
+            xi = x
+        per = 1 if typ == 0 else 2
+        od, gd = oracle_mod.Demod(oracle_mod.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D))
+        gd.keep_stages(keep)
+        want, got = [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            want.append(od.process(xi[per * lo:per * hi], typ))
+            got.append(gd.process(xi[per * lo:per * hi], typ))
+            assert len(want[-1]) == len(got[-1]), (c, mode, D, n, typ, cuts)
+        w, g = np.concatenate(want), np.concatenate(got)
+        if len(w):
+            big = np.abs(w) > 1e-3
+            assert np.array_equal(np.sign(w[big]), np.sign(g[big])), (c, mode, D, n, typ, cuts)
+            r = rms(w - g)
+            assert r <= 6e-4, (c, mode, D, n, typ, cuts, r)
+            worst = max(worst, r)
+    assert worst > 0.0
