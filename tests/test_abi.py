@@ -103,3 +103,30 @@ def test_host_program_builds_and_has_no_cpu_path(xa, tmp_path):
     assert r.returncode == 1 and "no CPU path" in r.stderr
     src = open(os.path.join(ROOT, "xritdemod_amd", "host", "xrit_demod_host.cpp")).read()
     assert "hip/hip_runtime" not in src          # the boundary is the C ABI only
+
+
+def test_integration_md_snippets_compile_against_the_header(tmp_path):
+    """INTEGRATION.md shows the code a maintainer of the reference would write; the self-contained snippets (the
+    SatHelper-shaped wrapper classes, the decoder's correlator and frame-fix calls) must at least parse against
+    include/xritdemod_amd.h."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", text, re.S)
+    wrapper = next(b for b in blocks if "namespace XritAmd" in b)
+    corr = next(b for b in blocks if "xrit_sync_correlate(" in b)
+    fix = next(b for b in blocks if "xrit_sync_fix_frames(" in b)
+    a = tmp_path / "wrapper.cpp"
+    a.write_text('#include <complex>\n#include <vector>\n#include <stdexcept>\n#include "xritdemod_amd.h"\n' + wrapper +
+                 "\nint main() { return 0; }\n")
+    b = tmp_path / "decoder.cpp"
+    b.write_text('#include <cstdint>\n#include <cstddef>\n#include "xritdemod_amd.h"\n#define CODEDFRAMESIZE 16384\n'
+                 "#define MINCORRELATIONBITS 46\nstruct V { void decode(const int8_t *, uint8_t *) {} };\n"
+                 "void f(uint8_t *codedData, const int8_t *symbols, size_t nSymbols, size_t nFrames, xrit_sync_hit *hits,\n"
+                 "       int8_t *frames, uint8_t *valid, uint8_t *decodedData) {\n    V viterbi;\n" + corr +
+                 "\n(void)word; (void)pos; (void)corr;\n" + fix + "\n}\nint main() { return 0; }\n")
+    for src in (a, b):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
