@@ -677,14 +677,21 @@ struct ClockPolicy {
         // ... while the residuals are still above what the floor looks like at 12 dB (rms 1e-4 sample): a small call
         // on a clean signal stops where a big one does (6 passes, 2e-4 from the serial loop) instead of running
         // 15..25 passes of ~100 us each down to 1e-6.
-        const bool above_floor = open_ != 0u && q > 9e-8f * (float)open_;
+        // A call that is still acquiring timing (a residual beyond 0.02 sample two or more passes in) is also one in
+        // which the loop is far from its fixed point and sensitive: 4e-5 sample left at the hand-offs of such a call
+        // showed as 5e-3 in its symbols (fuzz: cold HRIT start, 3147 symbols, 14.7 dB).  It runs on while boundaries
+        // freeze, whatever the level.
+        int memo = ctl[7];
+        if (ctl[1] >= 3 && large != 0) memo |= 0x100;
+        const bool acquiring = (memo & 0x100) != 0;
+        const bool above_floor = open_ != 0u && (acquiring || q > 9e-8f * (float)open_);
         const bool freezing = above_floor && open_prev != 0x7fffffff && (long long)open_prev - (long long)open_ >= 1 &&
                               200ll * ((long long)open_prev - (long long)open_) >= (long long)open_prev;
         // With a few thousand boundaries or fewer the summed residual is a noisy statistic (a handful of boundaries
         // carry it): one pass without a 45 % fall is not yet the floor there, two in a row are.
         const bool flat = q > 0.55f * q_prev;
-        const int flat_runs = flat ? ctl[7] + 1 : 0;
-        ctl[7] = flat_runs;
+        const int flat_runs = flat ? (memo & 0xff) + 1 : 0;
+        ctl[7] = (memo & 0x100) | (flat_runs > 0xff ? 0xff : flat_runs);
         const bool stalled = !freezing && (open_ >= 4096u ? flat : flat_runs >= 2);
         if (ctl[1] >= min_passes && large == 0 && stalled) ctl[0] = 1;
     }
