@@ -94,7 +94,12 @@ typedef struct xrit_demod_config {
     int32_t  slices;            /* > 1: cut a large call into that many time slices so that the front end of one
                                    overlaps the loops of the previous on a second stream (0/1 = off, the default:
                                    measured slower on MI355X, see demod.cpp) */
-    int32_t  reserved[6];
+    int32_t  clock_serial;      /* 1: the clock recovery runs as ONE serial trajectory on the device (a single wave,
+                                 * ~0.3 us per symbol) instead of time-tiled chains: no hand-offs, so what is left
+                                 * against the CPU chain is what any float32 M&M fed by this chain's Costas output
+                                 * shows (the recurrence lives on a 2^-21-sample lattice and keeps a one-ulp
+                                 * difference for ~1e5 symbols).  A diagnostic, not a production mode. */
+    int32_t  reserved[5];
 } xrit_demod_config;
 
 /* setLRITMode / setHRITMode + Parameters.h defaults (demodulator.cpp:177-197) */
@@ -225,6 +230,8 @@ int  xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, f
                        int device, xrit_clock **out);
 /* ClockRecovery::Work(in, out, n) -> symbols through n_out */
 int  xrit_clock_work(xrit_clock *c, const float *in, size_t n, float *out, size_t cap, size_t *n_out);
+/* serial = 1: one trajectory on a single wave (see xrit_demod_config.clock_serial); 0: time-tiled chains (default) */
+int  xrit_clock_set_serial(xrit_clock *c, int serial);
 void xrit_clock_destroy(xrit_clock *c);
 
 /* ------------------------------------------------------------------------

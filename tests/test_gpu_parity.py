@@ -148,6 +148,27 @@ def test_clock_stage(xa, oracle_mod, lrit_1m):
     assert tot > 100000
 
 
+def test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit(xa, oracle_mod, lrit_1m):
+    """cfg.clock_serial / xrit_clock_set_serial: ONE trajectory on a single wave.  On the oracle's own Costas output
+    it is the same float32 arithmetic in the same order as the CPU recurrence -- identical symbols, also across
+    calls (carried state and unread tail).  This is what separates the two sources of the soft-symbol difference:
+    the time-tiled hand-offs (absent here) and the input the clock recovery is given (identical here)."""
+    o = oracle_mod
+    d = o.Demod(o.config("lrit", 1.25e6, 1))
+    d.process(lrit_1m[:300000])
+    y = d.stage("costas")
+    args = (d.sps, 0.0037 ** 2 / 4, 0.5, 0.0037, 0.005)
+    mo, mg = o.ClockRecovery(*args), xa.ClockRecovery(*args, serial=True)
+    cuts = [0, 10, 100000, 100017, 300000]
+    tot = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        so, sg = mo.Work(y[a:b]), mg.Work(y[a:b])
+        assert len(so) == len(sg)
+        assert np.array_equal(so.view(np.uint32), sg.view(np.uint32))
+        tot += len(so)
+    assert tot > 60000
+
+
 # -------------------------------------------------------------------- chain
 CASES = {
     # BASELINE.json configs: C1 (LRIT file rate, no decimation), C2 (decimation 5), C3 (HRIT), C5 (decimation 32)

@@ -26,7 +26,7 @@ class DemodConfig(C.Structure):
                 ("clock_omega_limit", C.c_float),
                 ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
                 ("max_passes", C.c_int32), ("strict", C.c_int32), ("clock_min_passes", C.c_int32),
-                ("slices", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("slices", C.c_int32), ("clock_serial", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class DemodStats(C.Structure):
@@ -85,6 +85,7 @@ _SIGNATURES = {
     "xrit_costas_destroy": (None, [_vp]),
     "xrit_clock_create": (C.c_int, [C.c_float] * 5 + [C.c_int, C.POINTER(_vp)]),
     "xrit_clock_work": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "xrit_clock_set_serial": (C.c_int, [_vp, C.c_int]),
     "xrit_clock_destroy": (None, [_vp]),
     "xrit_synth_defaults": (None, [C.POINTER(SynthParams)]),
     "xrit_synth_generate_device": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, _sz, _vp, C.c_int, _vp]),
@@ -248,9 +249,11 @@ class ClockRecovery(_Handle):
     """SatHelper::ClockRecovery(omega, gainOmega, mu, gainMu, omegaRelativeLimit); Work(in, out, n) -> symbols."""
     _destroy = "xrit_clock_destroy"
 
-    def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit, device=0):
+    def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit, device=0, serial=False):
         super().__init__()
         _check(lib().xrit_clock_create(omega, gain_omega, mu, gain_mu, omega_rel_limit, device, C.byref(self._h)))
+        if serial:
+            _check(lib().xrit_clock_set_serial(self._h, 1))
 
     def Work(self, x):
         x = _c64(x)

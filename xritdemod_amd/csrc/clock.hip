@@ -583,6 +583,69 @@ __global__ void __launch_bounds__(1024) clock_tail_kernel(const float2 *__restri
     if ((int)threadIdx.x < carry) x[threadIdx.x] = tail[threadIdx.x];
 }
 
+// ------------------------------------------------------------------- serial
+// The recurrence as the CPU runs it: ONE trajectory from the carried state to the end of the call, no chains, no
+// hand-offs (cfg.clock_serial).  A single wave: every lane computes the same symbol from an LDS window that the
+// wave refills together (coalesced); lane 0 stores.  ~0.3 us per symbol -- a diagnostic that separates what the
+// time-tiled evaluation adds from what any float32 M&M fed by this chain's own Costas output differs from the CPU
+// chain by (the recurrence lives on a lattice of 2^-21 sample in mu and omega and does not forget a one-ulp
+// difference), not a production mode.
+constexpr int CLK_SER_W = 2048;      // samples per LDS window
+
+__global__ void __launch_bounds__(64) clock_serial_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+                                                          const ClockState *__restrict__ carried_in,
+                                                          ClockState *__restrict__ carried_out,
+                                                          ClockResult *__restrict__ res, float *__restrict__ soft,
+                                                          float2 *__restrict__ sym, unsigned long long cap, long long N,
+                                                          long long ni, ClockPar par, float2 *__restrict__ tail_out)
+{
+    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
+    __shared__ cf32 win[CLK_SER_W];
+    clock_table_to_lds<64>(table, table_g);
+    const int lane = threadIdx.x;
+    ClockState s = carried_in[0];
+    long long base = -(long long)CLK_SER_W;      // window = samples [base, base + CLK_SER_W)
+    unsigned long long oo = 0;
+    __syncthreads();
+    while (s.ii < ni && s.ii >= 0 && oo < cap) {
+        if (s.ii < base || s.ii + XR_MM_NTAPS > base + CLK_SER_W) {
+            __syncthreads();
+            base = s.ii;
+            for (int i = lane; i < CLK_SER_W; i += 64) {
+                const long long j = base + i;
+                const float2 v = x[j < N ? j : N - 1];
+                win[i] = cf32{v.x, v.y};
+            }
+            __syncthreads();
+        }
+        ClockState t = s;
+        t.ii = 0;
+        const cf32 p = clock_step_w(win + (int)(s.ii - base), table, t, par);
+        s.ii += t.ii;
+        t.ii = s.ii;
+        s = t;
+        if (lane == 0) {
+            if (soft) soft[oo] = p.x;
+            if (sym) sym[oo] = make_float2(p.x, p.y);
+        }
+        ++oo;
+    }
+    long long ii = s.ii;
+    if (ii > N) ii = N;
+    if (ii < 0) ii = 0;
+    if (lane == 0) {
+        res->ok = (s.ii >= ni || s.ii < 0) ? 1 : 0;     // 0: the output buffer filled before the input ran out
+        res->terminal_chain = 0;
+        res->n_symbols = oo;
+        res->ii_final = ii;
+        ClockState c = s;
+        c.ii = 0;
+        carried_out[0] = c;
+    }
+    const long long carry = N - ii;
+    for (long long i = lane; i < carry && i < 1024; i += 64) tail_out[i] = x[ii + i];
+}
+
 // ------------------------------------------------------------ hand-off solve
 // Policy for newton.h.  State components: (t = ii + mu, omega).  A residual of m
 // whole symbol periods is carried as a slip count (aux) that shifts all later chains.
@@ -707,7 +770,7 @@ __global__ void clk_fill_int_kernel(int *p, int v, int n)
 __global__ void __launch_bounds__(256) clock_reset_kernel(unsigned *counters, int words, int *terminal)
 {
     for (int i = threadIdx.x; i < words; i += 256) counters[i] = 0u;
-    if (threadIdx.x == 0) *terminal = 0x7fffffff;
+    if (threadIdx.x == 0 && terminal) *terminal = 0x7fffffff;
 }
 
 int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
@@ -889,6 +952,19 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
                               hipMemcpyDeviceToDevice, s));
         return XRIT_OK;
     }
+    if (serial) {
+        j.K = 1;
+        hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), 16, (int *)nullptr);
+        {
+            ProfScope ps(prof, "clock_serial", s);
+            hipLaunchKernelGGL(clock_serial_kernel, dim3(1), dim3(64), 0, s, x, table.as<float>(),
+                               st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1), clock_res(counters), soft_out,
+                               sym_out, (unsigned long long)cap, j.N, j.ni, par, tail.as<float2>() + 1024 * (cur ^ 1));
+        }
+        XR_HIP(hipGetLastError());
+        XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        return XRIT_OK;
+    }
     // chain budget: the slowest admissible symbol clock plus slack
     const double min_omega = (double)par.omega_mid - (double)par.omega_lim;
     // sample rings (see ClockTile).  Over SS symbols the read index advances by A at most; a ring of R samples
@@ -1034,6 +1110,10 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     ClockResult r;
     memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + 8, sizeof r);
     cur ^= 1;
+    if (!r.ok && serial) {
+        set_error("clock recovery produced more than the %zu symbols the output holds", job.cap);
+        return XRIT_E_CAPACITY;
+    }
     if (!r.ok) {
         set_error("clock recovery: chain budget exhausted before the end of the input");
         return XRIT_E_INVALID;

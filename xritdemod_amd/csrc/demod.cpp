@@ -183,6 +183,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
+        d->clock.serial = cfg->clock_serial != 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
     } while (0);
@@ -715,6 +716,13 @@ int xrit_clock_work(xrit_clock *c, const float *in, size_t n, float *out, size_t
     if (*n_out && out)
         XR_HIP(hipMemcpyAsync(out, c->out.p, *n_out * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     XR_HIP(hipStreamSynchronize(c->stream));
+    return XRIT_OK;
+}
+
+int xrit_clock_set_serial(xrit_clock *c, int serial)
+{
+    if (!c) return XRIT_E_INVALID;
+    c->st.serial = serial != 0;
     return XRIT_OK;
 }
 

@@ -122,6 +122,7 @@ struct ClockStage {
     int cu_count = 256;     // what the chip holds at once decides the chain length, see ClockStage::begin
     long long lds_per_cu = 160 * 1024;
     bool auto_ns = true;
+    bool serial = false;    // one trajectory, no chains (cfg.clock_serial): the floor measurement, ~0.3 us per symbol
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
