@@ -89,7 +89,8 @@ typedef struct xrit_demod_config {
     int32_t  max_passes;        /* hand-off passes before giving up (per loop); 0 = 192: a locked signal needs 2 + 5,
                                  * a cold start within the loops' lock-in range ~15, a pull-in with cycle slips
                                  * a pass or two per chain of the slipping stretch */
-    int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED instead of accepting the residual */
+    int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED when the Costas hand-off stays above its tolerance or the
+                                 * clock hand-off ends with large residuals / open slips (stats.clock_open_large) */
     int32_t  clock_min_passes;  /* clock hand-off passes always run (0 = default); max_passes caps both loops */
     int32_t  slices;            /* > 1: cut a large call into that many time slices so that the front end of one
                                    overlaps the loops of the previous on a second stream (0/1 = off, the default:
@@ -113,7 +114,7 @@ void xrit_demod_destroy(xrit_demod *d);
  * (:136-140, n/decimation outputs, remainder dropped), AGC (:143), RRC (:148),
  * Costas (:152), clock recovery (:156); soft_out receives Re(symbol)
  * (SymbolManager.cpp:104).  State persists across calls like the SatHelper
- * objects.  n_out may exceed nothing: cap must be >= n/(decimation*sps*0.99)+64.
+ * objects.  cap must be >= n/(decimation*sps*0.99)+64 (checked before anything runs).
  * Host buffers. */
 int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int sample_type,
                        float *soft_out, size_t cap, size_t *n_out);
@@ -141,11 +142,16 @@ typedef struct xrit_demod_stats {
     int32_t  costas_passes;       /* hand-off passes run, last call */
     int32_t  clock_passes;
     uint32_t costas_unconverged;  /* chain boundaries left above tolerance */
-    uint32_t clock_unconverged;
+    uint32_t clock_unconverged;   /* boundaries the last clock hand-off solve still moved: close to all of them on any
+                                   * healthy call (they keep moving at the recurrence's own 1e-4 floor), NOT a failure
+                                   * count -- that is clock_open_large */
     float    costas_max_residual; /* rad */
     float    clock_max_residual;  /* samples */
     int32_t  agc_serial_fallback; /* 1 if the affine scan guard tripped (|x|*rate > 1) */
-    int32_t  reserved[5];
+    uint32_t clock_open_large;    /* boundaries left with a timing residual beyond 0.02 sample or an unresolved symbol
+                                   * slip when the passes ended: 0 on a healthy call; non-zero means acquisition did
+                                   * not finish within max_passes (symbol count or decisions may be off) */
+    int32_t  reserved[4];
 } xrit_demod_stats;
 int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s);
 

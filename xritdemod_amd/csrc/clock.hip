@@ -166,6 +166,123 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
     S[k] = s;
 }
 
+// ------------------------------------------------------------ hand-off solve
+// Policy for newton.h.  State components: (t = ii + mu, omega).  A residual of m
+// whole symbol periods is carried as a slip count (aux) that shifts all later chains.
+struct ClockPolicy {
+    ClockState *S;
+    const ClockState *E;
+    const float4 *J;
+    int *dirty;
+    const int *nrun;      // symbols chain k produced when it last ran
+    unsigned *cnt;        // [0] changed, [1] not frozen, [2] max |r_t| bits, [3] large, [4] sum r_t^2 (float)
+    float trust_t, trust_w, tol_t, tol_w;
+    int min_passes;
+    const float4 *jmean;  // not null: every chain takes the stream's mean Jacobian (ClockStage::begin)
+
+    struct Elem { ClockState e, s; float4 j; int nrun; };
+    __device__ float4 jac_of(long long k) const { return jmean ? jmean[0] : J[k]; }
+    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], jac_of(k), nrun[k]}; }
+    __device__ bool active(const Elem &el) const { return el.nrun > 0; }
+    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
+    {
+        float rt = clock_tdiff(el.e, el.s);
+        float m = rintf(rt / el.e.omega);
+        r1 = rt - m * el.e.omega;
+        r2 = el.e.omega - el.s.omega;
+        aux = (int)m;
+    }
+    __device__ float4 jac(const Elem &el) const
+    {
+        float4 j = el.j;
+        if (!(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 16384.f) || !(fabsf(j.z) < 1.f) || !(fabsf(j.w) < 4.f))
+            j = make_float4(0.f, 0.f, 0.f, 0.f);
+        return j;
+    }
+    __device__ bool outside_trust(float d1, float d2) const
+    {
+        return !(fabsf(d1) <= trust_t) || !(fabsf(d2) <= trust_w);
+    }
+    // same idea as the Costas policy: a timing residual of a good part of a sample is an acquisition or slip
+    // transient, not something the finite-difference Jacobian describes
+    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.5f); }
+    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int slip, int slip_k,
+                           float r1, NewtonStat &st) const
+    {
+        const ClockState ek = el.e, old = el.s;
+        const bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
+                               ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
+                               ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
+        if (!active(el)) {
+            // chain k produced nothing: its successor starts where it stands
+            const bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
+            if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; st.changed += 1; }
+            return;
+        }
+        const bool frozen = fabsf(n1) <= tol_t && fabsf(n2) <= tol_w && slip == 0 && slip_k == 0 && hist_same;
+        if (frozen) return;
+        ClockState nw = ek;
+        clock_shift(nw, (float)slip * ek.omega + j1);
+        nw.omega = ek.omega + j2;
+        if (nw.ii < 0) { nw.ii = 0; nw.mu = 0.f; }
+        st.open_ += 1;
+        st.max_r = fmaxf(st.max_r, fabsf(r1));
+        if (fabsf(r1) > 0.02f || slip_k != 0) st.large += 1;
+        st.sum_sq += newton_fix(r1 * r1);
+        const bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
+        if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; st.changed += 1; }
+    }
+    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] open boundaries, ctl[3] max residual (bits),
+    // ctl[4] previous summed squared residual (bits).  The recurrence is chaotic at the 1e-5 level
+    // (interpolator-arm quantisation), so boundaries keep moving by that much for ever; what must close are the
+    // LARGE residuals (acquisition at the head of a cold-started call, symbol slips: decision flips kick mu by up
+    // to ~2e-3, acquisition and slips leave residuals >> 0.02 samples).  After that the passes go on only while
+    // the summed squared residual still falls by > 45 % per pass.
+    __device__ void decide(int *ctl) const
+    {
+        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1);
+        const unsigned mr = newton_cnt_load(cnt + 2), large = newton_cnt_load(cnt + 3);
+        const unsigned long long sq = (unsigned long long)newton_cnt_load(cnt + 4) |
+                                      ((unsigned long long)newton_cnt_load(cnt + 5) << 32);
+        ctl[1] += 1;
+        ctl[2] = (int)open_;
+        ctl[3] = (int)mr;
+        const float q = newton_unfix(sq);
+        const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
+        ctl[4] = __float_as_int(q);
+        ctl[5] = (large != 0 || __uint_as_float(mr) > 0.02f) ? 1 : 0;   // trust gate only while residuals are large
+        ctl[9] = (int)large;       // boundaries with a residual beyond 0.02 sample or an open slip: what a caller can act on
+        const int open_prev = ctl[1] == 1 ? 0x7fffffff : ctl[6];
+        ctl[6] = (int)open_;
+        if (changed == 0) { ctl[0] = 1; ctl[2] = 0; return; }
+        // "stalled" is the chaos floor only if the boundaries have also stopped freezing: at C2 112 653 of 113 266
+        // stay open from pass to pass (they move by 1e-5 for ever), whereas a call of a few dozen chains closes
+        // EXACTLY given the passes (20 -> 19 -> ... -> 0 open, then 3e-7 from the serial loop) and its summed
+        // residual does not fall monotonically on the way -- the stall test alone stopped such calls at 2e-3
+        // sample (fuzz at Es/N0 3..8 dB, HRIT: 5e-4..1e-3 rms, a hard decision flipped here and there).
+        // ... while the residuals are still above what the floor looks like at 12 dB (rms 1e-4 sample): a small call
+        // on a clean signal stops where a big one does (6 passes, 2e-4 from the serial loop) instead of running
+        // 15..25 passes of ~100 us each down to 1e-6.
+        // A call that is still acquiring timing (a residual beyond 0.02 sample two or more passes in) is also one in
+        // which the loop is far from its fixed point and sensitive: 4e-5 sample left at the hand-offs of such a call
+        // showed as 5e-3 in its symbols (fuzz: cold HRIT start, 3147 symbols, 14.7 dB).  It runs on while boundaries
+        // freeze, whatever the level.
+        int memo = ctl[7];
+        if (ctl[1] >= 3 && large != 0) memo |= 0x100;
+        const bool acquiring = (memo & 0x100) != 0;
+        const bool above_floor = open_ != 0u && (acquiring || q > 9e-8f * (float)open_);
+        const bool freezing = above_floor && open_prev != 0x7fffffff && (long long)open_prev - (long long)open_ >= 1 &&
+                              200ll * ((long long)open_prev - (long long)open_) >= (long long)open_prev;
+        // With a few thousand boundaries or fewer the summed residual is a noisy statistic (a handful of boundaries
+        // carry it): one pass without a 45 % fall is not yet the floor there, two in a row are.
+        const bool flat = q > 0.55f * q_prev;
+        const int flat_runs = flat ? (memo & 0xff) + 1 : 0;
+        ctl[7] = (memo & 0x100) | (flat_runs > 0xff ? 0xff : flat_runs);
+        const bool stalled = !freezing && (open_ >= 4096u ? flat : flat_runs >= 2);
+        if (ctl[1] >= min_passes && large == 0 && stalled) ctl[0] = 1;
+    }
+};
+
 // --------------------------------------------------------------------- pass
 // Sample access.  A lane advances through its chain at its own, data dependent
 // pace, reading an 8-sample window per symbol; done straight from global memory
@@ -184,74 +301,122 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
 // sub-step from global memory.
 constexpr int CLK_M = 2;      // samples kept below the start index
 constexpr int CLK_SLACK = 3;  // head room above the schedule: R >= CLK_M + CLK_SLACK + A + 8
+// The first CLK_MIR slots of a ring are kept twice, once more behind slot R - 1: the 8-sample window of a symbol
+// then never wraps, its reads are one address and seven immediate offsets instead of eight masked indices
+// (24 of the ~95 vector instructions of a symbol went into those indices).  Row stride WS = R + CLK_MIR float2,
+// odd, so the per-lane ds_read_b64 stay spread over the banks.
+#ifndef XR_CLK_MIR
+#define XR_CLK_MIR (XR_MM_NTAPS - 1)
+#endif
+constexpr int CLK_MIR = XR_CLK_MIR;      // 0: no mirror, masked window indices (row stride R + 1)
+constexpr int CLK_ROW_EXTRA = CLK_MIR > 0 ? CLK_MIR : 1;
 
 struct ClockTile {
-    float *table;          // 129 x 8
+    float *table;          // 129 x 8, one copy per workgroup
     int *wb;               // ring origin per chain (-1: row unused); the buffer index fits 32 bits
     float2 *tile;          // 64 x WS
+    float2 *dump;          // this thread's dump slot: stores that have nothing to store go there (a select instead
+                           // of a branch around the store)
 };
 
-__device__ __forceinline__ ClockTile clock_tile_carve(char *smem)
+// LDS of a workgroup: the table, then NG groups (one per 64 chains) of ring origins and rings, then the dump slots.
+// NG > 1 only with one wave per group (NV == 1): the groups then share nothing but the table.
+__device__ __forceinline__ ClockTile clock_tile_carve(char *smem, int grp, int ngroups, int WS)
 {
     ClockTile t;
     t.table = reinterpret_cast<float *>(smem);
-    t.wb = reinterpret_cast<int *>(smem + 4160);
-    t.tile = reinterpret_cast<float2 *>(smem + 4160 + 256);
+    t.wb = reinterpret_cast<int *>(smem + 4160) + 64 * grp;
+    float2 *tiles = reinterpret_cast<float2 *>(smem + 4160 + 256 * ngroups);
+    t.tile = tiles + (size_t)grp * 64 * WS;
+    t.dump = tiles + (size_t)ngroups * 64 * WS + threadIdx.x;
     return t;
 }
 
-static inline size_t clock_tile_bytes(int WS) { return 4160 + 256 + (size_t)64 * WS * sizeof(float2); }
+static inline size_t clock_tile_bytes(int WS, int ngroups, int threads)
+{
+    return 4160 + 256 * (size_t)ngroups + ((size_t)ngroups * 64 * WS + threads) * sizeof(float2);
+}
+
+// The call's samples as a raw buffer whose base is the lowest ring origin of the workgroup: element offsets are
+// 32-bit byte offsets from there (consecutive chains: a few hundred KiB), the position of a fill along the
+// schedule goes into the scalar offset, and a read beyond the end of the input returns zero instead of needing a
+// clamp -- one buffer_load per element, no address arithmetic in vector registers.
+struct ClockSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int omin;
+};
+__device__ __forceinline__ ClockSrc clock_src(const float2 *x, long long N, int omin)
+{
+    ClockSrc c;
+    omin = __builtin_amdgcn_readfirstlane(omin);     // wave-uniform by construction: keep the descriptor in SGPRs
+    c.omin = omin;
+    const long long left = (N - (long long)omin) * 8;
+    const unsigned bytes = left <= 0 ? 0u : (left > 0xffffffffLL ? 0xffffffffu : (unsigned)left);
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(x + omin), 0, bytes, 0x00020000);
+    return c;
+}
 
 // All threads of the block (NV waves).  A fill moves nc consecutive samples of every row, starting at
-// origin + first, into ring slots (first + col) mod R; only columns < ncol are stored (a sub-step adds nc or
-// nc - 1 samples, the surplus column is the first sample of the next fill: same cache line, no traffic).  The
-// 64 x nc elements are dealt to the lanes in row-major order, IT wave instructions per wave; every lane keeps
-// its elements' source index and LDS position in registers (prepare), so a fill is a straight run of
-// unconditional global loads that are all in flight together -- issued before the symbols they overlap are
-// computed, stored afterwards.  The loads must not sit under a lane predicate: the registers would become
-// phis and the compiler would wait for the data on the spot.
+// origin + first, into ring slots (first + col) mod R (and their mirror); only columns < ncol are stored (a
+// sub-step adds nc or nc - 1 samples, the surplus column is the first sample of the next fill: same cache line, no
+// traffic).  The 64 x nc elements are dealt to the lanes in row-major order, IT wave instructions per wave; every
+// lane keeps its elements' source offset and LDS position in registers (prepare), so a fill is a straight run of
+// unconditional loads that are all in flight together -- issued before the symbols they overlap are computed,
+// stored afterwards.  The loads must not sit under a lane predicate: the registers would become phis and the
+// compiler would wait for the data on the spot.
 template <int NV, int IT> struct ClockFill {
-    int gb[IT];         // sample index of the element at first = 0 (unused rows and surplus elements: 0)
+    unsigned gb[IT];    // byte offset from the source base of the element at first = 0 (unused rows, surplus: 0)
     int lc[IT];         // (row * WS) << 8 | col, -1: nothing to store
-    float2 v[IT];
-    __device__ __forceinline__ void prepare(const int *origin, int nc, int WS)
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u v[IT];
+    __device__ __forceinline__ void prepare(const int *origin, int nc, int WS, int omin)
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = NV > 1 ? threadIdx.x >> 6 : 0;
         const int magic = 65536 / nc + 1;                 // floor(e / nc) = (e * magic) >> 16 for e < 64 * 64
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int e = (it * NV + wave) * 64 + lane;
             const int row = (e * magic) >> 16, col = e - row * nc;
-            const bool ok = row < 64;
-            gb[it] = ok ? max(origin[min(row, 63)], 0) + col : 0;
+            const bool ok = row < 64 && origin[min(row, 63)] >= 0;
+            gb[it] = ok ? (unsigned)(origin[min(row, 63)] - omin + col) * 8u : 0u;
             lc[it] = ok ? ((row * WS) << 8) | col : -1;
         }
     }
-    __device__ __forceinline__ void issue(int first, const float2 *__restrict__ x, int last)
+    __device__ __forceinline__ void issue(int first, const ClockSrc &src)
     {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) v[it] = x[min(gb[it] + first, last)];
+        for (int it = 0; it < IT; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, gb[it], first * 8, 0);
     }
-    template <int R> __device__ __forceinline__ void commit(float2 *tile, int first, int ncol) const
+    template <int R> __device__ __forceinline__ void commit(float2 *tile, float2 *dump, int first, int ncol) const
     {
 #pragma unroll
-        for (int it = 0; it < IT; ++it)
-            if ((unsigned)(lc[it] & 255) < (unsigned)ncol && lc[it] >= 0)
-                tile[(lc[it] >> 8) + ((first + lc[it]) & (R - 1))] = v[it];
+        for (int it = 0; it < IT; ++it) {
+            const bool ok = (unsigned)(lc[it] & 255) < (unsigned)ncol && lc[it] >= 0;
+            const int slot = (first + lc[it]) & (R - 1);
+            float2 *p = tile + (lc[it] >> 8) + slot;
+            const float2 val = make_float2(__uint_as_float(v[it].x), __uint_as_float(v[it].y));
+            *(ok ? p : dump) = val;
+            if (CLK_MIR > 0) *((ok && slot < CLK_MIR) ? p + R : dump) = val;
+        }
     }
 };
 
 // ring position of the schedule after jj sub-steps (16.16 fixed point step)
 __device__ __forceinline__ int clock_cum(int jj, int STEP) { return (int)(((long long)jj * STEP) >> 16); }
 
-// One symbol from the ring: the window x[ii .. ii+7] sits in slots (off + k) mod R, off = ii - origin.
+// One symbol from the ring: the window x[ii .. ii+7] starts at slot off mod R (off = ii - origin) and runs on
+// without wrapping, into the mirror slots if need be.
 template <int R>
 __device__ __forceinline__ cf32 clock_step_ring(const cf32 *row, int &off, const float *table, ClockState &s,
                                                 const ClockPar &par)
 {
-    cf32 w[XR_MM_NTAPS];
+    cf32 wl[XR_MM_NTAPS];
+    const cf32 *w = row + (off & (R - 1));
+    if (CLK_MIR == 0) {
 #pragma unroll
-    for (int k = 0; k < XR_MM_NTAPS; ++k) w[k] = row[(off + k) & (R - 1)];
+        for (int k = 0; k < XR_MM_NTAPS; ++k) wl[k] = row[(off + k) & (R - 1)];
+        w = wl;
+    }
     ClockState t = s;
     t.ii = 0;
     cf32 p = clock_step_w(w, table, t, par);
@@ -263,17 +428,17 @@ __device__ __forceinline__ cf32 clock_step_ring(const cf32 *row, int &off, const
 
 // interpolator table -> LDS.  All loads are issued before the first store: as a plain copy loop the compiler
 // emits load / wait / store per element, 17 serial memory latencies at the head of every 64-thread block.
-template <int NTHR>
 __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__restrict__ src)
 {
     constexpr int NEL = (XR_MM_NSTEPS + 1) * XR_MM_NTAPS;
-    constexpr int NIT = (NEL + NTHR - 1) / NTHR;
+    constexpr int NIT = (NEL + 63) / 64;
+    const int nthr = blockDim.x;
     float tv[NIT];
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) tv[q] = src[min((int)threadIdx.x + q * NTHR, NEL - 1)];
+    for (int q = 0; q < NIT; ++q) tv[q] = src[min((int)threadIdx.x + q * nthr, NEL - 1)];
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
-        const int i = (int)threadIdx.x + q * NTHR;
+        const int i = (int)threadIdx.x + q * nthr;
         if (i < NEL) dst[i] = tv[q];
     }
 }
@@ -282,10 +447,8 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only.  Otherwise the wave
 // computes the sub-step from global memory with the guards.  orow (output pass): where the symbols go.
 // the output tile holds complex symbols, or only their real parts when nobody asks for the complex ones
-__device__ __forceinline__ void clock_put(float2 &d, const cf32 &p) { d = make_float2(p.x, p.y); }
+__device__ __forceinline__ void clock_put(cf32 &d, const cf32 &p) { d = p; }
 __device__ __forceinline__ void clock_put(float &d, const cf32 &p) { d = p.x; }
-__device__ __forceinline__ float2 clock_get(const float2 &v) { return v; }
-__device__ __forceinline__ float2 clock_get(const float &v) { return make_float2(v, 0.f); }
 
 template <int WP, bool OUT, typename OutT>
 __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *__restrict__ x, int WS, int lane,
@@ -332,137 +495,179 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
 // The sub-step loop with the ring fills two sub-steps ahead of the compute: the samples sub-step j+2 adds are
 // requested (into registers) before sub-step j is computed and stored after sub-step j+1.  compute(j, cum_j)
 // does the work of sub-step j.  Called by all threads of the block, t.wb (ring origins) already visible.
-template <int NV, int WP, int IT, typename Compute>
-__device__ __forceinline__ void clock_pipeline(const ClockTile &t, const float2 *__restrict__ x, long long N, int WS,
-                                               int nsub, int STEP, Compute &&compute)
+// a tile is shared by the NV waves of its group: with one wave per group LDS program order is all it takes
+template <int NV> __device__ __forceinline__ void clock_tile_barrier()
 {
-    const int last = (int)(N - 1);
+    if (NV > 1) lds_barrier();
+    else __builtin_amdgcn_wave_barrier();
+}
+
+template <int NV, int WP, int IT, typename Compute>
+__device__ __forceinline__ void clock_pipeline(const ClockTile &t, const ClockSrc &src, int WS, int nsub, int STEP,
+                                               Compute &&compute)
+{
     {
         // the first window: all R columns of every row
         ClockFill<NV, (WP + NV - 1) / NV> w;
-        w.prepare(t.wb, WP, WS);
-        w.issue(0, x, last);
-        w.template commit<WP>(t.tile, 0, WP);
+        w.prepare(t.wb, WP, WS, src.omin);
+        w.issue(0, src);
+        w.template commit<WP>(t.tile, t.dump, 0, WP);
     }
     const int nc = (STEP >> 16) + 1;
     if constexpr (IT * NV > 32) {
         // wide rings (sps > ~18): one fill in flight -- two would not fit the register file
         ClockFill<NV, IT> f;
-        f.prepare(t.wb, nc, WS);
-        lds_barrier();
+        f.prepare(t.wb, nc, WS, src.omin);
+        clock_tile_barrier<NV>();
         int c0 = 0;
         for (int j = 0; j < nsub; ++j) {
             const int c1 = clock_cum(j + 1, STEP);
-            if (j + 1 < nsub) f.issue(c0 + WP, x, last);
+            if (j + 1 < nsub) f.issue(c0 + WP, src);
             compute(j, c0);
-            lds_barrier();
-            if (j + 1 < nsub) f.template commit<WP>(t.tile, c0 + WP, c1 - c0);
-            lds_barrier();
+            clock_tile_barrier<NV>();
+            if (j + 1 < nsub) f.template commit<WP>(t.tile, t.dump, c0 + WP, c1 - c0);
+            clock_tile_barrier<NV>();
             c0 = c1;
         }
         return;
     }
     ClockFill<NV, IT> f0, f1;
-    f0.prepare(t.wb, nc, WS);
+    f0.prepare(t.wb, nc, WS, src.omin);
 #pragma unroll
     for (int it = 0; it < IT; ++it) { f1.gb[it] = f0.gb[it]; f1.lc[it] = f0.lc[it]; }
-    lds_barrier();
+    clock_tile_barrier<NV>();
     int c0 = 0, c1 = clock_cum(1, STEP);
-    if (nsub > 1) f1.issue(c0 + WP, x, last);
+    if (nsub > 1) f1.issue(c0 + WP, src);
     for (int j = 0; j < nsub; j += 2) {
         const int c2 = clock_cum(j + 2, STEP), c3 = clock_cum(j + 3, STEP);
-        if (j + 2 < nsub) f0.issue(c1 + WP, x, last);
+        if (j + 2 < nsub) f0.issue(c1 + WP, src);
         compute(j, c0);
-        lds_barrier();
-        if (j + 1 < nsub) f1.template commit<WP>(t.tile, c0 + WP, c1 - c0);
-        lds_barrier();
+        clock_tile_barrier<NV>();
+        if (j + 1 < nsub) f1.template commit<WP>(t.tile, t.dump, c0 + WP, c1 - c0);
+        clock_tile_barrier<NV>();
         if (j + 1 >= nsub) break;
-        if (j + 3 < nsub) f1.issue(c2 + WP, x, last);
+        if (j + 3 < nsub) f1.issue(c2 + WP, src);
         compute(j + 1, c1);
-        lds_barrier();
-        if (j + 2 < nsub) f0.template commit<WP>(t.tile, c1 + WP, c2 - c1);
-        lds_barrier();
+        clock_tile_barrier<NV>();
+        if (j + 2 < nsub) f0.template commit<WP>(t.tile, t.dump, c1 + WP, c2 - c1);
+        clock_tile_barrier<NV>();
         c0 = c2;
         c1 = c3;
     }
 }
 
-// NV == 3 (192 threads): wave 0 = base trajectories of 64 chains, wave 1 = start
-// shifted by h_t, wave 2 = omega shifted by h_w; the base lane forms the
-// finite-difference Jacobian.  NV == 1 (64 threads): base trajectories only, the
-// Jacobian of an earlier pass is kept (quasi-Newton).
+// lowest ring origin of the workgroup's rows (rows in use only); t.wb must be visible
+__device__ __forceinline__ int clock_origin_min(const int *wb)
+{
+    int o = wb[threadIdx.x & 63];
+    o = o < 0 ? 0x7fffffff : o;
+    for (int off = 32; off > 0; off >>= 1) o = min(o, __shfl_xor(o, off, 64));
+    return o == 0x7fffffff ? 0 : o;
+}
+
+// NV == 3 (192 threads, one group): wave 0 = base trajectories of 64 chains, wave 1 = start shifted by h_t,
+// wave 2 = omega shifted by h_w; the base lane forms the finite-difference Jacobian.  NV == 1: base trajectories
+// only -- the Jacobian of an earlier pass is kept, or the stream's mean Jacobian is used (quasi-Newton, see
+// ClockStage::begin) -- and the workgroup holds blockDim.x / 64 groups of 64 chains that share the table.
 template <int NV, int WP, int NCM>
-__global__ void __launch_bounds__(64 * NV) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+__global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                              const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
                                                              int *__restrict__ nrun, long long N, long long ni, int K,
                                                              int NS, ClockPar par, int SS, int W, int WS, int A,
-                                                             int STEP, const int *__restrict__ ctl)
+                                                             int STEP, const int *__restrict__ ctl, ClockPolicy pol,
+                                                             AffMap *__restrict__ aggs)
 {
-    if (ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
+    // the hand-off already closed (later passes of the batch are no-ops), or the gated solve has taken over
+    if (ctl[0] || (aggs != nullptr && ctl[NEWTON_CTL_TAKEOVER])) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float2 endv[NV > 1 ? 2 : 1][64];
-    __shared__ long long ref_ii[64];
+    __shared__ float2 endv[2][NV > 1 ? 64 : 1];
+    __shared__ long long ref_ii[NV > 1 ? 64 : 1];
     __shared__ int any_run;
-    const ClockTile t = clock_tile_carve(smem);
-    const int variant = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 64 + lane;
+    const int ngroups = NV > 1 ? 1 : (int)(blockDim.x >> 6);
+    const int variant = NV > 1 ? threadIdx.x >> 6 : 0, grp = NV > 1 ? 0 : threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ClockTile t = clock_tile_carve(smem, grp, ngroups, WS);
+    const int wv = blockIdx.x * ngroups + grp;      // which 64 chains
+    const int k = wv * 64 + lane;
     bool run = k < K;
     if (run) run = dirty[k] != 0;
     if (threadIdx.x == 0) any_run = 0;
     __syncthreads();
     if (run && variant == 0) any_run = 1;
-    clock_table_to_lds<64 * NV>(t.table, table_g);
+    clock_table_to_lds(t.table, table_g);
     __syncthreads();
-    if (!any_run) return;
+    if (!any_run && aggs == nullptr) return;
     ClockState s{};
     int produced = 0;
-    bool alive = run;
-    if (run) {
-        s = S[k];
-        if (NV > 1 && variant == 1) clock_shift(s, CLK_H_T);
-        if (NV > 1 && variant == 2) s.omega += CLK_H_W;
-    }
-    if (variant == 0) t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
-    __syncthreads();
-    const int origin = t.wb[lane];
-    int off = (int)(s.ii - origin);
-    const int nsub = (NS + SS - 1) / SS;
-    clock_pipeline<NV, WP, (NCM + NV - 1) / NV>(t, x, N, WS, nsub, STEP, [&](int j, int cum) {
-        clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                 produced, (float *)nullptr);
-    });
-    if (NV > 1) {
-        // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
-        if (variant == 0) ref_ii[lane] = s.ii;
-        __syncthreads();
-        if (variant > 0) endv[variant - 1][lane] = make_float2((float)(s.ii - ref_ii[lane]) + s.mu, s.omega);
-        __syncthreads();
-    }
-    if (variant == 0 && run) {
-        if (NV > 1) {
-            float2 et = endv[0][lane], ew = endv[1][lane];
-            float tb = s.mu;
-            float4 j;
-            j.x = (et.x - tb) / CLK_H_T;        // dt/dt0
-            j.y = (ew.x - tb) / CLK_H_W;        // dt/dw0
-            j.z = (et.y - s.omega) / CLK_H_T;   // dw/dt0
-            j.w = (ew.y - s.omega) / CLK_H_W;   // dw/dw0
-            J[k] = j;
+    float4 jk = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (a group none of whose chains runs has nothing to walk; with NV > 1 the three waves of the group decide together)
+    const bool walk = NV > 1 ? any_run != 0 : __any(run);
+    if (walk) {
+        bool alive = run;
+        if (run) {
+            s = S[k];
+            if (NV > 1 && variant == 1) clock_shift(s, CLK_H_T);
+            if (NV > 1 && variant == 2) s.omega += CLK_H_W;
         }
-        E[k] = s;
-        nrun[k] = produced;
-        dirty[k] = 0;
+        if (variant == 0) t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
+        if (NV > 1) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
+        const int origin = t.wb[lane];
+        int off = (int)(s.ii - origin);
+        const int nsub = (NS + SS - 1) / SS;
+        const ClockSrc src = clock_src(x, N, clock_origin_min(t.wb));
+        clock_pipeline<NV, WP, (NCM + NV - 1) / NV>(t, src, WS, nsub, STEP, [&](int j, int cum) {
+            clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                     produced, (float *)nullptr);
+        });
+        if (NV > 1) {
+            // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
+            if (variant == 0) ref_ii[lane] = s.ii;
+            __syncthreads();
+            if (variant > 0) endv[variant - 1][lane] = make_float2((float)(s.ii - ref_ii[lane]) + s.mu, s.omega);
+            __syncthreads();
+        }
+        if (variant == 0 && run) {
+            if (NV > 1) {
+                float2 et = endv[0][lane], ew = endv[1][lane];
+                float tb = s.mu;
+                jk.x = (et.x - tb) / CLK_H_T;        // dt/dt0
+                jk.y = (ew.x - tb) / CLK_H_W;        // dt/dw0
+                jk.z = (et.y - s.omega) / CLK_H_T;   // dw/dt0
+                jk.w = (ew.y - s.omega) / CLK_H_W;   // dw/dw0
+                J[k] = jk;
+            }
+            E[k] = s;
+            nrun[k] = produced;
+            dirty[k] = 0;
+        }
     }
+    if (aggs == nullptr || variant != 0 || wv * 64 >= K) return;
+    // wave-aligned hand-off solve (newton.h): this wave's 64 boundary maps, composed.  A chain that ran has its end
+    // state in registers.
+    AffMap e = aff_identity();
+    if (k < K - 1) {
+        ClockPolicy::Elem el;
+        el.s = S[k + 1];
+        if (run) {
+            el.e = s;
+            el.nrun = produced;
+            el.j = NV > 1 ? jk : pol.jac_of(k);
+        } else {
+            el.e = E[k];
+            el.nrun = nrun[k];
+            el.j = pol.jac_of(k);
+        }
+        e = newton_element(pol, el, false);
+    }
+    newton_wave_aggregate(e, wv, aggs);
 }
 
-// output pass: base trajectories only; symbol i of chain k goes to k*NS + i.  A lane
-// produces its symbols one after the other, so they are collected in an LDS tile of
-// CLK_OT symbols per chain and written out row-wise (4 lanes x 16 B per chain row).
-constexpr int CLK_OT = 16;
-
+// output pass: base trajectories only; symbol i of chain k goes to k*NS + i.  A lane's symbols of one sub-step
+// leave as one 16-byte store (soft) -- consecutive sub-steps fill the rest of the 128-byte line, which the L2 holds
+// until then (the lines in flight, 64 chains x 128 B per wave, fit it many times over).
 template <int WP, int NCM, bool SYM>
-__global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
+__global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
@@ -471,65 +676,49 @@ __global__ void __launch_bounds__(64) clock_output_kernel(const float2 *__restri
                                                           int STEP)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // soft output only (SYM false): the tile holds real parts -- half the LDS, one more block per CU
-    typedef typename std::conditional<SYM, float2, float>::type OutT;
-    __shared__ OutT otile[64][CLK_OT + 1];
-    __shared__ int made[64];
-    const ClockTile t = clock_tile_carve(smem);
-    clock_table_to_lds<64>(t.table, table_g);
+    const int ngroups = (int)(blockDim.x >> 6), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ClockTile t = clock_tile_carve(smem, grp, ngroups, WS);
+    clock_table_to_lds(t.table, table_g);
     __syncthreads();
-    const int lane = threadIdx.x;
-    const int kbase = blockIdx.x * 64;
-    const int k = kbase + lane;
+    const int k = (blockIdx.x * ngroups + grp) * 64 + lane;
     const bool mine = k < K;
+    if (!__any(mine)) return;
     ClockState s{};
     if (mine) s = S[k];
     int produced = 0;
     bool alive = mine;
     t.wb[lane] = alive ? max((int)s.ii - CLK_M, 0) : -1;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     const int origin = t.wb[lane];
     int off = (int)(s.ii - origin);
     const int nsub = (NS + SS - 1) / SS;
-    int i0 = 0;                                   // first symbol of the output tile being collected
-    clock_pipeline<1, WP, NCM>(t, x, N, WS, nsub, STEP, [&](int j, int cum) {
-        const int s0 = j * SS - i0;               // SS divides CLK_OT: a sub-step never straddles two tiles
-        clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                produced, &otile[lane][s0]);
-        if (s0 + SS < CLK_OT && j + 1 < nsub) return;
-        const int olim = min(CLK_OT, NS - i0);
-        made[lane] = produced - i0;          // symbols of this tile that exist (may be <= 0)
-        lds_barrier();
-        // row-wise write: lane l handles chain (it*16 + l/4), symbols (l%4)*4 .. +3
+    const ClockSrc src = clock_src(x, N, clock_origin_min(t.wb));
+    const unsigned long long obase = (unsigned long long)k * NS;
+    clock_pipeline<1, WP, NCM>(t, src, WS, nsub, STEP, [&](int j, int cum) {
+        cf32 ps[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = it * 16 + (lane >> 2);
-            const int q0 = (lane & 3) * 4;
-            const int have = made[c];
-            const unsigned long long o = (unsigned long long)(kbase + c) * NS + i0 + q0;
-            if (kbase + c < K && q0 < have && q0 < olim) {
-                const float2 v0 = clock_get(otile[c][q0]), v1 = clock_get(otile[c][q0 + 1]),
-                             v2 = clock_get(otile[c][q0 + 2]), v3 = clock_get(otile[c][q0 + 3]);
-                const int nv = min(min(have, olim) - q0, 4);
-                if (nv == 4 && o + 3 < cap && (NS & 3) == 0) {
-                    if (soft) *reinterpret_cast<float4 *>(soft + o) = make_float4(v0.x, v1.x, v2.x, v3.x);
-                    if (SYM && sym) {
-                        *reinterpret_cast<float4 *>(sym + o) = make_float4(v0.x, v0.y, v1.x, v1.y);
-                        *reinterpret_cast<float4 *>(sym + o + 2) = make_float4(v2.x, v2.y, v3.x, v3.y);
-                    }
-                } else {
-#define XR_PUT(Q, V)                                   \
-    if (Q < nv && o + Q < cap) {                       \
-        if (soft) soft[o + Q] = V.x;                   \
-        if (SYM && sym) sym[o + Q] = V;                \
-    }
-                    XR_PUT(0, v0) XR_PUT(1, v1) XR_PUT(2, v2) XR_PUT(3, v3)
-#undef XR_PUT
+        for (int i = 0; i < 4; ++i) ps[i] = cf32{0.f, 0.f};
+        const int before = produced;
+        // (sub-steps have at most 4 symbols, see ClockStage::begin)
+        clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                produced, ps);
+        const int nv = produced - before;          // symbols of this sub-step that exist
+        const unsigned long long o = obase + (unsigned long long)j * SS;
+        if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < cap) {
+            if (soft) *reinterpret_cast<float4 *>(soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
+            if (SYM && sym) {
+                *reinterpret_cast<float4 *>(sym + o) = make_float4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
+                *reinterpret_cast<float4 *>(sym + o + 2) = make_float4(ps[2].x, ps[2].y, ps[3].x, ps[3].y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < nv && o + i < cap) {
+                    if (soft) soft[o + i] = ps[i].x;
+                    if (SYM && sym) sym[o + i] = make_float2(ps[i].x, ps[i].y);
                 }
             }
         }
-        lds_barrier();
-        i0 += CLK_OT;
     });
     if (!mine) return;
     E[k] = s;
@@ -601,7 +790,7 @@ __global__ void __launch_bounds__(64) clock_serial_kernel(const float2 *__restri
 {
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
     __shared__ cf32 win[CLK_SER_W];
-    clock_table_to_lds<64>(table, table_g);
+    clock_table_to_lds(table, table_g);
     const int lane = threadIdx.x;
     ClockState s = carried_in[0];
     long long base = -(long long)CLK_SER_W;      // window = samples [base, base + CLK_SER_W)
@@ -646,119 +835,6 @@ __global__ void __launch_bounds__(64) clock_serial_kernel(const float2 *__restri
     for (long long i = lane; i < carry && i < 1024; i += 64) tail_out[i] = x[ii + i];
 }
 
-// ------------------------------------------------------------ hand-off solve
-// Policy for newton.h.  State components: (t = ii + mu, omega).  A residual of m
-// whole symbol periods is carried as a slip count (aux) that shifts all later chains.
-struct ClockPolicy {
-    ClockState *S;
-    const ClockState *E;
-    const float4 *J;
-    int *dirty;
-    const int *nrun;      // symbols chain k produced when it last ran
-    unsigned *cnt;        // [0] changed, [1] not frozen, [2] max |r_t| bits, [3] large, [4] sum r_t^2 (float)
-    float trust_t, trust_w, tol_t, tol_w;
-    int min_passes;
-
-    struct Elem { ClockState e, s; float4 j; int nrun; };
-    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], J[k], nrun[k]}; }
-    __device__ bool active(const Elem &el) const { return el.nrun > 0; }
-    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
-    {
-        float rt = clock_tdiff(el.e, el.s);
-        float m = rintf(rt / el.e.omega);
-        r1 = rt - m * el.e.omega;
-        r2 = el.e.omega - el.s.omega;
-        aux = (int)m;
-    }
-    __device__ float4 jac(const Elem &el) const
-    {
-        float4 j = el.j;
-        if (!(fabsf(j.x) < 4.f) || !(fabsf(j.y) < 16384.f) || !(fabsf(j.z) < 1.f) || !(fabsf(j.w) < 4.f))
-            j = make_float4(0.f, 0.f, 0.f, 0.f);
-        return j;
-    }
-    __device__ bool outside_trust(float d1, float d2) const
-    {
-        return !(fabsf(d1) <= trust_t) || !(fabsf(d2) <= trust_w);
-    }
-    // same idea as the Costas policy: a timing residual of a good part of a sample is an acquisition or slip
-    // transient, not something the finite-difference Jacobian describes
-    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.5f); }
-    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int slip, int slip_k,
-                           float r1, NewtonStat &st) const
-    {
-        const ClockState ek = el.e, old = el.s;
-        const bool hist_same = ek.p0.x == old.p0.x && ek.p0.y == old.p0.y && ek.p1.x == old.p1.x &&
-                               ek.p1.y == old.p1.y && ek.c0.x == old.c0.x && ek.c0.y == old.c0.y &&
-                               ek.c1.x == old.c1.x && ek.c1.y == old.c1.y;
-        if (!active(el)) {
-            // chain k produced nothing: its successor starts where it stands
-            const bool same = old.ii == ek.ii && old.mu == ek.mu && old.omega == ek.omega && hist_same;
-            if (!same) { S[k + 1] = ek; dirty[k + 1] = 1; st.changed += 1; }
-            return;
-        }
-        const bool frozen = fabsf(n1) <= tol_t && fabsf(n2) <= tol_w && slip == 0 && slip_k == 0 && hist_same;
-        if (frozen) return;
-        ClockState nw = ek;
-        clock_shift(nw, (float)slip * ek.omega + j1);
-        nw.omega = ek.omega + j2;
-        if (nw.ii < 0) { nw.ii = 0; nw.mu = 0.f; }
-        st.open_ += 1;
-        st.max_r = fmaxf(st.max_r, fabsf(r1));
-        if (fabsf(r1) > 0.02f || slip_k != 0) st.large += 1;
-        st.sum_sq += newton_fix(r1 * r1);
-        const bool same = old.ii == nw.ii && old.mu == nw.mu && old.omega == nw.omega && hist_same;
-        if (!same) { S[k + 1] = nw; dirty[k + 1] = 1; st.changed += 1; }
-    }
-    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] open boundaries, ctl[3] max residual (bits),
-    // ctl[4] previous summed squared residual (bits).  The recurrence is chaotic at the 1e-5 level
-    // (interpolator-arm quantisation), so boundaries keep moving by that much for ever; what must close are the
-    // LARGE residuals (acquisition at the head of a cold-started call, symbol slips: decision flips kick mu by up
-    // to ~2e-3, acquisition and slips leave residuals >> 0.02 samples).  After that the passes go on only while
-    // the summed squared residual still falls by > 45 % per pass.
-    __device__ void decide(int *ctl) const
-    {
-        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1);
-        const unsigned mr = newton_cnt_load(cnt + 2), large = newton_cnt_load(cnt + 3);
-        const unsigned long long sq = (unsigned long long)newton_cnt_load(cnt + 4) |
-                                      ((unsigned long long)newton_cnt_load(cnt + 5) << 32);
-        ctl[1] += 1;
-        ctl[2] = (int)open_;
-        ctl[3] = (int)mr;
-        const float q = newton_unfix(sq);
-        const float q_prev = ctl[1] == 1 ? INFINITY : __int_as_float(ctl[4]);
-        ctl[4] = __float_as_int(q);
-        ctl[5] = (large != 0 || __uint_as_float(mr) > 0.02f) ? 1 : 0;   // trust gate only while residuals are large
-        const int open_prev = ctl[1] == 1 ? 0x7fffffff : ctl[6];
-        ctl[6] = (int)open_;
-        if (changed == 0) { ctl[0] = 1; ctl[2] = 0; return; }
-        // "stalled" is the chaos floor only if the boundaries have also stopped freezing: at C2 112 653 of 113 266
-        // stay open from pass to pass (they move by 1e-5 for ever), whereas a call of a few dozen chains closes
-        // EXACTLY given the passes (20 -> 19 -> ... -> 0 open, then 3e-7 from the serial loop) and its summed
-        // residual does not fall monotonically on the way -- the stall test alone stopped such calls at 2e-3
-        // sample (fuzz at Es/N0 3..8 dB, HRIT: 5e-4..1e-3 rms, a hard decision flipped here and there).
-        // ... while the residuals are still above what the floor looks like at 12 dB (rms 1e-4 sample): a small call
-        // on a clean signal stops where a big one does (6 passes, 2e-4 from the serial loop) instead of running
-        // 15..25 passes of ~100 us each down to 1e-6.
-        // A call that is still acquiring timing (a residual beyond 0.02 sample two or more passes in) is also one in
-        // which the loop is far from its fixed point and sensitive: 4e-5 sample left at the hand-offs of such a call
-        // showed as 5e-3 in its symbols (fuzz: cold HRIT start, 3147 symbols, 14.7 dB).  It runs on while boundaries
-        // freeze, whatever the level.
-        int memo = ctl[7];
-        if (ctl[1] >= 3 && large != 0) memo |= 0x100;
-        const bool acquiring = (memo & 0x100) != 0;
-        const bool above_floor = open_ != 0u && (acquiring || q > 9e-8f * (float)open_);
-        const bool freezing = above_floor && open_prev != 0x7fffffff && (long long)open_prev - (long long)open_ >= 1 &&
-                              200ll * ((long long)open_prev - (long long)open_) >= (long long)open_prev;
-        // With a few thousand boundaries or fewer the summed residual is a noisy statistic (a handful of boundaries
-        // carry it): one pass without a 45 % fall is not yet the floor there, two in a row are.
-        const bool flat = q > 0.55f * q_prev;
-        const int flat_runs = flat ? (memo & 0xff) + 1 : 0;
-        ctl[7] = (memo & 0x100) | (flat_runs > 0xff ? 0xff : flat_runs);
-        const bool stalled = !freezing && (open_ >= 4096u ? flat : flat_runs >= 2);
-        if (ctl[1] >= min_passes && large == 0 && stalled) ctl[0] = 1;
-    }
-};
 
 __global__ void clk_fill_int_kernel(int *p, int v, int n)
 {
@@ -771,6 +847,41 @@ __global__ void __launch_bounds__(256) clock_reset_kernel(unsigned *counters, in
 {
     for (int i = threadIdx.x; i < words; i += 256) counters[i] = 0u;
     if (threadIdx.x == 0 && terminal) *terminal = 0x7fffffff;
+}
+
+// Mean chain Jacobian of a locked call (chains of the middle three quarters, entries the policy would accept), in a
+// fixed summation order.  The chain Jacobians of a locked stream scatter by 2 % around their mean, and the hand-off
+// converges with the mean just as it does with each chain's own (tests/experiments/clock_emulator.py), so the
+// finite-difference pass -- three trajectories per chain -- is run once per stream, not once per call.
+__global__ void __launch_bounds__(256) clock_jmean_kernel(const float4 *__restrict__ J, int K, float4 *__restrict__ out)
+{
+    __shared__ double acc[4][256];
+    __shared__ int cnt[256];
+    const int k0 = K / 8, k1 = K - K / 8;
+    double a = 0, b = 0, c = 0, d = 0;
+    int n = 0;
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += 256) {
+        const float4 j = J[k];
+        if (fabsf(j.x) < 4.f && fabsf(j.y) < 16384.f && fabsf(j.z) < 1.f && fabsf(j.w) < 4.f) {
+            a += j.x; b += j.y; c += j.z; d += j.w;
+            ++n;
+        }
+    }
+    acc[0][threadIdx.x] = a; acc[1][threadIdx.x] = b; acc[2][threadIdx.x] = c; acc[3][threadIdx.x] = d;
+    cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            for (int q = 0; q < 4; ++q) acc[q][threadIdx.x] += acc[q][threadIdx.x + off];
+            cnt[threadIdx.x] += cnt[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double inv = cnt[0] > 0 ? 1.0 / cnt[0] : 0.0;
+        out[0] = make_float4((float)(acc[0][0] * inv), (float)(acc[1][0] * inv), (float)(acc[2][0] * inv), (float)(acc[3][0] * inv));
+        reinterpret_cast<int *>(out + 1)[0] = cnt[0];
+    }
 }
 
 int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
@@ -798,7 +909,9 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     ClockState both[2] = {s0, s0};
     XR_HIP(hipMemcpy(st.p, both, sizeof both, hipMemcpyHostToDevice));
     XR_TRY(tail.reserve(2 * 1024 * sizeof(float2)));
-    XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
+    XR_TRY(jmean.reserve(64));
+    jmean_valid = false;
+    XR_TRY(counters.reserve((size_t)(max_passes + 8) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_res, 128));
     {
         int dev = 0, v = 0;
@@ -809,13 +922,14 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     }
     cur = 0;
     carry = 0;
+    force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     return XRIT_OK;
 }
 
 void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
-    work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release();
+    work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -842,26 +956,46 @@ int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
     return XRIT_OK;
 }
 
-// control block layout in `counters`: [0..8) ctl words, [8..16) ClockResult, per-pass counter slots from 16
+// control block layout in `counters`: [0..16) ctl words, [16..24) ClockResult, per-pass counter slots from 24
+constexpr int CLK_CTL_WORDS = 24;
 static inline int *clock_ctl(const DevBuf &b) { return b.as<int>(); }
-static inline ClockResult *clock_res(const DevBuf &b) { return reinterpret_cast<ClockResult *>(b.as<unsigned>() + 8); }
-static inline unsigned *clock_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + 16 + (size_t)pass * 8; }
+static inline ClockResult *clock_res(const DevBuf &b) { return reinterpret_cast<ClockResult *>(b.as<unsigned>() + 16); }
+static inline unsigned *clock_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + CLK_CTL_WORDS + (size_t)pass * 8; }
+
+// dynamic LDS beyond the default limit has to be asked for, once per kernel
+template <typename KernelT> static void clock_allow_lds(KernelT kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
     const Job &j = job;
     ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, nullptr,
-                    0.75f, 0.01f, tol_t, tol_w, min_passes};
-    const unsigned gridK = div_up((size_t)j.K, 64);
+                    0.75f, 0.01f, tol_t, tol_w, min_passes, j.mean_j ? jmean.as<float4>() : nullptr};
+    const unsigned nw = div_up((size_t)j.K, 64);              // waves of 64 chains
     const float2 *x = xbase();
+    // wave-aligned solve (newton.h): the pass leaves its waves' aggregates, one more launch applies them;
+    // `gated`: the three-launch solve with the trust gate (after a take-over, or when asked for)
+    const bool wave = !job.gated;
+    AffMap *aggs = wave ? wsolve.as<AffMap>() : nullptr;
+    NewtonStat *wslots = reinterpret_cast<NewtonStat *>(wsolve.as<AffMap>() + nw + 1);
     for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
         const int p = job.enqueued;
+        pol.cnt = clock_cnt(counters, p);
+        const bool jac = p < jac_passes && !j.mean_j;
         {
-            ProfScope ps(prof, p < jac_passes ? "clock_pass_jac" : "clock_pass", s);
+            ProfScope ps(prof, jac ? "clock_pass_jac" : "clock_pass", s);
 #define XR_CLK_PASS(NV, WPV, NCM)                                                                                     \
-    hipLaunchKernelGGL((clock_pass_kernel<NV, WPV, NCM>), dim3(gridK), dim3(64 * NV), j.tile_bytes, s, x,             \
-                       table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun,    \
-                       j.N, j.ni, j.K, NS, par, j.SS, j.W, j.WS, j.A, j.STEP, clock_ctl(counters))
+    do {                                                                                                              \
+        const size_t lds = NV > 1 ? j.tile_bytes3 : j.tile_bytes;                                                     \
+        clock_allow_lds(clock_pass_kernel<NV, WPV, NCM>, lds);                                                        \
+        hipLaunchKernelGGL((clock_pass_kernel<NV, WPV, NCM>), dim3(NV > 1 ? nw : div_up(nw, j.NG)),                   \
+                           dim3(NV > 1 ? 64 * NV : 64 * j.NG), lds, s, x, table.as<float>(), S.as<ClockState>(),      \
+                           E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, j.SS, j.W,   \
+                           j.WS, j.A, j.STEP, clock_ctl(counters), pol, aggs);                                        \
+    } while (0)
 #define XR_CLK_PASS_NV(NV)                                                                                            \
     do {                                                                                                              \
         if (!j.wide && narrow) XR_CLK_PASS(NV, 32, 20);                                                               \
@@ -869,20 +1003,22 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
         else XR_CLK_PASS(NV, 64, 64);                                                                                 \
     } while (0)
             const bool narrow = (j.STEP >> 16) + 1 <= 20;      // columns a sub-step adds to a ring
-            if (p < jac_passes) XR_CLK_PASS_NV(3);
+            if (jac) XR_CLK_PASS_NV(3);
             else XR_CLK_PASS_NV(1);
 #undef XR_CLK_PASS_NV
 #undef XR_CLK_PASS
         }
         {
             ProfScope ps(prof, "clock_solve", s);
-            pol.cnt = clock_cnt(counters, p);
-            if (newton_solve(pol, (long long)j.K - 1, work.as<AffMap>(), dlin.as<float2>(), clock_ctl(counters), s) != 0) {
+            if (wave) {
+                newton_apply_waves(pol, (long long)j.K - 1, aggs, clock_ctl(counters), wslots, s);
+            } else if (newton_solve(pol, (long long)j.K - 1, work.as<AffMap>(), dlin.as<float2>(), clock_ctl(counters), s) != 0) {
                 set_error("clock hand-off: %d chains exceed the solver's block budget", j.K);
                 return XRIT_E_INVALID;
             }
         }
     }
+    XR_HIP(hipGetLastError());
     return XRIT_OK;
 }
 
@@ -893,15 +1029,19 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
     const ClockState *st_in = st.as<ClockState>() + cur;
     ClockState *st_out = st.as<ClockState>() + (cur ^ 1);
     float2 *tail_out = tail.as<float2>() + 1024 * (cur ^ 1);
-    const unsigned gridK = div_up((size_t)j.K, 64);
+    const unsigned nw = div_up((size_t)j.K, 64);
     {
         ProfScope ps(prof, "clock_output", s);
         // (the first output pass of a call finds the marker set by clock_reset_kernel)
         if (again) hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
 #define XR_CLK_OUT_S(WPV, NCM, SYMV)                                                                                  \
-    hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(gridK), dim3(64), j.tile_bytes, s, x,              \
-                       table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts, j.soft, j.sym,            \
-                       (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W, j.WS, j.A, j.STEP)
+    do {                                                                                                              \
+        clock_allow_lds(clock_output_kernel<WPV, NCM, SYMV>, j.tile_bytes);                                           \
+        hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),            \
+                           j.tile_bytes, s, x, table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts,   \
+                           j.soft, j.sym, (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W,  \
+                           j.WS, j.A, j.STEP);                                                                        \
+    } while (0)
 #define XR_CLK_OUT(WPV, NCM)                              \
     do {                                                  \
         if (j.sym) XR_CLK_OUT_S(WPV, NCM, true);          \
@@ -917,7 +1057,7 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
                            st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
     XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     return XRIT_OK;
 }
 
@@ -928,6 +1068,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
 {
     passes = 0;
     unconverged = 0;
+    large_open = 0;
     max_residual = 0;
     job = Job{};
     Job &j = job;
@@ -954,7 +1095,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     }
     if (serial) {
         j.K = 1;
-        hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), 16, (int *)nullptr);
+        hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), CLK_CTL_WORDS, (int *)nullptr);
         {
             ProfScope ps(prof, "clock_serial", s);
             hipLaunchKernelGGL(clock_serial_kernel, dim3(1), dim3(64), 0, s, x, table.as<float>(),
@@ -962,7 +1103,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
                                sym_out, (unsigned long long)cap, j.N, j.ni, par, tail.as<float2>() + 1024 * (cur ^ 1));
         }
         XR_HIP(hipGetLastError());
-        XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         return XRIT_OK;
     }
     // chain budget: the slowest admissible symbol clock plus slack
@@ -982,8 +1123,21 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.wide = R > 32;
     j.SS = SS; j.W = R; j.A = A;
     j.STEP = (int)floor((double)SS * (double)par.omega_mid * 65536.0);
-    j.WS = R + 1;
-    j.tile_bytes = clock_tile_bytes(j.WS);
+    j.WS = R + CLK_ROW_EXTRA;
+    j.tile_bytes3 = clock_tile_bytes(j.WS, 1, 192);
+    // one-wave groups share the table: as many groups per workgroup as gives the CU the most waves (the rings
+    // fill LDS; two waves per SIMD is what the registers allow)
+    int waves_cu = 0;
+    j.NG = 1;
+    for (int ng = 1; ng <= 8; ++ng) {
+        const long long need = (long long)clock_tile_bytes(j.WS, ng, 64 * ng);
+        if (need > lds_per_cu) break;
+        long long wv = (long long)ng * (lds_per_cu / need);
+        if (wv > 8) wv = 8;
+        if (wv >= waves_cu) { waves_cu = (int)wv; j.NG = ng; }
+    }
+    if (waves_cu < 1) { set_error("clock recovery: a ring of %d samples per chain does not fit LDS", R); return XRIT_E_INVALID; }
+    j.tile_bytes = clock_tile_bytes(j.WS, j.NG, 64 * j.NG);
     if (auto_ns) {
         // One wave = 64 chains, and a wave's time is its chain length times a serial per-symbol latency: a pass
         // costs (generations of resident waves) x NS.  So the chain length is chosen from what the chip holds --
@@ -992,8 +1146,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         // chains lose more in the passes than their fewer hand-offs gain).  C2: 1792 resident waves, g = 1,
         // NS = 112 (the former 64 gave 1.66 generations = 2 x 64 symbol times per pass, and 190 k hand-offs
         // instead of 113 k).
-        const long long tile = ((long long)j.tile_bytes + 1279) / 1280 * 1280;
-        const long long resident = (long long)cu_count * (lds_per_cu / tile > 0 ? lds_per_cu / tile : 1);   // waves
+        const long long resident = (long long)cu_count * waves_cu;   // waves
         const double symbols = (double)j.N / min_omega;
         // (calls that do not fill the chip keep 64: 16-symbol chains would make their passes four times shorter,
         // but the fuzz runs found symbol slips and count mismatches with them at low Es/N0; 32-symbol chains are
@@ -1022,6 +1175,12 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     const int nbN = newton_blocks(K) > nbmax ? newton_blocks(K) : nbmax;
     XR_TRY(work.reserve((size_t)(3 * nbN + 8) * sizeof(AffMap)));
+    {
+        const size_t nw = div_up((size_t)K, 64);
+        XR_TRY(wsolve.reserve((nw + 2) * sizeof(AffMap) + (nw / 16 + 2) * sizeof(NewtonStat) + 64));
+        j.gated = force_gated;
+        j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !getenv("XRIT_NO_MEANJ");
+    }
     j.dirty = flags.as<int>();
     j.counts = flags.as<int>() + K;
     j.nrun = flags.as<int>() + 2 * K;
@@ -1029,7 +1188,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     const ClockState *st_in = st.as<ClockState>() + cur;
-    hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), (max_passes + 4) * 8, j.terminal);
+    hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), (max_passes + 5) * 8, j.terminal);
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
@@ -1074,8 +1233,10 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     const bool in_batch = closed();
     if (!in_batch) {
         while (hctl[0] == 0 && job.enqueued < max_passes) {
+            // a boundary outside the trust region (acquisition, a slip): from here on the gated three-launch solve
+            if (hctl[NEWTON_CTL_TAKEOVER]) job.gated = true;
             XR_TRY(enqueue_passes(4, s, prof));
-            XR_HIP(hipMemcpyAsync(h_res, counters.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
         }
         XR_TRY(enqueue_output(s, prof, true));
@@ -1091,7 +1252,17 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         const int want = passes + 1;
         batch = want < 5 ? 5 : (want > 32 ? 32 : want);   // (small calls run on while boundaries still freeze: 10..20 passes)
     }
+    if (job.K > 1) {
+        const bool clean = in_batch && hctl[NEWTON_CTL_TAKEOVER] == 0 && hctl[9] == 0 && passes <= 12;
+        if (job.mean_j && !clean) jmean_valid = false;           // the stream has changed: measure again
+        else if (!job.mean_j && !job.gated && clean && job.K >= 1024 && jac_passes > 0) {
+            hipLaunchKernelGGL(clock_jmean_kernel, dim3(1), dim3(256), 0, s, J.as<float4>(), job.K, jmean.as<float4>());
+            jmean_valid = true;
+            jmean_ns = NS;
+        }
+    }
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
+    large_open = job.K > 1 ? (unsigned)hctl[9] : 0;
     memcpy(&max_residual, &hctl[3], sizeof(float));
     if (getenv("XRIT_TRACE") && job.K > 1) {
         std::vector<unsigned> hc((size_t)passes * 8);
@@ -1108,7 +1279,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         }
     }
     ClockResult r;
-    memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + 8, sizeof r);
+    memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + 16, sizeof r);
     cur ^= 1;
     if (!r.ok && serial) {
         set_error("clock recovery produced more than the %zu symbols the output holds", job.cap);

@@ -22,6 +22,7 @@
 namespace xrit {
 
 constexpr int COSTAS_HEAD = 64;   // chains covered by the sequential coarse model
+constexpr int COSTAS_CTL_WORDS = 16;   // control words in front of the per-pass counter slots
 
 // ---------------------------------------------------------------- statistics
 // stat[k] = sum z^2 over chain k (squaring removes the BPSK modulation)
@@ -122,6 +123,103 @@ __global__ void costas_head_kernel(const float2 *__restrict__ stat, float2 *__re
     }
 }
 
+// ------------------------------------------------------------ hand-off solve
+// Policy for newton.h: the loop is pi-periodic in phase, so a residual of m*pi is
+// carried as a parity (aux) that shifts every later start by pi.
+struct CostasPolicy {
+    float2 *S;
+    const float2 *E;
+    const float4 *J;
+    int *dirty;
+    unsigned *cnt;           // [0] changed, [1] not frozen, [2] max |r_phase| bits
+    float trust_p, trust_f, tol_p, tol_f;
+    float accept, gate;      // stop test: accept when max residual <= accept; trust gate needed while > gate
+    const int *expansive;    // ctl[7]: some chain of this call saw the loop expansive
+    // In lock an error in a chain's start decays along the chain and the hand-off tolerance (1e-5 rad) is what is
+    // left of it in the output.  While the loop pulls in it is expansive for stretches (d phase / d start up to 2
+    // per chain over several chains in a row, more through a cycle slip): what one call leaves within tolerance
+    // the next one multiplies -- fuzz: cold start at -516 Hz cut in three short calls, first call 4e-6 off the
+    // serial loop, second 6e-4, third with two hard decisions flipped.  Such calls hand off three times tighter
+    // (first call 3e-7, second 4e-5: the floor the same amplification puts under the float32 differences of the
+    // two implementations); a locked stream never sees it.
+    __device__ float scale() const { return *expansive ? 0.3f : 1.0f; }
+
+    struct Elem { float2 e, s; float4 j; };
+    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], J[k]}; }
+    __device__ bool active(const Elem &) const { return true; }
+    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
+    {
+        float rp = el.e.x - el.s.x;
+        float m = rintf(rp * (float)(1.0 / XR_PI_D));
+        r1 = rp - m * (float)XR_PI_D;
+        r2 = el.e.y - el.s.y;
+        aux = ((int)m) & 1;
+    }
+    __device__ float4 jac(const Elem &el) const { return el.j; }
+    __device__ bool outside_trust(float d1, float d2) const
+    {
+        return !(fabsf(d1) <= trust_p) || !(fabsf(d2) <= trust_f);
+    }
+    // The loop's lock points are pi apart with an unstable equilibrium half way.  A residual beyond ~pi/8 means the
+    // next chain was started nearer to that than the tangent is good for (there it is expansive, and a Newton
+    // step through it lands on either side: boundaries then swap sides for ever -- seen on cold-started short
+    // calls, 1.5 rad residuals after 32 passes).  Such a boundary gets the plain hand-off; the correction that
+    // reaches it from upstream is dropped, and the region closes chain by chain.
+    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.4f); }
+    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int aux_prefix,
+                           int aux_k, float r1, NewtonStat &st) const
+    {
+        const int par = aux_prefix & 1;
+        const float amp = 1.0f / scale();
+        const bool frozen = fabsf(n1) * amp <= tol_p && fabsf(n2) * amp <= tol_f && par == 0 && (aux_k & 1) == 0;
+        if (frozen) return;
+        const float2 ek = el.e;
+        float2 nw = make_float2(ek.x + (par ? (float)XR_PI_D : 0.f) + j1, ek.y + j2);
+        const float2 old = el.s;
+        st.open_ += 1;
+        // what the stop test looks at: the hand-off residual r1 AND the whole Newton update n1 = r1 + (what reaches
+        // this boundary from upstream).  n1 estimates how far the start the last pass ran from was off; where the
+        // loop is not contractive (pull-in, near a cycle slip) small residuals add up along the chains, and a stop
+        // test on r1 alone closed calls whose output was 6e-4 away from the serial loop's (fuzz: cold start at
+        // -516 Hz in three short calls, two hard-decision flips behind it).
+        st.max_r = fmaxf(st.max_r, amp * fmaxf(fabsf(r1), fabsf(n1)));
+        st.sum_sq += newton_fix(r1 * r1);
+        if (nw.x != old.x || nw.y != old.y) {
+            S[k + 1] = nw;
+            dirty[k + 1] = 1;
+            st.changed += 1;
+        }
+    }
+    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits),
+    // ctl[4] max residual of the previous pass (bits), ctl[6] accepted on prediction: verify after the final pass.
+    // The residuals of the pass just run measure the starts it ran from; the Newton update this solve applied
+    // leaves ~C r^2 with C = r / r_prev^2 seen between the last two passes (C ~ 0.15 at C2: 6e-2 -> 7e-4 -> would
+    // be 1e-7).  Below ~1e-5 the residuals stop falling anyway: that is float32 rounding along a 256-sample chain,
+    // which no start state removes.  So when the predicted residual is well inside the acceptance, the next pass
+    // would only confirm it: the final pass runs from the updated starts right away, and costas_verify_kernel
+    // checks the residuals it leaves (against twice the acceptance: they ARE the rounding floor); if one is
+    // outside, the call goes on iterating.
+    __device__ void decide(int *ctl) const
+    {
+        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1), mr = newton_cnt_load(cnt + 2);
+        ctl[1] += 1;
+        ctl[2] = (int)open_;
+        const float max_r = __uint_as_float(mr);
+        ctl[3] = __float_as_int(max_r * scale());       // reported in radians
+        const float r_prev = ctl[1] >= 2 ? __int_as_float(ctl[4]) : 0.0f;
+        ctl[4] = (int)mr;
+        ctl[6] = 0;
+        // nothing moved, or what is still open sits within a factor two of the tolerance: accept
+        // (max_r comes in units of the scaled tolerance: update() multiplies by 1 / scale())
+        if (changed == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
+        else if (r_prev > 0.0f && max_r < 0.25f * r_prev && 4.0f * max_r * (max_r / r_prev) * (max_r / r_prev) <= accept) {
+            ctl[0] = 1;
+            ctl[6] = 1;
+        }
+        ctl[5] = max_r > gate ? 1 : 0;     // residuals this small cannot leave the trust region: skip the gate scan
+    }
+};
+
 // --------------------------------------------------------------------- pass
 // One wave = 64 chains, one lane per chain.  Samples move through LDS tiles of
 // COSTAS_CT samples per chain so that HBM sees coalesced 16-byte accesses
@@ -142,9 +240,11 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          float2 *__restrict__ state_out, long long n, int L, int K,
                                                          CostasGains g, double2 *__restrict__ om, long long om_off,
                                                          double inv_sps, float rot_c, float rot_s,
-                                                         int *__restrict__ ctl)
+                                                         int *__restrict__ ctl, CostasPolicy pol,
+                                                         AffMap *__restrict__ aggs)
 {
-    if (!FINAL && ctl[0]) return;     // the hand-off already closed: later passes of the batch are no-ops
+    // the hand-off already closed (later passes of the batch are no-ops), or the gated solve has taken over
+    if (!FINAL && (ctl[0] || (aggs != nullptr && ctl[NEWTON_CTL_TAKEOVER]))) return;
     __shared__ float2 tin[2][64][COSTAS_CT + 1];
     __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_OT * COSTAS_CT + 1];   // one 128-byte row per chain
     const int lane = threadIdx.x;
@@ -152,7 +252,11 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     const int k = kbase + lane;
     bool mine = k < K;
     if (!FINAL && mine) mine = dirty[k] != 0;
-    if (!__any(mine)) return;
+    const bool any_mine = __any(mine);
+    if (!any_mine && (FINAL || aggs == nullptr)) return;
+    float2 e_own = make_float2(0.f, 0.f);
+    float4 j_own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any_mine) {
     const long long base = (long long)k * L;
     int cnt = 0;
     float phase = 0.f, freq = 0.f;
@@ -266,117 +370,36 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
         if (tile + 1 < nt) stash(cur ^ 1);
         __syncthreads();
     }
-    if (!mine) return;
+    if (mine) {
     if (FINAL) {
         if (k == K - 1) state_out[0] = make_float2(phase, freq);
         if (om != nullptr) om[k] = make_double2((double)om_r, (double)om_i);
         E[k] = make_float2(phase, freq);        // costas_verify_kernel checks the hand-off that was actually used
     } else {
-        E[k] = make_float2(phase, freq);
-        J[k] = make_float4(t.pp, t.pf, t.fp, t.ff);
+        e_own = make_float2(phase, freq);
+        j_own = make_float4(t.pp, t.pf, t.fp, t.ff);
+        E[k] = e_own;
+        J[k] = j_own;
         // a chain in which the loop is expansive for a while (pull-in, a cycle slip: never in lock, where amp is
         // exactly 1) puts the whole call on the tight tolerances, see CostasPolicy::scale
         if (amp > XR_AMP_THR && ctl[7] == 0) ctl[7] = 1;
         dirty[k] = 0;
     }
+    }
+    }   // any_mine
+    if (FINAL || aggs == nullptr) return;
+    // wave-aligned hand-off solve (newton.h): compose this wave's 64 boundary maps; the last workgroup scans
+    AffMap e = aff_identity();
+    if (k < K - 1) {
+        CostasPolicy::Elem el;
+        el.s = S[k + 1];
+        if (mine) { el.e = e_own; el.j = j_own; }
+        else { el.e = E[k]; el.j = J[k]; }
+        e = newton_element(pol, el, false);
+    }
+    newton_wave_aggregate(e, (int)blockIdx.x, aggs);
 }
 
-// ------------------------------------------------------------ hand-off solve
-// Policy for newton.h: the loop is pi-periodic in phase, so a residual of m*pi is
-// carried as a parity (aux) that shifts every later start by pi.
-struct CostasPolicy {
-    float2 *S;
-    const float2 *E;
-    const float4 *J;
-    int *dirty;
-    unsigned *cnt;           // [0] changed, [1] not frozen, [2] max |r_phase| bits
-    float trust_p, trust_f, tol_p, tol_f;
-    float accept, gate;      // stop test: accept when max residual <= accept; trust gate needed while > gate
-    const int *expansive;    // ctl[7]: some chain of this call saw the loop expansive
-    // In lock an error in a chain's start decays along the chain and the hand-off tolerance (1e-5 rad) is what is
-    // left of it in the output.  While the loop pulls in it is expansive for stretches (d phase / d start up to 2
-    // per chain over several chains in a row, more through a cycle slip): what one call leaves within tolerance
-    // the next one multiplies -- fuzz: cold start at -516 Hz cut in three short calls, first call 4e-6 off the
-    // serial loop, second 6e-4, third with two hard decisions flipped.  Such calls hand off three times tighter
-    // (first call 3e-7, second 4e-5: the floor the same amplification puts under the float32 differences of the
-    // two implementations); a locked stream never sees it.
-    __device__ float scale() const { return *expansive ? 0.3f : 1.0f; }
-
-    struct Elem { float2 e, s; float4 j; };
-    __device__ Elem fetch(long long k) const { return Elem{E[k], S[k + 1], J[k]}; }
-    __device__ bool active(const Elem &) const { return true; }
-    __device__ void residual(const Elem &el, float &r1, float &r2, int &aux) const
-    {
-        float rp = el.e.x - el.s.x;
-        float m = rintf(rp * (float)(1.0 / XR_PI_D));
-        r1 = rp - m * (float)XR_PI_D;
-        r2 = el.e.y - el.s.y;
-        aux = ((int)m) & 1;
-    }
-    __device__ float4 jac(const Elem &el) const { return el.j; }
-    __device__ bool outside_trust(float d1, float d2) const
-    {
-        return !(fabsf(d1) <= trust_p) || !(fabsf(d2) <= trust_f);
-    }
-    // The loop's lock points are pi apart with an unstable equilibrium half way.  A residual beyond ~pi/8 means the
-    // next chain was started nearer to that than the tangent is good for (there it is expansive, and a Newton
-    // step through it lands on either side: boundaries then swap sides for ever -- seen on cold-started short
-    // calls, 1.5 rad residuals after 32 passes).  Such a boundary gets the plain hand-off; the correction that
-    // reaches it from upstream is dropped, and the region closes chain by chain.
-    __device__ bool distrust(float r1, float) const { return !(fabsf(r1) <= 0.4f); }
-    __device__ void update(long long k, const Elem &el, float j1, float j2, float n1, float n2, int aux_prefix,
-                           int aux_k, float r1, NewtonStat &st) const
-    {
-        const int par = aux_prefix & 1;
-        const float amp = 1.0f / scale();
-        const bool frozen = fabsf(n1) * amp <= tol_p && fabsf(n2) * amp <= tol_f && par == 0 && (aux_k & 1) == 0;
-        if (frozen) return;
-        const float2 ek = el.e;
-        float2 nw = make_float2(ek.x + (par ? (float)XR_PI_D : 0.f) + j1, ek.y + j2);
-        const float2 old = el.s;
-        st.open_ += 1;
-        // what the stop test looks at: the hand-off residual r1 AND the whole Newton update n1 = r1 + (what reaches
-        // this boundary from upstream).  n1 estimates how far the start the last pass ran from was off; where the
-        // loop is not contractive (pull-in, near a cycle slip) small residuals add up along the chains, and a stop
-        // test on r1 alone closed calls whose output was 6e-4 away from the serial loop's (fuzz: cold start at
-        // -516 Hz in three short calls, two hard-decision flips behind it).
-        st.max_r = fmaxf(st.max_r, amp * fmaxf(fabsf(r1), fabsf(n1)));
-        st.sum_sq += newton_fix(r1 * r1);
-        if (nw.x != old.x || nw.y != old.y) {
-            S[k + 1] = nw;
-            dirty[k + 1] = 1;
-            st.changed += 1;
-        }
-    }
-    // After every solve: ctl[0] done, ctl[1] passes run, ctl[2] boundaries still open, ctl[3] max residual (bits),
-    // ctl[4] max residual of the previous pass (bits), ctl[6] accepted on prediction: verify after the final pass.
-    // The residuals of the pass just run measure the starts it ran from; the Newton update this solve applied
-    // leaves ~C r^2 with C = r / r_prev^2 seen between the last two passes (C ~ 0.15 at C2: 6e-2 -> 7e-4 -> would
-    // be 1e-7).  Below ~1e-5 the residuals stop falling anyway: that is float32 rounding along a 256-sample chain,
-    // which no start state removes.  So when the predicted residual is well inside the acceptance, the next pass
-    // would only confirm it: the final pass runs from the updated starts right away, and costas_verify_kernel
-    // checks the residuals it leaves (against twice the acceptance: they ARE the rounding floor); if one is
-    // outside, the call goes on iterating.
-    __device__ void decide(int *ctl) const
-    {
-        const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1), mr = newton_cnt_load(cnt + 2);
-        ctl[1] += 1;
-        ctl[2] = (int)open_;
-        const float max_r = __uint_as_float(mr);
-        ctl[3] = __float_as_int(max_r * scale());       // reported in radians
-        const float r_prev = ctl[1] >= 2 ? __int_as_float(ctl[4]) : 0.0f;
-        ctl[4] = (int)mr;
-        ctl[6] = 0;
-        // nothing moved, or what is still open sits within a factor two of the tolerance: accept
-        // (max_r comes in units of the scaled tolerance: update() multiplies by 1 / scale())
-        if (changed == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
-        else if (r_prev > 0.0f && max_r < 0.25f * r_prev && 4.0f * max_r * (max_r / r_prev) * (max_r / r_prev) <= accept) {
-            ctl[0] = 1;
-            ctl[6] = 1;
-        }
-        ctl[5] = max_r > gate ? 1 : 0;     // residuals this small cannot leave the trust region: skip the gate scan
-    }
-};
 
 // After the final pass of a hand-off that was accepted on prediction (ctl[6]): the residuals its starts leave
 // must be inside the acceptance, else the call is not closed (ctl[0] = 0) and the host goes on iterating.
@@ -408,8 +431,9 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     max_passes = max_passes_ > 0 ? max_passes_ : 192;
     XR_TRY(state.reserve(2 * sizeof(float2)));
     XR_HIP(hipMemset(state.p, 0, 2 * sizeof(float2)));
-    XR_TRY(counters.reserve((size_t)(max_passes + 4) * 8 * sizeof(unsigned)));
-    XR_HIP(hipHostMalloc((void **)&h_counters, 8 * sizeof(unsigned)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
+    XR_HIP(hipHostMalloc((void **)&h_counters, COSTAS_CTL_WORDS * sizeof(unsigned)));
+    force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     cur = 0;
     return XRIT_OK;
 }
@@ -417,7 +441,7 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 void CostasStage::release()
 {
     state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();
-    work.release(); flags.release(); counters.release();
+    work.release(); flags.release(); counters.release(); wsolve.release();
     if (h_counters) (void)hipHostFree(h_counters);
     h_counters = nullptr;
 }
@@ -432,9 +456,10 @@ int CostasStage::get_state(float *phase, float *freq, hipStream_t s)
     return XRIT_OK;
 }
 
-// control block: counters[0..8) = ctl words, per-pass counter slots after it
+// control block: counters[0..16) = ctl words, per-pass counter slots after it
+
 static inline int *costas_ctl(const DevBuf &b) { return b.as<int>(); }
-static inline unsigned *costas_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + 8 + (size_t)pass * 8; }
+static inline unsigned *costas_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + COSTAS_CTL_WORDS + (size_t)pass * 8; }
 
 int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
@@ -442,17 +467,24 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
     CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
                      tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7};
     const unsigned gridK = div_up((size_t)job.K, 64);
+    // wave-aligned solve (newton.h) unless this call has gone over to the gated three-launch one
+    const bool wave = !job.gated;
+    const int nw = (int)gridK;
+    AffMap *aggs = wave ? wsolve.as<AffMap>() : nullptr;
+    NewtonStat *wslots = reinterpret_cast<NewtonStat *>(wsolve.as<AffMap>() + nw + 1);
     for (int q = 0; q < count && job.enqueued < max_passes; ++q, ++job.enqueued) {
+        pol.cnt = costas_cnt(counters, job.enqueued);
         {
             ProfScope ps(prof, "costas_pass", s);
             hipLaunchKernelGGL(costas_pass_kernel<false>, dim3(gridK), dim3(64), 0, s, job.in, job.out, S.as<float2>(),
                                E.as<float2>(), J.as<float4>(), flags.as<int>(), (float2 *)nullptr, (long long)job.n, L,
-                               job.K, gains, (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f, costas_ctl(counters));
+                               job.K, gains, (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f, costas_ctl(counters), pol, aggs);
         }
         {
             ProfScope ps(prof, "costas_solve", s);
-            pol.cnt = costas_cnt(counters, job.enqueued);
-            if (newton_solve(pol, nel, work.as<AffMap>(), dlin.as<float2>(), costas_ctl(counters), s) != 0) {
+            if (wave) {
+                newton_apply_waves(pol, nel, aggs, costas_ctl(counters), wslots, s);
+            } else if (newton_solve(pol, nel, work.as<AffMap>(), dlin.as<float2>(), costas_ctl(counters), s) != 0) {
                 set_error("Costas hand-off: %d chains exceed the solver's block budget", job.K);
                 return XRIT_E_INVALID;
             }
@@ -469,14 +501,14 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
     hipLaunchKernelGGL(costas_pass_kernel<true>, dim3(div_up((size_t)job.K, 64)), dim3(64), 0, s, job.in, job.out,
                        S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)job.n, L,
                        job.K, gains, job.om, job.om_off, job.inv_sps, (float)cos(dth), (float)sin(dth),
-                       costas_ctl(counters));
+                       costas_ctl(counters), CostasPolicy{}, (AffMap *)nullptr);
     if (job.K > 1) {
         CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
                          tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7};
         hipLaunchKernelGGL(costas_verify_kernel, dim3(div_up((size_t)job.K - 1, 256)), dim3(256), 0, s, pol,
                            (long long)job.K - 1, costas_ctl(counters));
     }
-    XR_HIP(hipMemcpyAsync(h_counters, counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     XR_HIP(hipGetLastError());
     return XRIT_OK;
 }
@@ -506,8 +538,13 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     const size_t agg_bytes = (((size_t)(3 * newton_blocks(K) + 6) * sizeof(AffMap)) + 15) & ~(size_t)15;
     XR_TRY(dlin.reserve((size_t)(K + 1) * sizeof(float2)));
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
+    {
+        const size_t nw = div_up((size_t)K, 64);
+        XR_TRY(wsolve.reserve((nw + 2) * sizeof(AffMap) + (nw / 16 + 2) * sizeof(NewtonStat) + 64));
+        job.gated = force_gated;
+    }
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
-    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 2) * 8 * sizeof(unsigned), s));
+    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
@@ -553,8 +590,9 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
     if (!in_batch) {
         if (redone) *redone = true;
         while (h_counters[0] == 0 && job.enqueued < max_passes) {
+            if (h_counters[NEWTON_CTL_TAKEOVER]) job.gated = true;     // a boundary outside the trust region
             XR_TRY(enqueue_passes(2, s, prof));
-            XR_HIP(hipMemcpyAsync(h_counters, counters.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
         }
         XR_TRY(enqueue_final(s, prof));

@@ -360,7 +360,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     int rc = XRIT_OK;
     d->agc_fallback_seen = false;
     int worst_cp = 0, worst_kp = 0;
-    unsigned unc_c = 0, unc_k = 0;
+    unsigned unc_c = 0, unc_k = 0, large_k = 0;
     float res_c = 0, res_k = 0;
     SliceIO io[2];
     hipStream_t s2 = d->stream2;
@@ -397,6 +397,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         worst_kp = d->clock.passes > worst_kp ? d->clock.passes : worst_kp;
         unc_c += d->costas.unconverged;
         unc_k += d->clock.unconverged;
+        large_k += d->clock.large_open;
         res_c = d->costas.max_residual > res_c ? d->costas.max_residual : res_c;
         res_k = d->clock.max_residual > res_k ? d->clock.max_residual : res_k;
     }
@@ -413,10 +414,15 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.costas_max_residual = res_c;
     d->stats.clock_max_residual = res_k;
     d->stats.agc_serial_fallback = d->agc_fallback_seen;
+    d->stats.clock_open_large = large_k;
     *n_out = total_sym;
     if (rc != XRIT_OK) return rc;
     if (d->cfg.strict && unc_c) {
         set_error("Costas hand-off did not close: %u boundaries above tolerance", unc_c);
+        return XRIT_E_NOT_CONVERGED;
+    }
+    if (d->cfg.strict && large_k) {
+        set_error("clock hand-off ended with %u boundaries beyond 0.02 sample or with an open symbol slip", large_k);
         return XRIT_E_NOT_CONVERGED;
     }
     return XRIT_OK;

@@ -84,7 +84,8 @@ struct CostasStage {
     int max_passes = 32;
     float trust = 1.0f, tol_phase = 1e-5f, tol_freq = 3e-8f;
     DevBuf state;           // float2 (phase, freq) carried across calls
-    DevBuf S, E, J, stat, dlin, work, flags, counters;
+    DevBuf S, E, J, stat, dlin, work, flags, counters, wsolve;
+    bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1)
     unsigned *h_counters = nullptr;   // pinned
     int cur = 0;
     int passes = 0;
@@ -107,6 +108,7 @@ struct CostasStage {
     struct Job {
         const float2 *in = nullptr; float2 *out = nullptr; size_t n = 0; int K = 0; int enqueued = 0;
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
+        bool gated = false;     // this call has gone over to the gated solve
     } job;
     int batch = 4;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
@@ -131,14 +133,18 @@ struct ClockStage {
     // sits right-aligned in front of it.  Unaligned, every output row straddled two lines (partial-line writes).
     float2 *xbase() const { return xbuf.as<float2>() + (16 - carry % 16) % 16; }
     DevBuf st;              // carried ClockState + carry count
-    DevBuf S, E, J, om, work, counters, sym, dlin, flags;
+    DevBuf S, E, J, om, work, counters, sym, dlin, flags, wsolve, jmean;
+    bool jmean_valid = false;         // jmean holds the mean chain Jacobian of an earlier, locked call with ...
+    int jmean_ns = 0;                 // ... this chain length
+    bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1: A/B runs)
     DevBuf tail;                      // 2 x 1024 samples left unread by a call (ping-pong with the state)
     void *h_res = nullptr;            // pinned copy of the control block + result
     float tol_t = 2e-6f, tol_w = 2e-7f;
     int cur = 0;
     size_t carry = 0;       // samples held over from the previous call
     int passes = 0;
-    unsigned unconverged = 0;
+    unsigned unconverged = 0;   // boundaries the last solve still moved (~all of them on any healthy call: the floor)
+    unsigned large_open = 0;    // boundaries left with a residual beyond 0.02 sample or an open symbol slip
     float max_residual = 0;
     size_t last_symbols = 0;
     int init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
@@ -161,7 +167,10 @@ struct ClockStage {
     struct Job {
         size_t n = 0, cap = 0; float *soft = nullptr; float2 *sym = nullptr;
         long long N = 0, ni = 0; int K = 0, enqueued = 0, SS = 0, W = 0, WS = 0, A = 0, STEP = 0; bool wide = false, short_input = false;
-        size_t tile_bytes = 0;
+        size_t tile_bytes = 0, tile_bytes3 = 0;   // one-wave groups (NG per workgroup) / the three-wave Jacobian pass
+        int NG = 1;
+        bool mean_j = false;    // the passes use the stream's mean Jacobian: no finite-difference pass
+        bool gated = false;     // this call has gone over to the gated solve
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one

@@ -186,12 +186,12 @@ struct ClockState {
 #define XR_MM_INTERPOLATE(ROW, W, AR, AI)                                        \
     do {                                                                         \
         typedef float __attribute__((ext_vector_type(2))) xr_f2_;                \
-        xr_f2_ a_ = {0.0f, 0.0f};                                                \
+        xr_f2_ a_;                                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < XR_MM_NTAPS; ++k_) {             \
             const float tp_ = (float)(ROW)[XR_MM_NTAPS - 1 - k_];                \
             const cf32 v_ = (W)[k_];                                             \
             const xr_f2_ vv_ = {v_.x, v_.y};                                     \
-            a_ = a_ + vv_ * tp_;                                                 \
+            a_ = k_ == 0 ? vv_ * tp_ : a_ + vv_ * tp_;   /* 0 + p == p */        \
         }                                                                        \
         AR = a_.x;                                                               \
         AI = a_.y;                                                               \

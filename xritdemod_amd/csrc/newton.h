@@ -381,6 +381,185 @@ __global__ void __launch_bounds__(NEWTON_SMALL_BLOCK) newton_small_kernel(P p, l
     }
 }
 
+// ---- wave-aligned solve: the steady-state path ---------------------------------------------------------------
+// The three launches above cost a burst ~60 us per pass in launch latency alone (kernel time 36 us, of which 13 are
+// spent re-reading what the pass kernel just had in registers).  Here the pass kernel itself leaves, per wave of 64
+// chains, the composition of its 64 boundary maps (newton_wave_aggregate) -- a few thousand aggregates per burst --
+// and ONE launch applies the step: every workgroup (16 waves = 1024 boundaries) scans the aggregates in front of
+// its own waves in LDS (two per thread at C2, ten Hillis-Steele steps), each wave recomputes its 64 maps, scans
+// them with shuffles and starts from its prefix.  (Measured and dropped: the scan done by the workgroup of the
+// pass kernel that finishes last -- one wave walking 1770 aggregates is a chain of ~56 memory latencies, +70 us
+// per pass.)  The trust gate needs the un-gated solution first and a second global scan; this path has none: a
+// wave that finds a boundary outside the trust region raises ctl[NEWTON_CTL_TAKEOVER] and the host continues with
+// the gated three-launch solve (acquisition, cold starts: the calls that need a host round trip per batch anyway).
+// Boundary k sits between chains k and k + 1; wave w covers boundaries [64 w, 64 w + 64).
+constexpr int NEWTON_CTL_TAKEOVER = 8;   // control word: the wave-aligned path met a boundary outside the trust region
+constexpr int NEWTON_WAVES_BLOCK = 1024;
+constexpr int NEWTON_WAVES_PER_BLOCK = NEWTON_WAVES_BLOCK / 64;
+
+__device__ __forceinline__ AffMap aff_shfl_down(const AffMap &v, int off)
+{
+    AffMap r;
+    r.a11 = __shfl_down(v.a11, off, 64); r.a12 = __shfl_down(v.a12, off, 64);
+    r.a21 = __shfl_down(v.a21, off, 64); r.a22 = __shfl_down(v.a22, off, 64);
+    r.b1 = __shfl_down(v.b1, off, 64); r.b2 = __shfl_down(v.b2, off, 64);
+    r.aux = __shfl_down(v.aux, off, 64);
+    return r;
+}
+__device__ __forceinline__ AffMap aff_shfl_up(const AffMap &v, int off)
+{
+    AffMap r;
+    r.a11 = __shfl_up(v.a11, off, 64); r.a12 = __shfl_up(v.a12, off, 64);
+    r.a21 = __shfl_up(v.a21, off, 64); r.a22 = __shfl_up(v.a22, off, 64);
+    r.b1 = __shfl_up(v.b1, off, 64); r.b2 = __shfl_up(v.b2, off, 64);
+    r.aux = __shfl_up(v.aux, off, 64);
+    return r;
+}
+__device__ __forceinline__ AffMap aff_shfl(const AffMap &v, int src)
+{
+    AffMap r;
+    r.a11 = __shfl(v.a11, src, 64); r.a12 = __shfl(v.a12, src, 64);
+    r.a21 = __shfl(v.a21, src, 64); r.a22 = __shfl(v.a22, src, 64);
+    r.b1 = __shfl(v.b1, src, 64); r.b2 = __shfl(v.b2, src, 64);
+    r.aux = __shfl(v.aux, src, 64);
+    return r;
+}
+
+// inclusive scan over the wave (lane order = boundary order)
+__device__ __forceinline__ AffMap aff_wave_scan(AffMap v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const AffMap lo = aff_shfl_up(v, off);
+        if (lane >= off) v = aff_combine(lo, v);
+    }
+    return v;
+}
+
+// Epilogue of a pass kernel, called by the wave that holds chains [64 w, 64 w + 64) with `e` = this lane's boundary
+// map (identity beyond the last boundary): the ordered composition of the 64 maps goes to aggs[w].
+__device__ __forceinline__ void newton_wave_aggregate(AffMap e, int w, AffMap *aggs)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const AffMap hi = aff_shfl_down(e, off);
+        e = aff_combine(e, hi);          // lanes whose partner is out of range hold garbage nobody reads
+    }
+    if ((threadIdx.x & 63) == 0) aggs[w] = e;
+}
+
+template <typename P>
+__global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(P p, long long n, const AffMap *aggs,
+                                                                               int *ctl, NewtonStat *slots)
+{
+    if (ctl[0] || ctl[NEWTON_CTL_TAKEOVER]) return;
+    __shared__ AffMap buf[NEWTON_WAVES_BLOCK];
+    __shared__ NewtonStat wst[NEWTON_WAVES_PER_BLOCK];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int w0 = blockIdx.x * NEWTON_WAVES_PER_BLOCK;         // first wave of this workgroup
+    const int w = w0 + wib;
+    const long long k = (long long)w * 64 + lane;
+    // this lane's boundary first: its loads overlap the scan below
+    const typename P::Elem el = p.fetch(k < n ? k : n - 1);
+    // composition of the aggregates [0, w) for every wave of the workgroup: thread t composes a run of consecutive
+    // aggregates, the workgroup scans the runs, a wave finishes from the run boundary in front of it
+    const int nw = (int)((n + 63) / 64);
+    const int need = min(nw, w0 + NEWTON_WAVES_PER_BLOCK);      // aggregates [0, need) are looked at
+    const int run = (need + NEWTON_WAVES_BLOCK - 1) / NEWTON_WAVES_BLOCK;
+    {
+        const int b0 = (int)threadIdx.x * run, b1 = min(need, b0 + run);
+        AffMap v = aff_identity();
+        for (int b = b0; b < b1; ++b) v = aff_combine(v, aggs[b]);
+        aff_block_scan<NEWTON_WAVES_BLOCK>(v, buf);              // buf[t] = aggregates [0, (t + 1) run)
+    }
+    NewtonStat st{0u, 0u, 0u, 0.f, 0ull};
+    if ((long long)w * 64 < n) {
+        const int t0 = w / run;                                 // run that holds aggregate w
+        AffMap pre = t0 > 0 ? buf[t0 - 1] : aff_identity();
+        for (int b = t0 * run; b < w; ++b) pre = aff_combine(pre, aggs[b]);
+        const AffMap e = k < n ? newton_element(p, el, false) : aff_identity();
+        const AffMap inc = aff_wave_scan(e);
+        AffMap ex = aff_shfl_up(inc, 1);
+        if (lane == 0) ex = aff_identity();
+        // delta[0] = 0: delta at this lane's boundary = (everything in front of it)(0)
+        const float d1 = ex.a11 * pre.b1 + ex.a12 * pre.b2 + ex.b1, d2 = ex.a21 * pre.b1 + ex.a22 * pre.b2 + ex.b2;
+        const int aux = pre.aux + ex.aux;
+        const bool out = k < n && p.active(el) && p.outside_trust(d1, d2);
+        if (__any(out)) {
+            // the linearisation is not believed this far out: the gated solve takes over (host side)
+            if (lane == 0) atomicExch(&ctl[NEWTON_CTL_TAKEOVER], 1);
+        } else if (k < n) {
+            const float j1 = e.a11 * d1 + e.a12 * d2, j2 = e.a21 * d1 + e.a22 * d2;
+            p.update(k, el, j1, j2, e.b1 + j1, e.b2 + j2, aux, e.aux, e.b1, st);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        st.changed += __shfl_down(st.changed, off, 64);
+        st.open_ += __shfl_down(st.open_, off, 64);
+        st.large += __shfl_down(st.large, off, 64);
+        st.max_r = fmaxf(st.max_r, __shfl_down(st.max_r, off, 64));
+        st.sum_sq += (unsigned long long)__shfl_down((long long)st.sum_sq, off, 64);
+    }
+    if (lane == 0) wst[wib] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        NewtonStat t = wst[0];
+        for (int q = 1; q < NEWTON_WAVES_PER_BLOCK; ++q) {
+            t.changed += wst[q].changed; t.open_ += wst[q].open_; t.large += wst[q].large;
+            t.max_r = fmaxf(t.max_r, wst[q].max_r); t.sum_sq += wst[q].sum_sq;
+        }
+        slots[blockIdx.x] = t;
+        is_last = __hip_atomic_fetch_add(&p.cnt[7], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    NewtonStat t{0u, 0u, 0u, 0.f, 0ull};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += NEWTON_WAVES_BLOCK) {
+        const NewtonStat o = slots[b];
+        t.changed += o.changed; t.open_ += o.open_; t.large += o.large;
+        t.max_r = fmaxf(t.max_r, o.max_r); t.sum_sq += o.sum_sq;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        t.changed += __shfl_down(t.changed, off, 64);
+        t.open_ += __shfl_down(t.open_, off, 64);
+        t.large += __shfl_down(t.large, off, 64);
+        t.max_r = fmaxf(t.max_r, __shfl_down(t.max_r, off, 64));
+        t.sum_sq += (unsigned long long)__shfl_down((long long)t.sum_sq, off, 64);
+    }
+    __syncthreads();
+    if (lane == 0) wst[wib] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t = wst[0];
+        for (int q = 1; q < NEWTON_WAVES_PER_BLOCK; ++q) {
+            t.changed += wst[q].changed; t.open_ += wst[q].open_; t.large += wst[q].large;
+            t.max_r = fmaxf(t.max_r, wst[q].max_r); t.sum_sq += wst[q].sum_sq;
+        }
+        p.cnt[0] = t.changed;
+        p.cnt[1] = t.open_;
+        p.cnt[2] = t.open_ ? __float_as_uint(t.max_r) : 0u;
+        p.cnt[3] = t.large;
+        *reinterpret_cast<unsigned long long *>(&p.cnt[4]) = t.open_ ? t.sum_sq : 0ull;
+        __threadfence();
+        if (!__hip_atomic_load(&ctl[NEWTON_CTL_TAKEOVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) p.decide(ctl);
+    }
+}
+
+static inline int newton_waves(long long n) { return (int)((n + 63) / 64); }
+// storage: newton_waves(n) AffMaps (aggregates) and newton_waves(n) / 16 + 1 NewtonStat slots
+template <typename P>
+static inline void newton_apply_waves(const P &p, long long n, const AffMap *aggs, int *ctl, NewtonStat *slots,
+                                      hipStream_t s)
+{
+    if (n <= 0) return;
+    const int nw = newton_waves(n);
+    hipLaunchKernelGGL(newton_apply_waves_kernel<P>, dim3((nw + NEWTON_WAVES_PER_BLOCK - 1) / NEWTON_WAVES_PER_BLOCK),
+                       dim3(NEWTON_WAVES_BLOCK), 0, s, p, n, aggs, ctl, slots);
+}
+
 static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
 
 // agg storage: 3 * (blocks + 1) AffMaps (two sets of block aggregates, one statistics slot per block); dlin: n + 1 float2
