@@ -92,9 +92,8 @@ typedef struct xrit_demod_config {
     int32_t  strict;            /* 1: XRIT_E_NOT_CONVERGED when the Costas hand-off stays above its tolerance or the
                                  * clock hand-off ends with large residuals / open slips (stats.clock_open_large) */
     int32_t  clock_min_passes;  /* clock hand-off passes always run (0 = default); max_passes caps both loops */
-    int32_t  slices;            /* > 1: cut a large call into that many time slices so that the front end of one
-                                   overlaps the loops of the previous on a second stream (0/1 = off, the default:
-                                   measured slower on MI355X, see demod.cpp) */
+    int32_t  slices;            /* ignored (round 1 could cut a call into time slices on two streams; measured slower
+                                   on MI355X and removed) */
     int32_t  clock_serial;      /* 1: the clock recovery runs as ONE serial trajectory on the device (a single wave,
                                  * ~0.3 us per symbol) instead of time-tiled chains: no hand-offs, so what is left
                                  * against the CPU chain is what any float32 M&M fed by this chain's Costas output
@@ -114,7 +113,9 @@ void xrit_demod_destroy(xrit_demod *d);
  * (:136-140, n/decimation outputs, remainder dropped), AGC (:143), RRC (:148),
  * Costas (:152), clock recovery (:156); soft_out receives Re(symbol)
  * (SymbolManager.cpp:104).  State persists across calls like the SatHelper
- * objects.  cap must be >= n/(decimation*sps*0.99)+64 (checked before anything runs).
+ * objects.  cap must be >= n/(decimation*sps*0.99)+64: a smaller one is refused before anything runs
+ * (XRIT_E_CAPACITY, n_out = a capacity that suffices, the handle unchanged).  A call that fails later, after a
+ * stage has advanced its carried state, leaves the handle unusable (every further call returns XRIT_E_INVALID).
  * Host buffers. */
 int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int sample_type,
                        float *soft_out, size_t cap, size_t *n_out);
@@ -253,6 +254,14 @@ typedef struct xrit_synth_params {
 void xrit_synth_defaults(xrit_synth_params *p);
 int  xrit_synth_generate_device(const xrit_synth_params *p, uint64_t start, size_t n,
                                 float *d_out_interleaved, int device, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement helper ("also measure a device read microbenchmark
+ * on the box and report both"): GB/s of a hand-written read-only sweep over a
+ * device buffer, `reps` sweeps timed with HIP events on `stream`.  Not part of
+ * the reference's interface.
+ * ------------------------------------------------------------------------ */
+int xrit_device_read_bandwidth(const void *d_buf, size_t bytes, int reps, int device, void *stream, double *gb_per_s);
 
 #ifdef __cplusplus
 }

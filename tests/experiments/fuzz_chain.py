@@ -60,6 +60,19 @@ for c in range(cases):
             ok = False
     w, g = np.concatenate(want), np.concatenate(got)
     msg = ""
+    ser_msg = ""
+    if os.environ.get("FUZZ_SERIAL") and ok and len(w):
+        # the same chain with the clock recovery as one serial trajectory: what is left against the oracle there is
+        # not the hand-offs' doing
+        sd = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1))
+        ser = np.concatenate([sd.process(xi[per * lo:per * hi], typ) for lo, hi in zip(cuts[:-1], cuts[1:])])
+        if len(ser) == len(w):
+            big = np.abs(w) > 1e-3
+            ser_msg = " | serial-device rms %.2e sign %d, tiled-serial rms %.2e sign %d" % (
+                float(np.sqrt(np.mean((w - ser) ** 2))), int(np.sum(np.sign(w[big]) != np.sign(ser[big]))),
+                float(np.sqrt(np.mean((g - ser) ** 2))), int(np.sum(np.sign(g[big]) != np.sign(ser[big]))))
+        else:
+            ser_msg = " | serial-device COUNT %d" % len(ser)
     if os.environ.get("FUZZ_DUMP") and only:
         np.save(f"/tmp/fuzz_case{c}.npy", xi)
         print("   seed", seed, "stats", gd.stats().costas_passes, gd.stats().clock_passes, gd.stats().costas_unconverged, gd.stats().clock_unconverged, gd.stats().agc_serial_fallback)
@@ -69,8 +82,8 @@ for c in range(cases):
         r = float(np.sqrt(np.mean((w - g) ** 2)))
         if sgn or r > 6e-4:
             ok = False
-        msg = f"rms {r:.2e} sign {sgn}"
-    print(("ok  " if ok else "FAIL"), c, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg,
+        msg = f"rms {r:.2e} sign {sgn}" + ser_msg
+    print(("ok  " if ok else "FAIL"), c, "seed", seed, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg,
           {k: round(v, 2) for k, v in extra.items()}, knobs, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged, flush=True)
     bad += 0 if ok else 1
 print("failures:", bad)

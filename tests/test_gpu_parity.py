@@ -3,13 +3,17 @@
 Tolerances (float32 path, stated per check):
   * FIR / AGC / RRC / Costas outputs: max |err| <= 2e-5, rms <= 2e-6 relative to signals of amplitude ~0.5
     (different summation order, scan instead of serial gain recurrence, hand-off tolerance 1e-5 rad).
-  * recovered symbols: count identical, hard-decision sign identical wherever |oracle| > 1e-3,
-    rms <= 4e-4 (measured 2.2e-4 .. 3e-4).  BASELINE.json asks for 1e-4; the Mueller & Mueller recurrence selects one of 128
-    interpolator arms per symbol from rint(mu*128), which makes it chaotic at the 1e-5 level in mu: the
-    oracle run twice with inputs 1 ulp apart already differs by 3e-5..9e-5 rms
-    (tests/test_oracle_kat.py::test_clock_recovery_is_chaotic_at_ulp_level), and a time-tiled evaluation adds
-    hand-off residuals of the same kind.  With enough hand-off passes on a short burst
-    the tiled result closes on the serial one (test_clock_closes_with_more_passes).
+  * recovered symbols: count identical, hard-decision sign identical wherever |oracle| > 1e-3 (Es/N0 >= 6 dB; below,
+    see test_randomised_chains), rms <= 3.2e-4 -- pinned ~1.3x above what is measured (2.0e-4 .. 2.5e-4 on every
+    configuration and burst size), so that a regression shows.  BASELINE.json asks for 1e-4: that target is kept as
+    an expected failure (test_soft_symbol_target_of_1e_4).  Why it is missed, measured: the
+    M&M recurrence lives on a lattice -- mu and omega move in steps of 2^-21 sample (float32 near 4.25), the
+    interpolator arm is rint(mu*128) -- and does not forget a one-step difference for ~1e5 symbols.  The SAME device
+    chain with the clock recovery run as one serial trajectory (cfg.clock_serial, bit-identical to the CPU
+    recurrence on identical input: test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit) is already 1.05e-4 away
+    from the oracle on the bench burst, because its Costas output differs from the oracle's by 1e-6; the time-tiled
+    evaluation adds the rest.  On calls of a few thousand chains or fewer the passes go on until the hand-offs
+    close exactly and the result IS the serial one (test_clock_closes_with_more_passes).
   * int8 soft symbols (what the decoder receives): within 1 LSB.
 """
 import ctypes as C
@@ -36,7 +40,7 @@ def xa():
     return xritdemod_amd
 
 
-def check_symbols(got, want, rms_tol=5e-4):
+def check_symbols(got, want, rms_tol=3.2e-4):
     assert len(got) == len(want), (len(got), len(want))
     if len(want) == 0:
         return 0.0
@@ -143,7 +147,7 @@ def test_clock_stage(xa, oracle_mod, lrit_1m):
         assert len(so) == len(sg)
         if len(so):
             check_symbols(sg.real, so.real)
-            assert rms(sg - so) <= 6e-4
+            assert rms(sg - so) <= 4.5e-4          # complex symbols: both components
         tot += len(so)
     assert tot > 100000
 
@@ -207,6 +211,36 @@ def test_chain_parity(xa, oracle_mod, case):
     assert st.symbols_out == len(got) and st.costas_unconverged == 0 and st.agc_serial_fallback == 0
 
 
+@pytest.mark.xfail(strict=False, reason="BASELINE.json's 1e-4 rms: the serial-device floor itself is 1.05e-4 on the bench "
+                                        "burst, the time-tiled hand-offs land at 2.2e-4 .. 2.5e-4 (DESIGN.md section 6)")
+def test_soft_symbol_target_of_1e_4(xa, oracle_mod):
+    mode, fs, D, kw, n = CASES["C2"]
+    x = synth_signal(4 * n, **kw)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    got = xa.Demodulator(xa.Demodulator.config(mode, fs, D)).process(x)
+    assert len(got) == len(want)
+    assert rms(got - want) <= 1e-4
+
+
+def test_serial_device_floor_and_what_tiling_adds(xa, oracle_mod):
+    """The two sources of the soft-symbol difference, separated on one burst: the chain with the clock recovery as
+    ONE serial trajectory (no hand-offs) against the oracle = what the 1e-6 difference of the two Costas outputs
+    does to a recurrence that does not forget; the time-tiled chain against that serial run = what the hand-offs
+    add.  Both with identical symbol counts and hard decisions."""
+    mode, fs, D, kw, n = CASES["C2"]
+    x = synth_signal(4 * n, **kw)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
+    til = xa.Demodulator(xa.Demodulator.config(mode, fs, D)).process(x)
+    assert len(ser) == len(til) == len(want)
+    floor = check_symbols(ser, want, rms_tol=2e-4)         # measured 0.6e-4 .. 1.3e-4 depending on the burst
+    tiled = check_symbols(til, want)
+    big = np.abs(ser) > 1e-3
+    assert np.array_equal(np.sign(til[big]), np.sign(ser[big]))
+    assert rms(til - ser) <= 3.2e-4
+    assert floor <= tiled + 1e-5                            # tiling never beats the serial run it approximates
+
+
 def test_clock_closes_with_more_passes(xa, oracle_mod):
     """On a short burst, enough hand-off passes bring the tiled clock recovery onto the serial trajectory."""
     o = oracle_mod
@@ -243,7 +277,7 @@ def test_integer_ingest(xa, oracle_mod, stype):
         code = o.SAMPLE_S16IQ if stype == "s16" else o.SAMPLE_S8IQ
         want = o.Demod(o.config("lrit", fs, D)).process(q, code)
         got = xa.Demodulator(xa.Demodulator.config("lrit", fs, D)).process(q, code)
-        check_symbols(got, want, rms_tol=5e-4)
+        check_symbols(got, want)
 
 
 def test_golden_fixtures(xa):
@@ -273,24 +307,19 @@ def test_capacity_and_argument_errors(xa):
     n = C.c_size_t(0)
     rc = xa.lib().xrit_demod_process(dem._h, x.ctypes.data_as(C.c_void_p), len(x), 0, out.ctypes.data_as(C.c_void_p), 10, C.byref(n))
     assert rc == -5 and n.value > 10 and b"capacity" in xa.lib().xrit_last_error()
+    # refused before anything ran: the handle is unchanged and gives what a fresh one gives
+    assert np.array_equal(dem.process(x), xa.Demodulator(xa.Demodulator.config("lrit")).process(x))
     rc = xa.lib().xrit_demod_process(dem._h, x.ctypes.data_as(C.c_void_p), len(x), 7, out.ctypes.data_as(C.c_void_p), 10, C.byref(n))
     assert rc == -1
     bad = xa.Demodulator.config("lrit")
     bad.device = 99
     with pytest.raises(xa.XritError):
         xa.Demodulator(bad)
-
-
-def test_time_slices_are_chunk_invariant(xa, oracle_mod):
-    """cfg.slices > 1 overlaps the front end of one slice with the loops of the previous on a second stream; the
-    symbols must be the ones of the un-sliced call (state is carried from slice to slice)."""
-    x = synth_signal(6000000, fs_in=6.25e6)
-    want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, 5)).process(x)
-    one = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5)).process(x)
-    three = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, slices=3)).process(x)
-    assert len(one) == len(three) == len(want)
-    check_symbols(three, want)
-    assert rms(one - three) <= 4e-4 and (np.sign(one) == np.sign(three))[np.abs(want) > 1e-3].all()
+    for field, value in (("rrc_taps", 1), ("agc_rate", 0.0), ("agc_reference", -0.5), ("agc_gain", 0.0), ("symbol_rate", 0)):
+        bad = xa.Demodulator.config("lrit")
+        setattr(bad, field, value)
+        with pytest.raises(xa.XritError):
+            xa.Demodulator(bad)
 
 
 def test_run_to_run_determinism(xa):
@@ -789,45 +818,80 @@ def test_mid_stream_jump_after_the_spare_pass_was_dropped(xa, oracle_mod):
     assert passes[2] == passes[3] == passes[4] == 2 and passes[5] > 2, passes
 
 
+def _random_case(rng, snr_lo, snr_hi):
+    mode = "lrit" if rng.random() < 0.6 else "hrit"
+    D = int(rng.choice([1, 2, 3, 5, 8, 16, 32]))
+    fs = (1.25e6 if mode == "lrit" else 2.5e6) * D
+    n = int(rng.integers(1, 12000)) * D + int(rng.integers(0, D))
+    typ = int(rng.choice([0, 0, 1, 2]))
+    sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
+    p = synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=0.1 if typ == 0 else 0.3,
+                          seed=int(rng.integers(1, 1 << 30)), esn0_db=float(rng.uniform(snr_lo, snr_hi)),
+                          carrier_hz=float(rng.uniform(-600, 600)), clock_ppm=float(rng.uniform(-100, 100)),
+                          timing_offset=float(rng.uniform(0, 1)), phase0=float(rng.uniform(-3.1, 3.1)))
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 4)))]))
+    keep = bool(rng.random() < 0.3)
+    return mode, D, fs, n, typ, p, cuts, keep
+
+
+def _run_case(xa, oracle_mod, mode, D, fs, n, typ, p, cuts, keep, **cfg):
+    x = synth.generate(p, n)
+    if typ == 1:
+        xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    elif typ == 2:
+        xi = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
+    else:
+        xi = x
+    per = 1 if typ == 0 else 2
+    od, gd = oracle_mod.Demod(oracle_mod.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, **cfg))
+    gd.keep_stages(keep)
+    want, got = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        want.append(od.process(xi[per * lo:per * hi], typ))
+        got.append(gd.process(xi[per * lo:per * hi], typ))
+        assert len(want[-1]) == len(got[-1]), (mode, D, n, typ, cuts)
+    return np.concatenate(want), np.concatenate(got)
+
+
 def test_randomised_chains(xa, oracle_mod):
     """A fixed-seed slice of tests/experiments/fuzz_chain.py (which found every regression case above): random mode,
-    decimation, length, chunking, ingest type, Es/N0 6..20 dB, carrier inside the lock-in range, clock error, kept or
-    fused stages -- same symbol count, hard decisions identical, soft rms <= 6e-4 on every case."""
+    decimation, length, chunking, ingest type, carrier inside the lock-in range, clock error, kept or fused stages.
+    Es/N0 6..20 dB: same symbol count, hard decisions identical, soft rms <= 6e-4 on every case (short cold-started
+    calls: most close exactly, the worst acquisitions are 4..5e-4).  Es/N0 2..6 dB, where one symbol in ten is wrong
+    anyway and far more of them sit near zero: same symbol count, at most one differing hard decision per 10^4
+    symbols, rms <= 1e-3 (fuzz, 150 cases: two above 6e-4, one flipped decision in 16 413 symbols at 2.7 dB; the
+    serial-device run of those cases agrees with the oracle, i.e. this is the hand-offs' doing and is stated as such)."""
     rng = np.random.default_rng(20260929)
     worst = 0.0
     for c in range(48):
-        mode = "lrit" if rng.random() < 0.6 else "hrit"
-        D = int(rng.choice([1, 2, 3, 5, 8, 16, 32]))
-        fs = (1.25e6 if mode == "lrit" else 2.5e6) * D
-        n = int(rng.integers(1, 12000)) * D + int(rng.integers(0, D))
-        typ = int(rng.choice([0, 0, 1, 2]))
-        sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
-        p = synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=0.1 if typ == 0 else 0.3,
-                              seed=int(rng.integers(1, 1 << 30)), esn0_db=float(rng.uniform(6, 20)),
-                              carrier_hz=float(rng.uniform(-600, 600)), clock_ppm=float(rng.uniform(-100, 100)),
-                              timing_offset=float(rng.uniform(0, 1)), phase0=float(rng.uniform(-3.1, 3.1)))
-        cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 4)))]))
-        keep = bool(rng.random() < 0.3)
-        x = synth.generate(p, n)
-        if typ == 1:
-            xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
-        elif typ == 2:
-            xi = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
-        else:
-            xi = x
-        per = 1 if typ == 0 else 2
-        od, gd = oracle_mod.Demod(oracle_mod.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D))
-        gd.keep_stages(keep)
-        want, got = [], []
-        for lo, hi in zip(cuts[:-1], cuts[1:]):
-            want.append(od.process(xi[per * lo:per * hi], typ))
-            got.append(gd.process(xi[per * lo:per * hi], typ))
-            assert len(want[-1]) == len(got[-1]), (c, mode, D, n, typ, cuts)
-        w, g = np.concatenate(want), np.concatenate(got)
+        low = c >= 28
+        case = _random_case(rng, 2, 6) if low else _random_case(rng, 6, 20)
+        w, g = _run_case(xa, oracle_mod, *case)
         if len(w):
             big = np.abs(w) > 1e-3
-            assert np.array_equal(np.sign(w[big]), np.sign(g[big])), (c, mode, D, n, typ, cuts)
+            flips = int(np.sum(np.sign(w[big]) != np.sign(g[big])))
             r = rms(w - g)
-            assert r <= 6e-4, (c, mode, D, n, typ, cuts, r)
+            if low:
+                assert flips <= 1 + len(w) // 10000 and r <= 1e-3, (c, case[:5], flips, r)
+            else:
+                assert flips == 0 and r <= 6e-4, (c, case[:5], flips, r)
             worst = max(worst, r)
     assert worst > 0.0
+
+
+@pytest.mark.parametrize("seed,esn0,carrier,ppm,toff,ph,n", [
+    (207702987, 3.45, 381.61, 9.98, 0.51, 1.61, 274735),      # fuzz (2..6 dB): tiled 7.9e-4, serial device 6e-6
+    (151577245, 2.66, -139.61, -7.34, 0.96, 2.74, 221449),    # fuzz: one hard decision flipped in 16 413 symbols
+])
+def test_low_snr_regression_seeds(xa, oracle_mod, seed, esn0, carrier, ppm, toff, ph, n):
+    """The low-Es/N0 cases the fuzz script flagged, kept as regression inputs (HRIT, decimation 5, one cold-started
+    call).  The serial-device run must agree with the oracle (it did: the difference is the hand-offs'), the tiled
+    run must stay inside the low-SNR bar of test_randomised_chains."""
+    p = synth.SynthParams(fs_in=12.5e6, symbol_rate=927000.0, alpha=0.3, amplitude=0.1, seed=seed, esn0_db=esn0,
+                          carrier_hz=carrier, clock_ppm=ppm, timing_offset=toff, phase0=ph)
+    case = ("hrit", 5, 12.5e6, n, 0, p, [0, n], False)
+    w, g = _run_case(xa, oracle_mod, *case)
+    _, ser = _run_case(xa, oracle_mod, *case, clock_serial=1)
+    big = np.abs(w) > 1e-3
+    assert np.array_equal(np.sign(w[big]), np.sign(ser[big])) and rms(w - ser) <= 5e-4
+    assert int(np.sum(np.sign(w[big]) != np.sign(g[big]))) <= 2 and rms(w - g) <= 1e-3

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "xrit_clock_work": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "xrit_clock_set_serial": (C.c_int, [_vp, C.c_int]),
     "xrit_clock_destroy": (None, [_vp]),
+    "xrit_device_read_bandwidth": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, C.POINTER(C.c_double)]),
     "xrit_synth_defaults": (None, [C.POINTER(SynthParams)]),
     "xrit_synth_generate_device": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, _sz, _vp, C.c_int, _vp]),
 }
@@ -360,6 +361,14 @@ class Demodulator(_Handle):
 def synth_generate_device(params, start, n, d_out_ptr, device=0, stream=None):
     _check(lib().xrit_synth_generate_device(C.byref(params), start, n, C.c_void_p(d_out_ptr), device,
                                             C.c_void_p(stream) if stream else None))
+
+
+def device_read_bandwidth(d_buf_ptr, nbytes, reps=10, device=0, stream=None):
+    """GB/s of a hand-written read-only sweep over a device buffer (measurement helper)."""
+    out = C.c_double(0)
+    _check(lib().xrit_device_read_bandwidth(C.c_void_p(d_buf_ptr), nbytes, reps, device,
+                                            C.c_void_p(stream) if stream else None, C.byref(out)))
+    return out.value
 
 
 def synth_params(**over):

@@ -51,9 +51,8 @@ struct xrit_demod {
     AgcStage agc;
     CostasStage costas;
     ClockStage clock;
-    DevBuf bufA[2], bufB[2], bufC[2], stat[2], in_dev, soft_dev, q_in, q_out;   // two sets: one per time slice in flight
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_in = nullptr, ev_fe[2] = {nullptr, nullptr}, ev_lp[2] = {nullptr, nullptr};
+    DevBuf bufA, bufB, bufC, stat, in_dev, soft_dev, q_in, q_out;
+    bool poisoned = false;      // a call failed after some stage had advanced its carried state
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
     bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
     bool agc_fallback_seen = false;   // this call: the AGC's guard sent a slice down the serial path
@@ -154,8 +153,21 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
 {
     if (!cfg || !out) { set_error("null argument"); return XRIT_E_INVALID; }
     *out = nullptr;
-    if (cfg->decimation < 1 || cfg->symbol_rate == 0 || !(cfg->sample_rate > 0) || cfg->rrc_taps < 1) {
+    if (cfg->decimation < 1 || cfg->symbol_rate == 0 || !(cfg->sample_rate > 0)) {
         set_error("invalid configuration");
+        return XRIT_E_INVALID;
+    }
+    if (cfg->rrc_taps < 3) {
+        set_error("rrc_taps = %d: the matched filter needs at least 3 taps (RRC_TAPS is 63, Parameters.h:28)", cfg->rrc_taps);
+        return XRIT_E_INVALID;
+    }
+    // the AGC's gain recurrence is evaluated as a scan of maps g -> min(a g + b, c), valid for positive gains
+    if (!(cfg->agc_rate > 0) || !(cfg->agc_reference > 0) || !(cfg->agc_gain > 0) || !(cfg->agc_max_gain >= 0)) {
+        set_error("AGC rate, reference and initial gain must be positive (Parameters.h:34-37: 0.01, 0.5, 1, 4000)");
+        return XRIT_E_INVALID;
+    }
+    if (!(cfg->sample_rate / (float)cfg->decimation / (float)cfg->symbol_rate >= 1.0f)) {
+        set_error("fewer than one sample per symbol after decimation");
         return XRIT_E_INVALID;
     }
     XR_TRY(select_device(cfg->device));
@@ -168,12 +180,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
     d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
     int rc = XRIT_OK;
     do {
-        if (hipStreamCreate(&d->stream) != hipSuccess || hipStreamCreate(&d->stream2) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
-        bool ev_ok = hipEventCreateWithFlags(&d->ev_in, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 2 && ev_ok; ++i)
-            ev_ok = hipEventCreateWithFlags(&d->ev_fe[i], hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&d->ev_lp[i], hipEventDisableTiming) == hipSuccess;
-        if (!ev_ok) { set_error("hipEventCreate failed"); rc = XRIT_E_HIP; break; }
+        if (hipStreamCreate(&d->stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
@@ -198,11 +205,8 @@ void xrit_demod_destroy(xrit_demod *d)
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->bufC[i].release(); d->stat[i].release(); }
+    d->bufA.release(); d->bufB.release(); d->bufC.release(); d->stat.release();
     d->in_dev.release(); d->soft_dev.release();
-    if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
-    if (d->ev_in) (void)hipEventDestroy(d->ev_in);
-    for (int i = 0; i < 2; ++i) { if (d->ev_fe[i]) (void)hipEventDestroy(d->ev_fe[i]); if (d->ev_lp[i]) (void)hipEventDestroy(d->ev_lp[i]); }
     d->q_in.release(); d->q_out.release();
     for (auto &b : d->stage_buf) b.release();
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -231,16 +235,15 @@ struct SliceIO {
     bool stat_ready = false;
 };
 
-static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set, hipStream_t s, Profiler *prof,
-                     SliceIO *io)
+static int front_end(xrit_demod *d, const void *in, size_t n, int type, hipStream_t s, Profiler *prof, SliceIO *io)
 {
     const unsigned D = d->cfg.decimation;
     size_t length = n;
     if (D > 1) length = n / D;   // demodulator.cpp:137 -- the remainder of the chunk is dropped
     io->length = length;
-    XR_TRY(d->bufA[set].reserve((length + 8) * sizeof(float2)));
-    XR_TRY(d->bufB[set].reserve((length + 8) * sizeof(float2)));
-    float2 *A = d->bufA[set].as<float2>(), *B = d->bufB[set].as<float2>();
+    XR_TRY(d->bufA.reserve((length + 8) * sizeof(float2)));
+    XR_TRY(d->bufB.reserve((length + 8) * sizeof(float2)));
+    float2 *A = d->bufA.as<float2>(), *B = d->bufB.as<float2>();
     const float2 *cur = nullptr;
     // with a decimator in front, its epilogue leaves the AGC's composed gain maps: the AGC sweeps the stream
     // twice (scan of the maps aside) instead of three times
@@ -267,8 +270,8 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     AgcFill fill{};
     float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
     if (agc_in_rrc || agc_in_rrc_d1) {
-        XR_TRY(d->bufC[set].reserve((length + 8) * sizeof(float2)));
-        Cfb = d->bufC[set].as<float2>();
+        XR_TRY(d->bufC.reserve((length + 8) * sizeof(float2)));
+        Cfb = d->bufC.as<float2>();
         if (agc_in_rrc_d1) XR_TRY(d->agc.fused_reduce(cur, length, 3, s, prof));
         XR_TRY(d->agc.fused_scan(cur, Cfb, length, agc_in_rrc ? d->dec.RC : 3, s, prof, &fill));    // :143
     }
@@ -279,20 +282,19 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
     const int L = d->costas.L;
     const size_t K = (length + (size_t)L - 1) / (size_t)L;
-    XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
+    XR_TRY(d->stat.reserve((K + 2) * sizeof(float2)));
     io->stat_ready = length > 0 && d->rrc.stat_supported(L);
     // (fused: A holds the decimator output, which the fill reads; the filter output goes to B's place instead)
     const bool fill_on = agc_in_rrc || agc_in_rrc_d1;
     float2 *rrc_out = fill_on ? B : A;
-    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
+    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat.as<float2>() : nullptr, L,
                       nullptr, fill_on ? &fill : nullptr)); // :148
     XR_TRY(keep_stage(d, 2, rrc_out, length, s));
     io->rrc = rrc_out;
     return XRIT_OK;
 }
 
-static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_t cap, size_t *nsym, hipStream_t s,
-                 Profiler *prof)
+static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, size_t *nsym, hipStream_t s, Profiler *prof)
 {
     const size_t length = io.length;
     const int L = d->costas.L;
@@ -310,7 +312,7 @@ static int loops(xrit_demod *d, const SliceIO &io, int set, float *d_soft, size_
         sym = d->stage_buf[4].as<float2>();
     }
     const double inv_sps = 1.0 / (double)d->sps;
-    const float2 *stat = io.stat_ready ? d->stat[set].as<float2>() : nullptr;
+    const float2 *stat = io.stat_ready ? d->stat.as<float2>() : nullptr;
     XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
     XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
     if (length) XR_TRY(d->agc.request_flag(s));        // the AGC's guard flag rides along: no wait of its own
@@ -340,68 +342,37 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
     const unsigned D = d->cfg.decimation;
-    const size_t esz = type == XRIT_SAMPLE_FLOATIQ ? 8 : (type == XRIT_SAMPLE_S16IQ ? 4 : 2);
-
-    // A call can be cut into time slices so that the front end of slice c+1 (stream 2) overlaps the feedback
-    // loops of slice c (caller's stream).  The chain is chunk invariant (state is carried from slice to slice
-    // exactly as from call to call) and slices are multiples of decimation x 5120 samples, so nothing is dropped
-    // between them.  Off unless asked for (cfg.slices > 1): measured at C2, every extra slice costs ~0.5 ms of
-    // per-slice fixed work (solves, guesses, one host synchronise) and the concurrent kernels slow each other
-    // down, 3.4 ms -> 3.8 / 4.3 / 4.8 ms for 2 / 3 / 4 slices.
-    const size_t quantum = (size_t)D * 5120;
-    size_t slices = 1;
-    if (!d->keep_stages && !d->keep_symbols && d->cfg.slices > 1 && n >= ((size_t)1 << 22)) {
-        slices = (size_t)d->cfg.slices;
-        while (slices > 1 && n / slices < ((size_t)1 << 20)) --slices;
+    if (d->poisoned) {
+        set_error("this handle's carried state is inconsistent after an earlier failed call: destroy it and create a new one");
+        return XRIT_E_INVALID;
     }
-    const size_t per = slices > 1 ? (n / slices) / quantum * quantum : n;
-
+    // the symbols this call can produce at most (slowest admissible symbol clock, plus the unread tail of the last
+    // call): checked before any stage advances its state
+    {
+        const size_t length = D > 1 ? n / D : n;
+        const double min_omega = (double)d->sps * (1.0 - (double)d->cfg.clock_omega_limit);
+        const size_t worst = (size_t)(((double)length + (double)d->clock.carry) / min_omega) + 2;
+        if (worst > cap && length > 0) {
+            set_error("output capacity %zu is below the %zu symbols this call may produce (n / (decimation * sps * (1 - omega limit)) + 2)", cap, worst);
+            *n_out = worst;        // the capacity that suffices; nothing has run, the handle is unchanged
+            return XRIT_E_CAPACITY;
+        }
+    }
     size_t total_sym = 0, total_len = 0;
-    int rc = XRIT_OK;
     d->agc_fallback_seen = false;
-    int worst_cp = 0, worst_kp = 0;
-    unsigned unc_c = 0, unc_k = 0, large_k = 0;
-    float res_c = 0, res_k = 0;
-    SliceIO io[2];
-    hipStream_t s2 = d->stream2;
-    if (slices > 1) {
-        // stream 2 may read the caller's buffer only after whatever the caller queued on its stream
-        XR_HIP(hipEventRecord(d->ev_in, s));
-        XR_HIP(hipStreamWaitEvent(s2, d->ev_in, 0));
+    SliceIO io;
+    int rc = front_end(d, d_samples, n, type, s, prof, &io);
+    if (rc == XRIT_OK) rc = loops(d, io, d_soft, cap, &total_sym, s, prof);
+    if (rc != XRIT_OK) {
+        // some stage has flipped its ping-pong state, a later one has not: the handle cannot go on
+        d->poisoned = true;
+        *n_out = 0;
+        return rc;
     }
-    for (size_t c = 0; c < slices && rc == XRIT_OK; ++c) {
-        const size_t off = c * per;
-        const size_t cnt = (c + 1 == slices) ? n - off : per;
-        const int set = (int)(c & 1);
-        if (c == 0) {
-            XR_TRY(front_end(d, (const char *)d_samples + off * esz, cnt, type, set, slices > 1 ? s2 : s, prof, &io[set]));
-            if (slices > 1) XR_HIP(hipEventRecord(d->ev_fe[set], s2));
-        }
-        if (c + 1 < slices) {
-            // front end of the next slice: its buffers were last read by the loops of slice c-1
-            const size_t off1 = (c + 1) * per;
-            const size_t cnt1 = (c + 2 == slices) ? n - off1 : per;
-            const int set1 = (int)((c + 1) & 1);
-            if (c >= 1) XR_HIP(hipStreamWaitEvent(s2, d->ev_lp[set1], 0));
-            XR_TRY(front_end(d, (const char *)d_samples + off1 * esz, cnt1, type, set1, s2, prof, &io[set1]));
-            XR_HIP(hipEventRecord(d->ev_fe[set1], s2));
-        }
-        if (slices > 1) XR_HIP(hipStreamWaitEvent(s, d->ev_fe[set], 0));
-        size_t nsym = 0;
-        rc = loops(d, io[set], set, d_soft ? d_soft + total_sym : nullptr, cap > total_sym ? cap - total_sym : 0, &nsym, s,
-                   prof);
-        if (slices > 1) XR_HIP(hipEventRecord(d->ev_lp[set], s));
-        total_sym += nsym;
-        total_len += io[set].length;
-        worst_cp = d->costas.passes > worst_cp ? d->costas.passes : worst_cp;
-        worst_kp = d->clock.passes > worst_kp ? d->clock.passes : worst_kp;
-        unc_c += d->costas.unconverged;
-        unc_k += d->clock.unconverged;
-        large_k += d->clock.large_open;
-        res_c = d->costas.max_residual > res_c ? d->costas.max_residual : res_c;
-        res_k = d->clock.max_residual > res_k ? d->clock.max_residual : res_k;
-    }
-    if (slices > 1) XR_HIP(hipStreamSynchronize(s2));
+    total_len = io.length;
+    const int worst_cp = d->costas.passes, worst_kp = d->clock.passes;
+    const unsigned unc_c = d->costas.unconverged, unc_k = d->clock.unconverged, large_k = d->clock.large_open;
+    const float res_c = d->costas.max_residual, res_k = d->clock.max_residual;
     if (prof) d->prof.collect();
     d->stage_n[4] = total_sym;
     d->stats.samples_in = n;
@@ -416,7 +387,6 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.agc_serial_fallback = d->agc_fallback_seen;
     d->stats.clock_open_large = large_k;
     *n_out = total_sym;
-    if (rc != XRIT_OK) return rc;
     if (d->cfg.strict && unc_c) {
         set_error("Costas hand-off did not close: %u boundaries above tolerance", unc_c);
         return XRIT_E_NOT_CONVERGED;
@@ -756,6 +726,13 @@ int xrit_synth_generate_device(const xrit_synth_params *p, uint64_t start, size_
     if (!p || (n && !d_out)) { set_error("null argument"); return XRIT_E_INVALID; }
     XR_TRY(select_device(device));
     return launch_synth(*p, start, n, reinterpret_cast<float2 *>(d_out), (hipStream_t)stream);
+}
+
+int xrit_device_read_bandwidth(const void *d_buf, size_t bytes, int reps, int device, void *stream, double *gb_per_s)
+{
+    if (!d_buf || !gb_per_s) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    return launch_read_bw(d_buf, bytes, reps, (hipStream_t)stream, gb_per_s);
 }
 
 }  // extern "C"

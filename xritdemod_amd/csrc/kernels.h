@@ -186,5 +186,6 @@ int launch_sync_fix(const int8_t *data, size_t n, const xrit_sync_hit *hits, uns
 int launch_quantize_i8(const float *in, int8_t *out, size_t n, hipStream_t s);
 int launch_convert(const void *in, int type, float2 *out, size_t n, hipStream_t s);
 int launch_synth(const xrit_synth_params &p, uint64_t start, size_t n, float2 *out, hipStream_t s);
+int launch_read_bw(const void *buf, size_t bytes, int reps, hipStream_t s, double *gbs);
 
 }  // namespace xrit

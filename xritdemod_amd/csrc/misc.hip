@@ -117,4 +117,52 @@ int launch_synth(const xrit_synth_params &p, uint64_t start, size_t n, float2 *o
     return XRIT_OK;
 }
 
+// ------------------------------------------------------------ measurement
+// What a hand-written read-only sweep reaches on this device (bench.py reports it next to the vendor peak, as
+// SURVEY.md section 8(d) asks): every workgroup owns contiguous 64 KiB tiles, 16-byte non-temporal loads, eight in
+// flight per thread -- the best of the patterns scripts/ubench/read_bw.hip compares (7.0-7.1 TB/s on MI355X).
+__global__ void __launch_bounds__(256) read_bw_kernel(const float4 *__restrict__ in, size_t words, float *sink)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *p = reinterpret_cast<const v4f *>(in);
+    const size_t tile = 4096;                                  // 16-byte words per tile
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 + tile <= words; t0 += (size_t)gridDim.x * tile) {
+        for (size_t i = threadIdx.x; i < tile; i += 256 * 8) {
+            v4f v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + t0 + i + (size_t)u * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = 1.f;
+}
+
+int launch_read_bw(const void *buf, size_t bytes, int reps, hipStream_t s, double *gbs)
+{
+    *gbs = 0;
+    const size_t words = bytes / 16 / 4096 * 4096;
+    if (words == 0 || reps < 1) { set_error("read bandwidth probe: buffer too small"); return XRIT_E_INVALID; }
+    float *sink = nullptr;
+    XR_HIP(hipMalloc((void **)&sink, 64));
+    hipEvent_t a, b;
+    XR_HIP(hipEventCreate(&a));
+    XR_HIP(hipEventCreate(&b));
+    const unsigned blocks = (unsigned)(words / 4096 < 8192 ? words / 4096 : 8192);
+    hipLaunchKernelGGL(read_bw_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(buf), words, sink);
+    XR_HIP(hipEventRecord(a, s));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(read_bw_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(buf), words, sink);
+    XR_HIP(hipEventRecord(b, s));
+    XR_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    XR_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    if (ms > 0) *gbs = (double)words * 16.0 * reps / (ms * 1e-3) / 1e9;
+    return XRIT_OK;
+}
+
 }  // namespace xrit
