@@ -105,7 +105,6 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--costas-chain", type=int, default=0, help="samples per Costas chain (0 = library default)")
     ap.add_argument("--clock-chain", type=int, default=0, help="symbols per clock-recovery chain (0 = library default)")
-    ap.add_argument("--slices", type=int, default=0, help="time slices per call (0 = library default, 1 = off)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="also time the oracle on this many host threads, one independent stream segment each "
                          "(SURVEY.md 8(d)(ii)); 0 = every logical CPU of the host; 1 = off.  The single-thread figure "
@@ -183,7 +182,7 @@ def main():
                 host_segs.append(bursts[b_, o_:o_ + n_t].cpu().numpy().view(np.complex64).reshape(-1))
 
     cfg = xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
-                                clock_chain_syms=args.clock_chain, slices=args.slices)
+                                clock_chain_syms=args.clock_chain)
     dem = xa.Demodulator(cfg)
     sps = dem.sps
     cap = int(n_burst / (D * sps * 0.99)) + 64

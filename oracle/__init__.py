@@ -43,7 +43,13 @@ class Agc(C.Structure):
 
 class Costas(C.Structure):
     _fields_ = [("phase", C.c_float), ("freq", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
-                ("max_freq", C.c_float), ("min_freq", C.c_float)]
+                ("max_freq", C.c_float), ("min_freq", C.c_float), ("wrap_pi", C.c_int), ("imag_axis", C.c_int)]
+
+
+class Knobs(C.Structure):
+    """xo_knobs: the semantic choices that cannot be checked against the absent libSatHelper (xrit_oracle.h)."""
+    _fields_ = [("fir_phase_last", C.c_int), ("mm_fudge", C.c_int), ("mm_drop_tail", C.c_int),
+                ("costas_wrap_pi", C.c_int), ("costas_imag_axis", C.c_int)]
 
 
 class MMState(C.Structure):
@@ -110,12 +116,35 @@ def lib():
         L.xo_sync_fix_frames.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
         L.xo_sync_fix_frames.restype = None
         L.xo_convert_samples.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.xo_knobs_default.argtypes = [C.POINTER(Knobs)]
+        L.xo_set_knobs.argtypes = [C.POINTER(Knobs)]
+        L.xo_get_knobs.argtypes = [C.POINTER(Knobs)]
         _lib = L
     return _lib
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class knobs:
+    """Context manager: objects created inside see the given knob values (defaults elsewhere)."""
+
+    def __init__(self, **over):
+        self.k = Knobs()
+        lib().xo_knobs_default(C.byref(self.k))
+        for name, v in over.items():
+            setattr(self.k, name, int(v))
+
+    def __enter__(self):
+        self.old = Knobs()
+        lib().xo_get_knobs(C.byref(self.old))
+        lib().xo_set_knobs(C.byref(self.k))
+        return self.k
+
+    def __exit__(self, *exc):
+        lib().xo_set_knobs(C.byref(self.old))
+        return False
 
 
 def _c64(a):

@@ -22,6 +22,30 @@
 #endif
 
 /* ------------------------------------------------------------------------- */
+/* Knobs (xrit_oracle.h)                                                     */
+/* ------------------------------------------------------------------------- */
+static xo_knobs g_knobs = {0, XO_MM_FUDGE, 0, 0, 0};
+
+void xo_knobs_default(xo_knobs *k)
+{
+    k->fir_phase_last = 0;
+    k->mm_fudge = XO_MM_FUDGE;
+    k->mm_drop_tail = 0;
+    k->costas_wrap_pi = 0;
+    k->costas_imag_axis = 0;
+}
+
+void xo_set_knobs(const xo_knobs *k)
+{
+    if (!k) { xo_knobs_default(&g_knobs); return; }
+    g_knobs = *k;
+    if (g_knobs.mm_fudge < 0) g_knobs.mm_fudge = 0;
+    if (g_knobs.mm_fudge > 64) g_knobs.mm_fudge = 64;
+}
+
+void xo_get_knobs(xo_knobs *k) { *k = g_knobs; }
+
+/* ------------------------------------------------------------------------- */
 /* Tap designers                                                             */
 /* ------------------------------------------------------------------------- */
 
@@ -175,6 +199,7 @@ void xo_mmse_table(float *table)
 
 struct xo_fir {
     unsigned D;
+    int      phase;  /* 0, or D-1 (knob fir_phase_last): output m reads x[m D + phase - k] */
     int      T;
     float   *rtaps;  /* reversed taps: rtaps[i] = h[T-1-i] */
     xo_cf   *buf;    /* [T-1 history | new samples] */
@@ -185,6 +210,7 @@ xo_fir *xo_fir_create(unsigned decimation, const float *taps, int ntaps)
 {
     xo_fir *f = (xo_fir *)calloc(1, sizeof(*f));
     f->D = decimation ? decimation : 1;
+    f->phase = g_knobs.fir_phase_last ? (int)f->D - 1 : 0;
     f->T = ntaps;
     f->rtaps = (float *)malloc(sizeof(float) * ntaps);
     for (int i = 0; i < ntaps; i++) f->rtaps[i] = taps[ntaps - 1 - i];
@@ -223,7 +249,7 @@ void xo_fir_work(xo_fir *f, const xo_cf *in, xo_cf *out, int n_out)
     memcpy(f->buf + (T - 1), in, sizeof(xo_cf) * n_in);
     const float *rt = f->rtaps;
     for (int m = 0; m < n_out; m++) {
-        const xo_cf *w = f->buf + (size_t)m * f->D; /* w[i] = x[m*D - (T-1) + i] */
+        const xo_cf *w = f->buf + (size_t)m * f->D + f->phase; /* w[i] = x[m*D + phase - (T-1) + i] */
         float sr[4] = {0, 0, 0, 0}, si[4] = {0, 0, 0, 0};
         int i = 0;
         for (; i + 4 <= T; i += 4) {
@@ -288,6 +314,8 @@ void xo_costas_init(xo_costas *c, float loop_bw)
     c->freq = 0;
     c->max_freq = 1.0f;
     c->min_freq = -1.0f;
+    c->wrap_pi = g_knobs.costas_wrap_pi;
+    c->imag_axis = g_knobs.costas_imag_axis;
 }
 
 static inline float xo_clip(float x, float clip)
@@ -314,11 +342,17 @@ void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n)
         out[i].re = yr;
         out[i].im = yi;
         float err = yr * yi;
+        if (c->imag_axis) err = -err;                  /* knob: stable lock a quarter turn away */
         err = xo_clip(err, 1.0f);
         freq = freq + c->beta * err;
         phase = phase + freq + c->alpha * err;
-        while (phase > twopi) phase -= twopi;
-        while (phase < -twopi) phase += twopi;
+        if (c->wrap_pi) {                              /* knob: (-pi, pi] */
+            while (phase > 0.5f * twopi) phase -= twopi;
+            while (phase <= -0.5f * twopi) phase += twopi;
+        } else {
+            while (phase > twopi) phase -= twopi;
+            while (phase < -twopi) phase += twopi;
+        }
         if (freq > c->max_freq) freq = c->max_freq;
         else if (freq < c->min_freq) freq = c->min_freq;
     }
@@ -337,6 +371,7 @@ struct xo_mm {
     xo_cf *buf;   /* [carry | new] */
     size_t cap;
     int    carry;
+    int    fudge, drop_tail;   /* knobs mm_fudge, mm_drop_tail */
 };
 
 xo_mm *xo_mm_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit)
@@ -348,6 +383,8 @@ xo_mm *xo_mm_create(float omega, float gain_omega, float mu, float gain_mu, floa
     m->omega_lim = omega * omega_rel_limit;
     m->gain_omega = gain_omega;
     m->gain_mu = gain_mu;
+    m->fudge = g_knobs.mm_fudge;
+    m->drop_tail = g_knobs.mm_drop_tail;
     xo_mmse_table(m->table);
     return m;
 }
@@ -386,13 +423,13 @@ int xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, flo
     }
     memcpy(m->buf + m->carry, in, sizeof(xo_cf) * (size_t)n);
     const xo_cf *x = m->buf;
-    long ni = (long)total - XO_MM_NTAPS - XO_MM_FUDGE;
+    long ni = (long)total - XO_MM_NTAPS - m->fudge;
     long ii = 0;
     int oo = 0;
     float mu = m->mu, omega = m->omega;
     /* a symbol consumes at least one sample in any sane configuration: the bound only stops a NaN state (an AGC
      * driven outside its stable range upstream) from emitting symbols for ever into the caller's n + 64 buffer */
-    while (ii < ni && oo < n + XO_MM_FUDGE) {
+    while (ii < ni && oo < n + XO_MM_FUDGE + 8) {
         m->p_2t = m->p_1t;
         m->p_1t = m->p_0t;
         /* mmse_fir_interpolator_cc::interpolate */
@@ -433,7 +470,7 @@ int xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, flo
     m->mu = mu;
     m->omega = omega;
     if (ii > (long)total) ii = (long)total;
-    m->carry = (int)((long)total - ii);
+    m->carry = m->drop_tail ? 0 : (int)((long)total - ii);
     memmove(m->buf, m->buf + ii, sizeof(xo_cf) * (size_t)m->carry);
     return oo;
 }
@@ -491,6 +528,7 @@ struct xo_demod {
     xo_cf    *stage[6];  /* 0 converted input .. 5 clock recovery */
     int       stage_n[6];
     size_t    cap;
+    int       imag_axis; /* knob costas_imag_axis: SymbolManager keeps Im(symbol) */
 };
 
 /* main(), demodulator.cpp:436-450 */
@@ -511,6 +549,7 @@ xo_demod *xo_demod_create(const xo_config *cfg)
     d->mm = xo_mm_create(sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha,
                          cfg->clock_omega_limit);
     d->rrc = xo_fir_create(1, d->rrc_taps, cfg->rrc_taps | 1);
+    d->imag_axis = g_knobs.costas_imag_axis;
     return d;
 }
 
@@ -580,7 +619,8 @@ int xo_demod_process(xo_demod *d, const void *samples, int n, int sample_type,
     int symbols = xo_mm_work(d->mm, d->stage[4], length, d->stage[5]); /* :156 */
     d->stage_n[5] = symbols;
     if (symbols > cap_out) return -symbols;
-    for (int i = 0; i < symbols; i++) soft_out[i] = d->stage[5][i].re; /* SymbolManager.cpp:104 */
+    for (int i = 0; i < symbols; i++)                                  /* SymbolManager.cpp:104 */
+        soft_out[i] = d->imag_axis ? d->stage[5][i].im : d->stage[5][i].re;
     return symbols;
 }
 

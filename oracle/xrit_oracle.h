@@ -37,6 +37,32 @@ typedef struct { float re, im; } xo_cf;
 #define XO_MM_NSTEPS 128
 #define XO_MM_FUDGE  16
 
+/* ---- knobs for the semantics that cannot be checked against upstream ----
+ * libSatHelper is absent (PARITY UNPINNED above), so a handful of details of its blocks are design choices of
+ * this restatement, not facts.  Each has a knob; the defaults are the GNU Radio 3.7 behaviour the in-repo
+ * flowgraph wires (demodulator/demod_tcp_qt.py).  Objects read the knobs when they are created.
+ * tests/test_oracle_kat.py runs the implementation-independent known-answer tests over the whole knob matrix and
+ * records how far each knob moves the soft symbols. */
+typedef struct {
+    int fir_phase_last;   /* FirFilter with decimation D.  0: output m = sum h[k] x[m D - k] (taken at the FIRST sample
+                           * of each group of D, GNU Radio fir_filter_ccf).  1: sum h[k] x[m D + D-1 - k] (at the
+                           * last sample of the group: a loop that filters after collecting D samples). */
+    int mm_fudge;         /* ClockRecovery: samples held back beyond the 8 interpolator taps (GNU Radio: 16); 0..64 */
+    int mm_drop_tail;     /* 0: samples a call did not read are carried to the next call (chunk invariant, what
+                           * GNU Radio's scheduler does through consume_each).  1: every call starts reading at its
+                           * own first sample, the unread tail of the previous call is lost (a Work() that keeps only
+                           * mu / omega / the last symbols between calls). */
+    int costas_wrap_pi;   /* 0: phase wrapped by while-loops at +-2 pi (GNU Radio control_loop::phase_wrap).
+                           * 1: wrapped into (-pi, pi] every sample. */
+    int costas_imag_axis; /* SymbolManager.cpp:104: "old was imaginary due bug in libSatHelper costas loop".
+                           * 0: the loop locks with the data on the real axis (error = re * im) and the chain keeps
+                           * Re(symbol).  1: the old behaviour as far as that comment tells: data on the imaginary
+                           * axis (error = -re * im), the chain keeps Im(symbol). */
+} xo_knobs;
+void xo_knobs_default(xo_knobs *k);
+void xo_set_knobs(const xo_knobs *k);   /* NULL: defaults */
+void xo_get_knobs(xo_knobs *k);
+
 /* ---- tap designers (run once at start-up, demodulator.cpp:443-444) ---- */
 /* Filters::lowPass(gain, Fs, cutoff, transitionWidth, HAMMING, beta): returns
  * the tap count (GNU Radio firdes length rule); writes at most cap taps. */
@@ -64,7 +90,7 @@ void xo_agc_init(xo_agc *a, float rate, float reference, float gain, float max_g
 void xo_agc_work(xo_agc *a, const xo_cf *in, xo_cf *out, int n);
 
 /* ---- CostasLoop(loopBw, order=2) ---- */
-typedef struct { float phase, freq, alpha, beta, max_freq, min_freq; } xo_costas;
+typedef struct { float phase, freq, alpha, beta, max_freq, min_freq; int wrap_pi, imag_axis; } xo_costas;
 void xo_costas_init(xo_costas *c, float loop_bw);
 void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n);
 
