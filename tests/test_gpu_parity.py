@@ -475,6 +475,106 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
     assert np.array_equal(np.sign(gq[np.abs(wq) > 2]), np.sign(wq[np.abs(wq) > 2]))
 
 
+def test_host_program_symbol_manager_loss_semantics(xa, oracle_mod, tmp_path):
+    """--drop: SymbolManager's queue between the DSP thread and the sender thread, with the reference's two ways of
+    losing symbols (SymbolManager.cpp:78-83: everything queued is dropped while no decoder is connected; :97-101: a
+    chunk is dropped when the queue is full), and the queue fill reported as demodulatorFifoUsage
+    (decoder/src/Statistics.h:34)."""
+    import re
+    import socket
+    import subprocess
+    import threading
+    import time
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    n, block = 3000000, 250000
+    x = synth_signal(n)
+    f = tmp_path / "capture.cf32"
+    x.tofile(f)
+    od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
+    wq = oracle_mod.quantize_i8(np.concatenate([od.process(x[i:i + block]) for i in range(0, n, block)]))
+
+    def stats(err):
+        m = re.search(r"capacity (\d+), peak (\d+), demodulatorFifoUsage (\d+) % at end of input \(peak (\d+) %\), sent (\d+), "
+                      r"dropped while full (\d+), dropped while disconnected (\d+)", err)
+        assert m, err
+        return [int(v) for v in m.groups()]
+
+    def is_the_piece_at(gq, start):
+        """gq is the contiguous piece of the oracle's int8 stream that starts at `start` (to the 1-LSB truncation edges)"""
+        d = np.abs(gq.astype(np.int16) - wq[start:start + len(gq)].astype(np.int16))
+        return len(d) == len(gq) and d.max() <= 1 and np.mean(d == 0) > 0.98
+
+    # (1) the decoder starts listening 1.5 s into a paced run: what was demodulated before that is gone, what comes
+    #     after arrives complete and in order
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    port = srv.getsockname()[1]
+    got = bytearray()
+
+    def serve_late():
+        time.sleep(1.5)
+        srv.listen(1)
+        conn, _ = srv.accept()
+        while True:
+            b = conn.recv(65536)
+            if not b:
+                break
+            got.extend(b)
+        conn.close()
+
+    th = threading.Thread(target=serve_late)
+    th.start()
+    r = subprocess.run([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
+                        "--sink", f"tcp://127.0.0.1:{port}", "--stats", "--drop", "--paced"], capture_output=True, text=True,
+                       timeout=120)
+    th.join(timeout=30)
+    srv.close()
+    assert r.returncode == 0, r.stderr
+    cap, peak, use_end, use_peak, sent, d_full, d_disc = stats(r.stderr)
+    gq = np.frombuffer(bytes(got), np.int8)
+    assert cap == 1024 * 1024 and d_full == 0 and d_disc > 0 and sent == len(gq) > 100000
+    assert d_disc + sent == len(wq)
+    assert is_the_piece_at(gq, d_disc)                         # the stream resumes exactly where the dropped part ends
+    assert use_peak == peak * 100 // cap
+
+    # (2) a decoder that reads slowly and a small queue: chunks are dropped while the queue is full
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+    got2 = bytearray()
+
+    def serve_slow():
+        conn, _ = srv.accept()
+        t0 = time.time()
+        while True:
+            if time.time() - t0 < 2.0:
+                time.sleep(0.05)
+                b = conn.recv(2048)
+            else:
+                b = conn.recv(65536)
+            if not b:
+                break
+            got2.extend(b)
+        conn.close()
+
+    th = threading.Thread(target=serve_slow)
+    th.start()
+    r = subprocess.run([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
+                        "--sink", f"tcp://127.0.0.1:{port}", "--stats", "--drop", "--queue-symbols", "8192"],
+                       capture_output=True, text=True, timeout=120)
+    th.join(timeout=60)
+    srv.close()
+    assert r.returncode == 0, r.stderr
+    cap, peak, use_end, use_peak, sent, d_full, d_disc = stats(r.stderr)
+    g2 = np.frombuffer(bytes(got2), np.int8)
+    assert cap == 8192 and d_full > 0 and "SymbolManager Buffer is full!!! Dropping samples." in r.stderr
+    assert sent == len(g2) and sent + d_full + d_disc == len(wq)
+    assert use_peak >= 100                                       # a chunk is only refused once the queue is AT its capacity
+    assert is_the_piece_at(g2[:50000], 0)                        # up to the first drop the stream is the oracle's
+
+
 def test_host_program_output_locks_in_the_decoder(xa, tmp_path):
     """The whole plumbing against the decoder's own criteria: a capture of coded frames -> xrit_demod_host (the
     reference's 512 Ki-sample chunks) -> TCP -> what a decoder on the socket would do: correlate, align, fix the

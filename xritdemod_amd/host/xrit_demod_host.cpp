@@ -12,6 +12,13 @@
 //                               in pieces of at most 16384 bytes (SM_SOCKET_BUFFER_SIZE)
 //   * SymbolManager.cpp:23-35   the demodulator is the TCP *client*; it retries the
 //                               connection once per second until the decoder listens
+//   * SymbolManager.cpp:78-106  --drop: the reference's queue between the DSP thread and the sender thread, with its
+//                               loss behaviour: a chunk of symbols is DROPPED when 1 Mi symbols are already queued
+//                               ("SymbolManager Buffer is full!!! Dropping samples."), and everything queued is
+//                               dropped while no decoder is connected.  The default (no --drop) is lossless: the DSP
+//                               loop waits for the socket, which is what a file run at GPU speed wants.
+//   * decoder/src/Statistics.h:34  --stats reports the queue's fill as demodulatorFifoUsage (percent of its capacity,
+//                               one byte like the decoder's statistics field) with its peak and the drop counts
 //   * DiagManager.cpp:24-62,    --diag: the constellation tap -- after every chain call up to 1024 floats of
 //     demodulator.cpp:161-163   the complex symbols (I, Q interleaved) are queued; whenever 1024 are queued and
 //                               10 ms have passed they go out as int8 (x128, clamp, truncation) in one UDP
@@ -25,8 +32,10 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <deque>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +61,8 @@ struct Options {
     int connect_tries = 30;
     bool paced = false;
     bool stats = false;
+    bool drop = false;             // SymbolManager's queue and loss behaviour instead of back-pressure
+    size_t queue_symbols = 1024 * 1024;   // SM_MAX_SYMBOL_BUFFER (SymbolManager.h:23)
 };
 
 void usage()
@@ -60,7 +71,7 @@ void usage()
                  "usage: xrit_demod_host --input FILE [--format cf32|s16|s8] [--mode lrit|hrit]\n"
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
                  "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
-                 "         [--diag udp://HOST:PORT]\n");
+                 "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]]\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -82,6 +93,8 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--device") { if (!(v = need("--device"))) return false; o.device = std::atoi(v); }
         else if (a == "--connect-tries") { if (!(v = need("--connect-tries"))) return false; o.connect_tries = std::atoi(v); }
         else if (a == "--diag") { if (!(v = need("--diag"))) return false; o.diag = v; }
+        else if (a == "--queue-symbols") { if (!(v = need("--queue-symbols"))) return false; o.queue_symbols = (size_t)std::atoll(v); }
+        else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
@@ -180,6 +193,60 @@ struct Sink {
     }
 };
 
+// ---- SymbolManager's queue (--drop) ---------------------------------------------------------------------------
+// SymbolManager::add / ::process (SymbolManager.cpp:37-52,78-106): the DSP thread queues soft symbols, the sender
+// thread takes at most 16384 of them at a time, quantises (x127, clamp, C cast) and sends.  Two ways to lose
+// symbols, both kept: add() drops its whole chunk when the queue already holds `cap` symbols, process() empties
+// the queue while no decoder is connected.
+struct SymbolQueue {
+    std::deque<float> q;
+    std::mutex m;
+    size_t cap = 1024 * 1024;
+    size_t dropped_full = 0, dropped_disconnected = 0, peak = 0;
+
+    void add(const float *sym, size_t n)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (q.size() >= cap) {
+            std::fprintf(stderr, "SymbolManager Buffer is full!!! Dropping samples.\n");
+            dropped_full += n;
+            return;
+        }
+        q.insert(q.end(), sym, sym + n);
+        if (q.size() > peak) peak = q.size();
+    }
+    size_t take(int8_t *out, size_t max)
+    {
+        std::lock_guard<std::mutex> g(m);
+        const size_t n = q.size() < max ? q.size() : max;
+        for (size_t i = 0; i < n; ++i) {
+            float f = q.front() * 127;
+            f = f > 127 ? 127 : f;
+            f = f < -128 ? -128 : f;
+            out[i] = (int8_t)(char)f;
+            q.pop_front();
+        }
+        return n;
+    }
+    void clear_disconnected()
+    {
+        std::lock_guard<std::mutex> g(m);
+        dropped_disconnected += q.size();
+        q.clear();
+    }
+    size_t size()
+    {
+        std::lock_guard<std::mutex> g(m);
+        return q.size();
+    }
+    // decoder/src/Statistics.h:34: one byte, percent of the capacity (a chunk may overshoot the capacity: clamped)
+    static unsigned usage(size_t fill, size_t cap)
+    {
+        const size_t pc = cap ? fill * 100 / cap : 0;
+        return (unsigned)(pc > 255 ? 255 : pc);
+    }
+};
+
 // ---- constellation tap (DiagManager) -----------------------------------------------------------------------
 struct Diag {
     int fd = -1;
@@ -261,7 +328,56 @@ int main(int argc, char **argv)
     FILE *in = std::fopen(o.input.c_str(), "rb");
     if (!in) { std::perror("input"); xrit_demod_destroy(chain); return 1; }
     Sink sink;
-    if (!sink.open(o.sink, o.connect_tries)) { std::fclose(in); xrit_demod_destroy(chain); return 1; }
+    SymbolQueue queue;
+    queue.cap = o.queue_symbols;
+    std::atomic<bool> dsp_done{false};
+    std::thread sender;
+    if (o.drop) {
+        // the reference's symbolThread / process() loop: connect attempts happen HERE, next to the DSP, not before it
+        if (o.sink.rfind("tcp://", 0) != 0) { std::fprintf(stderr, "--drop needs a tcp:// sink\n"); std::fclose(in); xrit_demod_destroy(chain); return 2; }
+        const std::string hp = o.sink.substr(6);
+        const size_t c = hp.rfind(':');
+        if (c == std::string::npos) { std::fprintf(stderr, "sink: tcp://HOST:PORT expected\n"); std::fclose(in); xrit_demod_destroy(chain); return 2; }
+        sink.kind = Sink::TCP;
+        sink.host = hp.substr(0, c);
+        sink.port = std::atoi(hp.c_str() + c + 1);
+        sender = std::thread([&] {
+            std::vector<int8_t> buf(16384);
+            bool connected = false;
+            int failed = 0;
+            for (;;) {
+                if (!connected) {
+                    std::fprintf(stderr, "Trying to connect to decoder at %s:%d\n", sink.host.c_str(), sink.port);
+                    connected = sink.connect_once();
+                    if (!connected) {
+                        queue.clear_disconnected();          // SymbolManager.cpp:78-83
+                        if (dsp_done.load() && ++failed >= 2) return;
+                        std::this_thread::sleep_for(std::chrono::seconds(1));
+                        continue;
+                    }
+                }
+                const size_t n = queue.take(buf.data(), buf.size());
+                if (n == 0) {
+                    if (dsp_done.load()) return;
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    continue;
+                }
+                size_t off = 0;
+                while (off < n) {
+                    const ssize_t w = ::send(sink.fd, buf.data() + off, n - off, MSG_NOSIGNAL);
+                    if (w <= 0) {
+                        std::fprintf(stderr, "Disconnected from decoder.\n");
+                        ::close(sink.fd);
+                        sink.fd = -1;
+                        connected = false;
+                        break;                                 // the rest of this piece is lost, like the reference's
+                    }
+                    off += (size_t)w;
+                }
+                sink.sent += off;
+            }
+        });
+    } else if (!sink.open(o.sink, o.connect_tries)) { std::fclose(in); xrit_demod_destroy(chain); return 1; }
 
     Diag diag;
     std::vector<float> diag_iq;
@@ -293,9 +409,13 @@ int main(int argc, char **argv)
         size_t nsym = 0;
         rc = xrit_demod_process(chain, raw.data(), n, type, soft.data(), cap, &nsym);
         if (rc != XRIT_OK) { std::fprintf(stderr, "process: %s\n", xrit_last_error()); exit_code = 1; break; }
-        rc = xrit_quantize_i8(chain, soft.data(), q.data(), nsym);
-        if (rc != XRIT_OK) { std::fprintf(stderr, "quantize: %s\n", xrit_last_error()); exit_code = 1; break; }
-        if (!sink.send_all(q.data(), nsym)) { exit_code = 1; break; }
+        if (o.drop) {
+            queue.add(soft.data(), nsym);         // SymbolManager::add: never waits, may drop
+        } else {
+            rc = xrit_quantize_i8(chain, soft.data(), q.data(), nsym);
+            if (rc != XRIT_OK) { std::fprintf(stderr, "quantize: %s\n", xrit_last_error()); exit_code = 1; break; }
+            if (!sink.send_all(q.data(), nsym)) { exit_code = 1; break; }
+        }
         if (diag.fd >= 0 && nsym > 0) {
             // the first symbols of the call, complex (stage 4); only what the tap can take is copied back
             std::vector<float> all;
@@ -310,11 +430,22 @@ int main(int argc, char **argv)
         total_sym += nsym;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    const size_t fill_at_eof = o.drop ? queue.size() : 0;
+    if (o.drop) {
+        dsp_done.store(true);
+        sender.join();
+    }
     if (o.stats) {
         xrit_demod_stats st;
         if (xrit_demod_get_stats(chain, &st) == XRIT_OK)
             std::fprintf(stderr, "samples in %zu, symbols out %zu, %.3f s (%.2f Msamples/s incl. file and PCIe)\n",
                          total_in, total_sym, secs, secs > 0 ? total_in / secs * 1e-6 : 0.0);
+        if (o.drop)
+            std::fprintf(stderr, "symbol queue: capacity %zu, peak %zu, demodulatorFifoUsage %u %% at end of input (peak %u %%), "
+                                 "sent %zu, dropped while full %zu, dropped while disconnected %zu\n",
+                         queue.cap, queue.peak, SymbolQueue::usage(fill_at_eof, queue.cap),
+                         SymbolQueue::usage(queue.peak, queue.cap), sink.sent, queue.dropped_full,
+                         queue.dropped_disconnected);
     }
     sink.close_all();
     std::fclose(in);
