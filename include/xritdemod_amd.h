@@ -41,6 +41,12 @@ extern "C" {
 #define XRIT_SAMPLE_FLOATIQ 0
 #define XRIT_SAMPLE_S16IQ   1
 #define XRIT_SAMPLE_S8IQ    2
+/* not a FrontendDevice.h type: the RTL-SDR frontend converts its unsigned bytes itself and hands floats to
+ * onSamplesAvailable (RtlFrontend.cpp:102-116: lut[b] = (b - 128) / 127.f, then a running-average DC tracker with
+ * alpha = 1 - exp(-1 / (0.05 sampleRate)), :57).  With this type the chain takes the raw bytes and does that
+ * conversion on the device, statement for statement (including the reference's `i % 1`, which makes one average
+ * serve I and Q alike). */
+#define XRIT_SAMPLE_U8IQ    3
 
 const char *xrit_last_error(void);
 const char *xrit_version(void);
@@ -217,6 +223,13 @@ typedef struct xrit_fir     xrit_fir;      /* SatHelper::FirFilter      (demodul
 typedef struct xrit_agc     xrit_agc;      /* SatHelper::AGC            (:447) */
 typedef struct xrit_costas  xrit_costas;   /* SatHelper::CostasLoop     (:448) */
 typedef struct xrit_clock   xrit_clock;    /* SatHelper::ClockRecovery  (:449) */
+typedef struct xrit_rtl     xrit_rtl;      /* RtlFrontend's byte -> float conversion (RtlFrontend.cpp:102-116) */
+
+/* sample_rate: what RtlFrontend::SetSampleRate received (alpha of the DC tracker, RtlFrontend.cpp:57) */
+int  xrit_rtl_create(float sample_rate, int device, xrit_rtl **out);
+/* n_complex IQ pairs = 2 n_complex bytes in, 2 n_complex floats out (what the frontend passes to its callback) */
+int  xrit_rtl_work(xrit_rtl *r, const uint8_t *data, size_t n_complex, float *out_iq);
+void xrit_rtl_destroy(xrit_rtl *r);
 
 int  xrit_fir_create(unsigned decimation, const float *taps, int ntaps, int device, xrit_fir **out);
 /* FirFilter::Work(in, out, nOut): consumes nOut*decimation samples */

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libxrit_oracle.so")
 
-SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ = 0, 1, 2
+SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ, SAMPLE_U8IQ = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -44,6 +44,10 @@ class Agc(C.Structure):
 class Costas(C.Structure):
     _fields_ = [("phase", C.c_float), ("freq", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
                 ("max_freq", C.c_float), ("min_freq", C.c_float), ("wrap_pi", C.c_int), ("imag_axis", C.c_int)]
+
+
+class Rtl(C.Structure):
+    _fields_ = [("lut", C.c_float * 256), ("alpha", C.c_float), ("iavg", C.c_float), ("qavg", C.c_float)]
 
 
 class Knobs(C.Structure):
@@ -116,6 +120,8 @@ def lib():
         L.xo_sync_fix_frames.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
         L.xo_sync_fix_frames.restype = None
         L.xo_convert_samples.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.xo_rtl_init.argtypes = [C.POINTER(Rtl), C.c_float]
+        L.xo_rtl_work.argtypes = [C.POINTER(Rtl), vp, C.c_uint, vp]
         L.xo_knobs_default.argtypes = [C.POINTER(Knobs)]
         L.xo_set_knobs.argtypes = [C.POINTER(Knobs)]
         L.xo_get_knobs.argtypes = [C.POINTER(Knobs)]
@@ -218,6 +224,20 @@ class CostasLoop:
         return out
 
 
+class RtlIngest:
+    """RtlFrontend's byte -> float conversion (RtlFrontend.cpp:26-28,57,102-116)."""
+
+    def __init__(self, sample_rate):
+        self.s = Rtl()
+        lib().xo_rtl_init(C.byref(self.s), sample_rate)
+
+    def Work(self, data):
+        d = np.ascontiguousarray(data, np.uint8)
+        out = np.zeros(len(d), np.float32)
+        lib().xo_rtl_work(C.byref(self.s), _p(d), len(d), _p(out))
+        return out.view(np.complex64)
+
+
 class ClockRecovery:
     def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit):
         self._h = lib().xo_mm_create(omega, gain_omega, mu, gain_mu, omega_rel_limit)
@@ -287,6 +307,9 @@ class Demod:
             n = len(a)
         elif sample_type == SAMPLE_S16IQ:
             a = np.ascontiguousarray(samples, np.int16)
+            n = len(a) // 2
+        elif sample_type == SAMPLE_U8IQ:
+            a = np.ascontiguousarray(samples, np.uint8)
             n = len(a) // 2
         else:
             a = np.ascontiguousarray(samples, np.int8)

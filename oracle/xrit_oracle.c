@@ -529,6 +529,7 @@ struct xo_demod {
     int       stage_n[6];
     size_t    cap;
     int       imag_axis; /* knob costas_imag_axis: SymbolManager keeps Im(symbol) */
+    xo_rtl    rtl;       /* the RTL frontend's conversion state (XO_SAMPLE_U8IQ) */
 };
 
 /* main(), demodulator.cpp:436-450 */
@@ -550,6 +551,7 @@ xo_demod *xo_demod_create(const xo_config *cfg)
                          cfg->clock_omega_limit);
     d->rrc = xo_fir_create(1, d->rrc_taps, cfg->rrc_taps | 1);
     d->imag_axis = g_knobs.costas_imag_axis;
+    xo_rtl_init(&d->rtl, cfg->sample_rate);
     return d;
 }
 
@@ -562,6 +564,29 @@ void xo_demod_destroy(xo_demod *d)
     free(d->dec_taps);
     for (int i = 0; i < 6; i++) free(d->stage[i]);
     free(d);
+}
+
+/* RtlFrontend (RtlFrontend.cpp:26-28 table, :57 alpha, :102-116 conversion) */
+void xo_rtl_init(xo_rtl *r, float sample_rate)
+{
+    for (int i = 0; i < 256; i++) r->lut[i] = (i - 128) * (1.f / 127.f);
+    r->alpha = 1.f - exp(-1.0 / (sample_rate * 0.05f));
+    r->iavg = 0;
+    r->qavg = 0;
+}
+
+void xo_rtl_work(xo_rtl *r, const uint8_t *data, unsigned int length, float *iq)
+{
+    for (unsigned int i = 0; i < length; i++) {
+        iq[i] = r->lut[data[i]];
+        if (i % 1) {                                   /* sic: never true */
+            r->qavg += r->alpha * (iq[i] - r->qavg);
+            iq[i] -= r->qavg;
+        } else {
+            r->iavg += r->alpha * (iq[i] - r->iavg);
+            iq[i] -= r->iavg;
+        }
+    }
 }
 
 /* onSamplesAvailable, demodulator.cpp:54-74 (+ the FIFO -> complex
@@ -598,7 +623,10 @@ int xo_demod_process(xo_demod *d, const void *samples, int n, int sample_type,
         d->cap = (size_t)n;
     }
     int length = n;
-    xo_convert_samples(samples, sample_type, d->stage[0], (size_t)n);
+    if (sample_type == XO_SAMPLE_U8IQ)      /* the frontend converts, the callback receives FLOATIQ */
+        xo_rtl_work(&d->rtl, (const uint8_t *)samples, 2u * (unsigned int)n, (float *)d->stage[0]);
+    else
+        xo_convert_samples(samples, sample_type, d->stage[0], (size_t)n);
     const xo_cf *cur = d->stage[0];
     d->stage_n[0] = n;
     if (d->cfg.decimation > 1) {                       /* :136-140 */

@@ -32,6 +32,7 @@ typedef struct { float re, im; } xo_cf;
 #define XO_SAMPLE_FLOATIQ 0
 #define XO_SAMPLE_S16IQ   1
 #define XO_SAMPLE_S8IQ    2
+#define XO_SAMPLE_U8IQ    3   /* raw RTL-SDR bytes: converted as RtlFrontend.cpp:102-116 does before its callback */
 
 #define XO_MM_NTAPS  8
 #define XO_MM_NSTEPS 128
@@ -150,6 +151,12 @@ void xo_sync_correlate(const int8_t *data, uint32_t length, const uint64_t *word
 /* frame alignment + phase fix between correlator and Viterbi (decoder/src/newdecoder.cpp:239-270) */
 void xo_sync_fix_frames(const int8_t *data, size_t n, const uint32_t *word, const uint32_t *pos, const uint32_t *corr,
                         uint32_t frame, uint32_t min_corr, int8_t *frames, uint8_t *valid);
+/* RtlFrontend::internalCallback, RtlFrontend.cpp:102-116 (table :26-28, alpha :57): bytes -> floats with the
+ * frontend's running-average DC tracker; `length` bytes (2 per IQ pair), `length` floats out.  Literal, including
+ * the never-taken `if (i % 1)` that leaves ONE average for I and Q. */
+typedef struct { float lut[256]; float alpha, iavg, qavg; } xo_rtl;
+void xo_rtl_init(xo_rtl *r, float sample_rate);
+void xo_rtl_work(xo_rtl *r, const uint8_t *data, unsigned int length, float *iq);
 /* ingest conversion, demodulator.cpp:54-74 */
 void xo_convert_samples(const void *in, int sample_type, xo_cf *out, size_t n);
 

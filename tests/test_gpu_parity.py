@@ -280,6 +280,29 @@ def test_integer_ingest(xa, oracle_mod, stype):
         check_symbols(got, want)
 
 
+def test_rtl_u8_ingest(xa, oracle_mod):
+    """RtlFrontend.cpp:26-28,57,102-116: unsigned bytes -> (b - 128) / 127.f, then the frontend's running-average DC
+    tracker (one average for the interleaved I/Q stream: the reference's `i % 1`).  Stage against the oracle's
+    literal loop across calls (the average is carried), then the chain fed with raw bytes (XRIT_SAMPLE_U8IQ)."""
+    o = oracle_mod
+    x = synth_signal(600000, fs_in=2.5e6, symbol_rate=927000.0, alpha=0.3, amplitude=0.3)
+    u8 = np.clip(np.round(x.view(np.float32) * 127 + 128 + 3.0), 0, 255).astype(np.uint8)     # a DC offset of 3 LSB
+    ro, rg = o.RtlIngest(2.5e6), xa.RtlIngest(2.5e6)
+    for a, b in ((0, 2), (2, 200000), (200000, 200000), (200000, 1200000)):
+        yo, yg = ro.Work(u8[a:b]), rg.Work(u8[a:b])
+        assert len(yo) == len(yg) == (b - a) // 2
+        if b > a:
+            assert np.abs(yo - yg).max() <= 2e-7          # the scan composes the same maps with other roundings
+    want = o.Demod(o.config("hrit", 2.5e6, 1)).process(u8, o.SAMPLE_U8IQ)
+    got = xa.Demodulator(xa.Demodulator.config("hrit", 2.5e6, 1)).process(u8, xa.SAMPLE_U8IQ)
+    check_symbols(got, want)
+    # through the 5:1 decimator as well
+    x5 = synth_signal(1000000, fs_in=6.25e6, amplitude=0.3)
+    u5 = np.clip(np.round(x5.view(np.float32) * 127 + 128 - 2.0), 0, 255).astype(np.uint8)
+    check_symbols(xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5)).process(u5, xa.SAMPLE_U8IQ),
+                  o.Demod(o.config("lrit", 6.25e6, 5)).process(u5, o.SAMPLE_U8IQ))
+
+
 def test_golden_fixtures(xa):
     g = np.load(GOLD)
     dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))

@@ -171,6 +171,29 @@ def test_quantizer_and_ingest(oracle_mod):
     assert out[0] == np.complex64(127 / 128 - 1j) and out[1] == np.complex64(1 / 128)
 
 
+def test_rtl_ingest_kat(oracle_mod):
+    """RtlFrontend.cpp:26-28,57,102-116 by hand: table value, alpha, the first steps of the DC tracker -- with ONE
+    average for I and Q (the reference's `if (i % 1)` is never true) -- and the DC level it converges to."""
+    o = oracle_mod
+    r = o.RtlIngest(2560000.0)
+    assert r.s.lut[0] == np.float32(-128) * (np.float32(1) / np.float32(127)) and r.s.lut[128] == 0 and r.s.lut[255] == 1.0
+    assert r.s.alpha == np.float32(1.0 - np.exp(-1.0 / float(np.float32(2560000.0) * np.float32(0.05))))
+    y = r.Work(np.array([255, 0, 128, 200], np.uint8))
+    avg = np.float32(0)
+    want = []
+    for b in (255, 0, 128, 200):
+        v = np.float32(b - 128) * (np.float32(1) / np.float32(127))
+        avg = np.float32(avg + r.s.alpha * np.float32(v - avg))
+        want.append(np.float32(v - avg))
+    assert np.array_equal(y.view(np.float32), np.array(want, np.float32))
+    assert r.s.qavg == 0                                    # dead code upstream
+    # I at +10 LSB, Q at -4 LSB: the single average settles on their mean, 3 LSB
+    r = o.RtlIngest(2560000.0)
+    d = np.tile(np.array([138, 124], np.uint8), 2000000)
+    r.Work(d)
+    assert abs(r.s.iavg - 3.0 / 127) < 2e-4
+
+
 # ----------------------------------------------------------------------- chain
 @pytest.mark.parametrize("mode,fs,D,kw", [
     ("lrit", 1.25e6, 1, {}),

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libxritdemod_amd.so")
 
-SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ = 0, 1, 2
+SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ, SAMPLE_U8IQ = 0, 1, 2, 3
 
 
 class XritError(RuntimeError):
@@ -88,6 +88,9 @@ _SIGNATURES = {
     "xrit_clock_set_serial": (C.c_int, [_vp, C.c_int]),
     "xrit_clock_destroy": (None, [_vp]),
     "xrit_device_read_bandwidth": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, C.POINTER(C.c_double)]),
+    "xrit_rtl_create": (C.c_int, [C.c_float, C.c_int, C.POINTER(_vp)]),
+    "xrit_rtl_work": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "xrit_rtl_destroy": (None, [_vp]),
     "xrit_synth_defaults": (None, [C.POINTER(SynthParams)]),
     "xrit_synth_generate_device": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, _sz, _vp, C.c_int, _vp]),
 }
@@ -265,6 +268,22 @@ class ClockRecovery(_Handle):
         return out[:n.value].copy()
 
 
+class RtlIngest(_Handle):
+    """RtlFrontend's byte -> float conversion with its DC tracker (RtlFrontend.cpp:26-28,57,102-116)."""
+    _destroy = "xrit_rtl_destroy"
+
+    def __init__(self, sample_rate, device=0):
+        super().__init__()
+        _check(lib().xrit_rtl_create(sample_rate, device, C.byref(self._h)))
+
+    def Work(self, data):
+        d = np.ascontiguousarray(data, np.uint8)
+        n = len(d) // 2
+        out = np.zeros(n, np.complex64)
+        _check(lib().xrit_rtl_work(self._h, _p(d), n, _p(out)))
+        return out
+
+
 class Demodulator(_Handle):
     """The chain of processSamples() (demodulator.cpp:100-168) behind one handle."""
     _destroy = "xrit_demod_destroy"
@@ -307,6 +326,9 @@ class Demodulator(_Handle):
             n = len(a)
         elif sample_type == SAMPLE_S16IQ:
             a = np.ascontiguousarray(samples, np.int16)
+            n = len(a) // 2
+        elif sample_type == SAMPLE_U8IQ:
+            a = np.ascontiguousarray(samples, np.uint8)
             n = len(a) // 2
         else:
             a = np.ascontiguousarray(samples, np.int8)

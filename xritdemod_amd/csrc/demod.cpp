@@ -51,7 +51,8 @@ struct xrit_demod {
     AgcStage agc;
     CostasStage costas;
     ClockStage clock;
-    DevBuf bufA, bufB, bufC, stat, in_dev, soft_dev, q_in, q_out;
+    DevBuf bufA, bufB, bufC, bufR, stat, in_dev, soft_dev, q_in, q_out;
+    RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
     bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
@@ -67,6 +68,7 @@ struct xrit_fir { int device; hipStream_t stream; FirStage st; DevBuf in, out; }
 struct xrit_agc { int device; hipStream_t stream; AgcStage st; DevBuf in, out; };
 struct xrit_costas { int device; hipStream_t stream; CostasStage st; DevBuf in, out; };
 struct xrit_clock { int device; hipStream_t stream; ClockStage st; DevBuf in, out; };
+struct xrit_rtl { int device; hipStream_t stream; RtlIngestStage st; DevBuf in, out; };
 
 template <typename H> static int stage_open(H *h, int device)
 {
@@ -185,6 +187,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
+        if ((rc = d->rtl.init(cfg->sample_rate)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
         if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
@@ -205,7 +208,7 @@ void xrit_demod_destroy(xrit_demod *d)
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    d->bufA.release(); d->bufB.release(); d->bufC.release(); d->stat.release();
+    d->bufA.release(); d->bufB.release(); d->bufC.release(); d->bufR.release(); d->stat.release(); d->rtl.release();
     d->in_dev.release(); d->soft_dev.release();
     d->q_in.release(); d->q_out.release();
     for (auto &b : d->stage_buf) b.release();
@@ -238,6 +241,13 @@ struct SliceIO {
 static int front_end(xrit_demod *d, const void *in, size_t n, int type, hipStream_t s, Profiler *prof, SliceIO *io)
 {
     const unsigned D = d->cfg.decimation;
+    if (type == XRIT_SAMPLE_U8IQ) {
+        // RtlFrontend::internalCallback (RtlFrontend.cpp:102-116) hands FLOATIQ to onSamplesAvailable
+        XR_TRY(d->bufR.reserve((n + 8) * sizeof(float2)));
+        XR_TRY(d->rtl.run(in, d->bufR.as<float2>(), n, s, prof));
+        in = d->bufR.p;
+        type = XRIT_SAMPLE_FLOATIQ;
+    }
     size_t length = n;
     if (D > 1) length = n / D;   // demodulator.cpp:137 -- the remainder of the chunk is dropped
     io->length = length;
@@ -336,7 +346,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
                               size_t *n_out, void *stream)
 {
     if (!d || !n_out || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
-    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    if (type < 0 || type > 3) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
     *n_out = 0;
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
@@ -402,7 +412,7 @@ int xrit_demod_process(xrit_demod *d, const void *samples, size_t n, int type, f
                        size_t *n_out)
 {
     if (!d || !n_out || (n && !samples) || (cap && !soft_out)) { set_error("null argument"); return XRIT_E_INVALID; }
-    if (type < 0 || type > 2) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    if (type < 0 || type > 3) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
     XR_HIP(hipSetDevice(d->device));
     const size_t esz = type == XRIT_SAMPLE_FLOATIQ ? 8 : (type == XRIT_SAMPLE_S16IQ ? 4 : 2);
     XR_TRY(d->in_dev.reserve(n * esz + 16));
@@ -703,6 +713,34 @@ int xrit_clock_set_serial(xrit_clock *c, int serial)
 }
 
 void xrit_clock_destroy(xrit_clock *c) { stage_close(c); }
+
+int xrit_rtl_create(float sample_rate, int device, xrit_rtl **out)
+{
+    if (!out || !(sample_rate > 0)) { set_error("bad argument"); return XRIT_E_INVALID; }
+    xrit_rtl *r = new (std::nothrow) xrit_rtl();
+    if (!r) return XRIT_E_NOMEM;
+    r->stream = nullptr;
+    int rc = stage_open(r, device);
+    if (rc == XRIT_OK) rc = r->st.init(sample_rate);
+    if (rc != XRIT_OK) { stage_close(r); return rc; }
+    *out = r;
+    return XRIT_OK;
+}
+
+int xrit_rtl_work(xrit_rtl *r, const uint8_t *data, size_t n_complex, float *out_iq)
+{
+    if (!r || (n_complex && (!data || !out_iq))) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(r->device));
+    XR_TRY(r->in.reserve(2 * n_complex + 16));
+    XR_TRY(r->out.reserve((n_complex + 8) * sizeof(float2)));
+    if (n_complex) XR_HIP(hipMemcpyAsync(r->in.p, data, 2 * n_complex, hipMemcpyHostToDevice, r->stream));
+    XR_TRY(r->st.run(r->in.p, r->out.as<float2>(), n_complex, r->stream, nullptr));
+    if (n_complex) XR_HIP(hipMemcpyAsync(out_iq, r->out.p, n_complex * sizeof(float2), hipMemcpyDeviceToHost, r->stream));
+    XR_HIP(hipStreamSynchronize(r->stream));
+    return XRIT_OK;
+}
+
+void xrit_rtl_destroy(xrit_rtl *r) { stage_close(r); }
 
 // ---------------------------------------------------------------- synth
 void xrit_synth_defaults(xrit_synth_params *p)

@@ -50,6 +50,17 @@ struct AgcEpilogue {
     float rate, ref, maxg;
 };
 
+// ---- RTL-SDR ingest (RtlFrontend.cpp:26-28,57,102-116): u8 IQ -> float IQ with the frontend's DC tracker ----
+struct RtlIngestStage {
+    float alpha = 0;
+    DevBuf state;    // running average, ping-pong across calls
+    DevBuf aggs;
+    int cur = 0;
+    int init(float sample_rate);
+    void release();
+    int run(const void *in_u8, float2 *out, size_t n_complex, hipStream_t s, Profiler *prof);
+};
+
 // ---- AGC (demodulator.cpp:447; Work at :143) ------------------------------
 struct AgcStage {
     float rate = 0, ref = 0, maxg = 0;

@@ -68,7 +68,7 @@ struct Options {
 void usage()
 {
     std::fprintf(stderr,
-                 "usage: xrit_demod_host --input FILE [--format cf32|s16|s8] [--mode lrit|hrit]\n"
+                 "usage: xrit_demod_host --input FILE [--format cf32|s16|s8|u8] [--mode lrit|hrit]\n"
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
                  "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
                  "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]]\n");
@@ -311,6 +311,7 @@ int main(int argc, char **argv)
     if (o.format == "cf32") { type = XRIT_SAMPLE_FLOATIQ; bytes_per_sample = 8; }
     else if (o.format == "s16") { type = XRIT_SAMPLE_S16IQ; bytes_per_sample = 4; }
     else if (o.format == "s8") { type = XRIT_SAMPLE_S8IQ; bytes_per_sample = 2; }
+    else if (o.format == "u8") { type = XRIT_SAMPLE_U8IQ; bytes_per_sample = 2; }      // raw rtl_sdr capture
     else { usage(); return 2; }
 
     xrit_demod_config cfg;
