@@ -292,7 +292,7 @@ def test_rtl_u8_ingest(xa, oracle_mod):
         yo, yg = ro.Work(u8[a:b]), rg.Work(u8[a:b])
         assert len(yo) == len(yg) == (b - a) // 2
         if b > a:
-            assert np.abs(yo - yg).max() <= 2e-7          # the scan composes the same maps with other roundings
+            assert np.abs(yo - yg).max() <= 1e-6          # the serial float32 average gathers ~4e-7 of rounding
     want = o.Demod(o.config("hrit", 2.5e6, 1)).process(u8, o.SAMPLE_U8IQ)
     got = xa.Demodulator(xa.Demodulator.config("hrit", 2.5e6, 1)).process(u8, xa.SAMPLE_U8IQ)
     check_symbols(got, want)
@@ -585,7 +585,7 @@ def test_host_program_symbol_manager_loss_semantics(xa, oracle_mod, tmp_path):
     th = threading.Thread(target=serve_slow)
     th.start()
     r = subprocess.run([host_bin, "--input", str(f), "--mode", "lrit", "--sample-rate", "1250000", "--block", str(block),
-                        "--sink", f"tcp://127.0.0.1:{port}", "--stats", "--drop", "--queue-symbols", "8192"],
+                        "--sink", f"tcp://127.0.0.1:{port}", "--stats", "--drop", "--queue-symbols", "8192", "--sndbuf", "8192"],
                        capture_output=True, text=True, timeout=120)
     th.join(timeout=60)
     srv.close()

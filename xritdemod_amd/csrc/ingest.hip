@@ -12,7 +12,8 @@
 namespace xrit {
 
 struct RtlScanF {
-    typedef float2 T;                 // (a, b): avg -> a * avg + b
+    typedef double2 T;                // (a, b): avg -> a * avg + b.  Double: 1 - alpha is 1 - 8e-6, which float32
+                                      // holds to 0.4 % of alpha -- composed in float the average drifts from the serial one
     const unsigned char *in;
     float *out;                       // 2n floats (interleaved I, Q)
     const float *avg_in;
@@ -20,21 +21,21 @@ struct RtlScanF {
     float alpha;
     long long nbytes;
     __device__ static float lut(unsigned char b) { return (float)((int)b - 128) * (1.f / 127.f); }
-    __device__ T identity() const { return make_float2(1.f, 0.f); }
-    __device__ T combine(const T &lo, const T &hi) const { return make_float2(hi.x * lo.x, hi.x * lo.y + hi.y); }
+    __device__ T identity() const { return make_double2(1.0, 0.0); }
+    __device__ T combine(const T &lo, const T &hi) const { return make_double2(hi.x * lo.x, hi.x * lo.y + hi.y); }
     __device__ T reduce_run(long long i0, int cnt) const
     {
         T m = identity();
         for (int k = 0; k < cnt; ++k) {
             const float v = lut(in[i0 + k]);
             // avg' = avg + alpha * (v - avg)
-            m = combine(m, make_float2(1.f - alpha, alpha * v));
+            m = combine(m, make_double2(1.0 - (double)alpha, (double)alpha * (double)v));
         }
         return m;
     }
     __device__ void apply_run(long long i0, int cnt, const T &pre) const
     {
-        float avg = pre.x * avg_in[0] + pre.y;
+        float avg = (float)(pre.x * (double)avg_in[0] + pre.y);
         for (int k = 0; k < cnt; ++k) {
             float v = lut(in[i0 + k]);
             avg += alpha * (v - avg);
@@ -66,13 +67,13 @@ int RtlIngestStage::run(const void *in_u8, float2 *out, size_t n_complex, hipStr
     if (n_complex == 0) return XRIT_OK;
     const long long nb_ = (long long)n_complex * 2;
     const int nb = scan_blocks(nb_);
-    XR_TRY(aggs.reserve((size_t)(nb + scan_blocks(nb) + 4) * sizeof(float2)));
+    XR_TRY(aggs.reserve((size_t)(nb + scan_blocks(nb) + 4) * sizeof(double2)));
     RtlScanF f{reinterpret_cast<const unsigned char *>(in_u8), reinterpret_cast<float *>(out), state.as<float>() + cur,
                state.as<float>() + (cur ^ 1), alpha, nb_};
     ProfScope ps(prof, "rtl_ingest", s);
-    hipLaunchKernelGGL(scan_reduce_kernel<RtlScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, nb_, aggs.as<float2>());
-    scan_aggs_launch(f, aggs.as<float2>(), nb, s);
-    hipLaunchKernelGGL(scan_apply_kernel<RtlScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, nb_, aggs.as<float2>());
+    hipLaunchKernelGGL(scan_reduce_kernel<RtlScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, nb_, aggs.as<double2>());
+    scan_aggs_launch(f, aggs.as<double2>(), nb, s);
+    hipLaunchKernelGGL(scan_apply_kernel<RtlScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, nb_, aggs.as<double2>());
     XR_HIP(hipGetLastError());
     cur ^= 1;
     return XRIT_OK;

@@ -63,6 +63,7 @@ struct Options {
     bool stats = false;
     bool drop = false;             // SymbolManager's queue and loss behaviour instead of back-pressure
     size_t queue_symbols = 1024 * 1024;   // SM_MAX_SYMBOL_BUFFER (SymbolManager.h:23)
+    int sndbuf = 0;                // > 0: SO_SNDBUF of the decoder socket (the kernel's default grows to megabytes)
 };
 
 void usage()
@@ -71,7 +72,7 @@ void usage()
                  "usage: xrit_demod_host --input FILE [--format cf32|s16|s8|u8] [--mode lrit|hrit]\n"
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
                  "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
-                 "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]]\n");
+                 "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -94,6 +95,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--connect-tries") { if (!(v = need("--connect-tries"))) return false; o.connect_tries = std::atoi(v); }
         else if (a == "--diag") { if (!(v = need("--diag"))) return false; o.diag = v; }
         else if (a == "--queue-symbols") { if (!(v = need("--queue-symbols"))) return false; o.queue_symbols = (size_t)std::atoll(v); }
+        else if (a == "--sndbuf") { if (!(v = need("--sndbuf"))) return false; o.sndbuf = std::atoi(v); }
         else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
@@ -110,6 +112,7 @@ struct Sink {
     std::string host;
     int port = 0;
     int tries = 30;
+    int sndbuf = 0;
     size_t sent = 0;
 
     bool open(const std::string &spec, int connect_tries)
@@ -141,6 +144,7 @@ struct Sink {
         hints.ai_socktype = SOCK_STREAM;
         if (getaddrinfo(host.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res) return false;
         fd = ::socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+        if (fd >= 0 && sndbuf > 0) (void)setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &sndbuf, sizeof sndbuf);
         bool ok = fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0;
         freeaddrinfo(res);
         if (!ok) {
@@ -331,6 +335,7 @@ int main(int argc, char **argv)
     Sink sink;
     SymbolQueue queue;
     queue.cap = o.queue_symbols;
+    sink.sndbuf = o.sndbuf;
     std::atomic<bool> dsp_done{false};
     std::thread sender;
     if (o.drop) {
