@@ -128,6 +128,11 @@ int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int
 /* Same with device-resident input and output (no PCIe in the call). */
 int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type,
                               float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* Back to the state right after xrit_demod_create (filter histories, gain, loop states, unread tail), without
+ * giving up the device buffers: the start of another stream.  Also revives a handle a failed call left unusable. */
+int xrit_demod_reset(xrit_demod *d, void *stream);
+/* the hipStream_t the handle runs on when a call passes stream = NULL */
+void *xrit_demod_stream(xrit_demod *d);
 /* symbols per sample as the reference computes it (demodulator.cpp:437) */
 float xrit_demod_sps(const xrit_demod *d);
 int   xrit_demod_decimator_ntaps(const xrit_demod *d);
@@ -267,6 +272,56 @@ typedef struct xrit_synth_params {
 void xrit_synth_defaults(xrit_synth_params *p);
 int  xrit_synth_generate_device(const xrit_synth_params *p, uint64_t start, size_t n,
                                 float *d_out_interleaved, int device, void *stream);
+
+/* ------------------------------------------------------------------------
+ * One capture across the GPUs of a node.  The reference runs the
+ * chain on one CPU thread (demodulator.cpp:170-175); a burst is cut here in
+ * `world` time slices, one per GPU, and three small things cross GPUs -- RCCL
+ * ncclSend / ncclRecv over xGMI and one ncclAllGather of two integers per rank:
+ * the halo (the last xrit_group_halo_samples() input samples of rank g-1, which
+ * rank g demodulates first from a cold start), the last 256 soft symbols of rank
+ * g-1 (Costas pi ambiguity, straddling symbol), and (relative polarity, symbol
+ * count) of every rank (-> absolute polarity, output offset).  Independent
+ * capture segments need none of it: every rank uses xrit_group_chain() as a
+ * plain chain handle.
+ * ------------------------------------------------------------------------ */
+typedef struct xrit_group xrit_group;
+#define XRIT_GROUP_ID_BYTES 128
+/* One process per GPU: rank 0 makes the id (ncclGetUniqueId), the launcher hands
+ * it to every rank (environment, file, MPI, torch.distributed ...), every rank
+ * calls xrit_group_create with cfg->device = its GPU (collective call). */
+int xrit_group_unique_id(void *id /* [XRIT_GROUP_ID_BYTES] */);
+int xrit_group_create(const xrit_demod_config *cfg, int rank, int world, const void *id, xrit_group **out);
+/* One process driving `world` GPUs (ncclCommInitAll): out[0..world) are the ranks'
+ * handles, to be used from one thread each. */
+int xrit_group_create_all(const xrit_demod_config *cfg, const int *devices, int world, xrit_group **out);
+/* The same exchange without RCCL: ranks are threads of one process that hand
+ * their buffers over through device-to-device copies (hipMemcpyPeer across
+ * GPUs).  What a single-GPU box can run: several ranks on one device. */
+typedef struct xrit_local_fabric xrit_local_fabric;
+int  xrit_local_fabric_create(int world, xrit_local_fabric **out);
+void xrit_local_fabric_destroy(xrit_local_fabric *f);
+int  xrit_group_create_local(const xrit_demod_config *cfg, int rank, xrit_local_fabric *fabric, xrit_group **out);
+void xrit_group_destroy(xrit_group *g);
+xrit_demod *xrit_group_chain(xrit_group *g);
+int    xrit_group_rank(const xrit_group *g);
+int    xrit_group_world(const xrit_group *g);
+size_t xrit_group_halo_samples(const xrit_group *g);
+/* Collective: every rank passes ITS slice (n samples, device resident, slices in
+ * rank order make up the burst; n >= the halo) and receives its symbols in the
+ * stream's polarity with their offset in the burst's symbol sequence: rank r's
+ * symbols are out[offset .. offset + n_out) of what one chain would emit for the
+ * whole burst (to the clock recovery's floor; a rank that locked pi away from
+ * rank 0 has its symbols negated).  The chain of every rank restarts cold per
+ * call: consecutive calls are consecutive bursts only in the sense of rank 0. */
+int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t n_complex, int sample_type,
+                                    float *d_soft_out, size_t cap, size_t *n_out, uint64_t *offset_out,
+                                    int *polarity_out, void *stream);
+/* the same with host buffers (one H2D / D2H round trip per call, like xrit_demod_process) */
+int xrit_group_process_slice_host(xrit_group *g, const void *samples, size_t n_complex, int sample_type, float *soft_out,
+                                  size_t cap, size_t *n_out, uint64_t *offset_out, int *polarity_out);
+/* max over the ranks (timing: the slowest rank's seconds) */
+int xrit_group_allreduce_max(xrit_group *g, double *value, void *stream);
 
 /* ------------------------------------------------------------------------
  * Measurement helper ("also measure a device read microbenchmark

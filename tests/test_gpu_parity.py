@@ -700,6 +700,72 @@ def test_contiguous_split_on_device(xa, same_lock):
     assert e1 < (6e-4 if same_lock else 3e-3)
 
 
+def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
+    """xrit_group_* (C++) with the in-process fabric: two ranks as two threads on this GPU cut one
+    burst in two slices -- halo, boundary symbols, (polarity, count) all-gather, all behind the C ABI.  The joined
+    output is the uninterrupted chain's: same symbol count, same hard decisions, rank 0's part to the chaos floor,
+    rank 1's (cold start over the halo; pi away from the stream it is a different, equally valid lock) to 3e-3."""
+    import threading
+    import torch
+    n, D = 1200000, 5
+    x = synth_signal(2 * n, fs_in=6.25e6)
+    want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, D)).process(x)
+    fabric = xa.LocalFabric(2)
+    dev = torch.device("cuda", 0)
+    xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+    res, err = [None, None], []
+
+    def rank_main(r):
+        try:
+            g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), r, fabric=fabric)
+            assert g.world == 2 and g.rank == r and g.halo_samples % D == 0 and 400000 < g.halo_samples < n
+            cap = n // D + 1024
+            soft = torch.empty(cap, dtype=torch.float32, device=dev)
+            sl = xt[r * n:(r + 1) * n].contiguous()
+            for _ in range(2):                                  # a second burst on the same handles: same answer
+                k, off, pol = g.process_slice_device(sl.data_ptr(), n, soft.data_ptr(), cap)
+            res[r] = (soft[:k].cpu().numpy(), off, pol)
+        except Exception as e:          # noqa: BLE001
+            err.append(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not err, err
+    (s0, off0, pol0), (s1, off1, pol1) = res
+    assert off0 == 0 and pol0 == 1 and off1 == len(s0) and abs(pol1) == 1
+    got = np.concatenate([s0, s1])
+    assert len(got) == len(want)
+    big = np.abs(want) > 1e-3
+    assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
+    assert rms(s0 - want[:len(s0)]) < 3.2e-4
+    assert rms(s1 - want[len(s0):]) < (3.2e-4 if pol1 == 1 else 3e-3)
+
+
+def test_group_api_over_rccl_with_one_rank(xa, oracle_mod):
+    """The RCCL transport (ncclGetUniqueId / ncclCommInitRank) on the one GPU this box has: a world of one rank, so no
+    exchange happens, but the communicator is real and the slice call is the cold-started chain."""
+    import torch
+    n, D = 600000, 5
+    x = synth_signal(n, fs_in=6.25e6)
+    dev = torch.device("cuda", 0)
+    xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+    uid = xa.group_unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), 0, 1, uid)
+    cap = n // D + 1024
+    soft = torch.empty(cap, dtype=torch.float32, device=dev)
+    k, off, pol = g.process_slice_device(xt.data_ptr(), n, soft.data_ptr(), cap)
+    ref = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D)).process(x)
+    assert (off, pol) == (0, 1) and k == len(ref) and np.array_equal(soft[:k].cpu().numpy(), ref)
+    assert g.allreduce_max(1.5) == 1.5
+    # independent segments: the rank's chain as a plain handle
+    k2 = g.chain_process_device(xt.data_ptr(), n, soft.data_ptr(), cap)
+    assert k2 > 0
+
+
 def test_agc_inside_the_matched_filter_fill_is_the_same_chain(xa, oracle_mod):
     """With a decimator in front and nobody reading the AGC stage, the AGC never sweeps the stream itself: its
     composed run maps come out of the decimator's epilogue and the matched filter applies the gains while it

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "xrit_demod_destroy": (None, [_vp]),
     "xrit_demod_process": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "xrit_demod_process_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),
+    "xrit_demod_reset": (C.c_int, [_vp, _vp]),
+    "xrit_demod_stream": (_vp, [_vp]),
     "xrit_demod_sps": (C.c_float, [_vp]),
     "xrit_demod_decimator_ntaps": (C.c_int, [_vp]),
     "xrit_demod_keep_stages": (C.c_int, [_vp, C.c_int]),
@@ -87,6 +89,22 @@ _SIGNATURES = {
     "xrit_clock_work": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "xrit_clock_set_serial": (C.c_int, [_vp, C.c_int]),
     "xrit_clock_destroy": (None, [_vp]),
+    "xrit_group_unique_id": (C.c_int, [_vp]),
+    "xrit_group_create": (C.c_int, [C.POINTER(DemodConfig), C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "xrit_group_create_all": (C.c_int, [C.POINTER(DemodConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "xrit_local_fabric_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "xrit_local_fabric_destroy": (None, [_vp]),
+    "xrit_group_create_local": (C.c_int, [C.POINTER(DemodConfig), C.c_int, _vp, C.POINTER(_vp)]),
+    "xrit_group_destroy": (None, [_vp]),
+    "xrit_group_chain": (_vp, [_vp]),
+    "xrit_group_rank": (C.c_int, [_vp]),
+    "xrit_group_world": (C.c_int, [_vp]),
+    "xrit_group_halo_samples": (_sz, [_vp]),
+    "xrit_group_process_slice_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_int), _vp]),
+    "xrit_group_process_slice_host": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64),
+                                                C.POINTER(C.c_int)]),
+    "xrit_group_allreduce_max": (C.c_int, [_vp, C.POINTER(C.c_double), _vp]),
     "xrit_device_read_bandwidth": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, C.POINTER(C.c_double)]),
     "xrit_rtl_create": (C.c_int, [C.c_float, C.c_int, C.POINTER(_vp)]),
     "xrit_rtl_work": (C.c_int, [_vp, _vp, _sz, _vp]),
@@ -316,6 +334,10 @@ class Demodulator(_Handle):
     def decimator_ntaps(self):
         return lib().xrit_demod_decimator_ntaps(self._h)
 
+    def reset(self, stream=None):
+        """Back to the freshly created state (another stream begins); device buffers are kept."""
+        _check(lib().xrit_demod_reset(self._h, C.c_void_p(stream) if stream else None))
+
     def keep_stages(self, enable=True):
         _check(lib().xrit_demod_keep_stages(self._h, int(enable)))
 
@@ -383,6 +405,75 @@ class Demodulator(_Handle):
 def synth_generate_device(params, start, n, d_out_ptr, device=0, stream=None):
     _check(lib().xrit_synth_generate_device(C.byref(params), start, n, C.c_void_p(d_out_ptr), device,
                                             C.c_void_p(stream) if stream else None))
+
+
+GROUP_ID_BYTES = 128
+
+
+def group_unique_id():
+    """ncclGetUniqueId as bytes: rank 0 makes it, the launcher hands it to every rank."""
+    buf = (C.c_char * GROUP_ID_BYTES)()
+    _check(lib().xrit_group_unique_id(buf))
+    return bytes(buf)
+
+
+class LocalFabric(_Handle):
+    """In-process exchange between the ranks of a Group (threads of one process)."""
+    _destroy = "xrit_local_fabric_destroy"
+
+    def __init__(self, world):
+        super().__init__()
+        self.world = world
+        _check(lib().xrit_local_fabric_create(world, C.byref(self._h)))
+
+
+class Group(_Handle):
+    """One capture across the GPUs of a node (xrit_group_*): Group(cfg, rank, world, unique_id) with RCCL, or
+    Group(cfg, rank, fabric=LocalFabric(world)) for ranks that are threads of one process."""
+    _destroy = "xrit_group_destroy"
+
+    def __init__(self, cfg, rank, world=None, unique_id=None, fabric=None):
+        super().__init__()
+        self.cfg = cfg
+        self._fabric = fabric
+        if fabric is not None:
+            _check(lib().xrit_group_create_local(C.byref(cfg), rank, fabric._h, C.byref(self._h)))
+        else:
+            idb = (C.c_char * GROUP_ID_BYTES).from_buffer_copy(unique_id)
+            _check(lib().xrit_group_create(C.byref(cfg), rank, world, idb, C.byref(self._h)))
+
+    @property
+    def halo_samples(self):
+        return lib().xrit_group_halo_samples(self._h)
+
+    @property
+    def rank(self):
+        return lib().xrit_group_rank(self._h)
+
+    @property
+    def world(self):
+        return lib().xrit_group_world(self._h)
+
+    def chain_process_device(self, d_samples_ptr, n, d_soft_ptr, cap, sample_type=SAMPLE_FLOATIQ, stream=None):
+        """Independent segments: the rank's own chain, no exchange."""
+        n_out = C.c_size_t(0)
+        _check(lib().xrit_demod_process_device(lib().xrit_group_chain(self._h), C.c_void_p(d_samples_ptr), n, sample_type,
+                                               C.c_void_p(d_soft_ptr), cap, C.byref(n_out),
+                                               C.c_void_p(stream) if stream else None))
+        return n_out.value
+
+    def process_slice_device(self, d_samples_ptr, n, d_soft_ptr, cap, sample_type=SAMPLE_FLOATIQ, stream=None):
+        """Collective: (symbol count, offset in the burst's symbol sequence, absolute polarity)."""
+        n_out, off, pol = C.c_size_t(0), C.c_uint64(0), C.c_int(1)
+        _check(lib().xrit_group_process_slice_device(self._h, C.c_void_p(d_samples_ptr), n, sample_type,
+                                                     C.c_void_p(d_soft_ptr), cap, C.byref(n_out), C.byref(off),
+                                                     C.byref(pol), C.c_void_p(stream) if stream else None))
+        return n_out.value, off.value, pol.value
+
+    def allreduce_max(self, value, stream=None):
+        v = C.c_double(value)
+        _check(lib().xrit_group_allreduce_max(self._h, C.byref(v), C.c_void_p(stream) if stream else None))
+        return v.value
 
 
 def device_read_bandwidth(d_buf_ptr, nbytes, reps=10, device=0, stream=None):

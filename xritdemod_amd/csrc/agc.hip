@@ -93,16 +93,29 @@ __global__ void agc_begin_kernel(float *state_out)
     state_out[1] = 0.0f;
 }
 
-int AgcStage::init(float rate_, float reference, float gain0, float max_gain)
+int AgcStage::init(float rate_, float reference, float gain0_, float max_gain)
 {
     rate = rate_;
     ref = reference;
     maxg = max_gain;
+    gain0 = gain0_;
     XR_TRY(state.reserve(4 * sizeof(float)));
-    float h[4] = {gain0, 0.0f, gain0, 0.0f};   // two (gain, flag) slots, ping-pong
+    float h[4] = {gain0_, 0.0f, gain0_, 0.0f};   // two (gain, flag) slots, ping-pong
     XR_HIP(hipMemcpy(state.p, h, sizeof h, hipMemcpyHostToDevice));
     if (!h_flag) XR_HIP(hipHostMalloc((void **)&h_flag, 64));
     *h_flag = 0.0f;
+    cur = 0;
+    return XRIT_OK;
+}
+
+__global__ void agc_reset_kernel(float *st, float g)
+{
+    st[0] = g; st[1] = 0.f; st[2] = g; st[3] = 0.f;
+}
+
+int AgcStage::reset(hipStream_t s)
+{
+    hipLaunchKernelGGL(agc_reset_kernel, dim3(1), dim3(1), 0, s, state.as<float>(), gain0);
     cur = 0;
     return XRIT_OK;
 }

@@ -926,6 +926,23 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     return XRIT_OK;
 }
 
+__global__ void clock_state_reset_kernel(ClockState *st, float mu, float omega)
+{
+    ClockState s{};
+    s.ii = 0; s.mu = mu; s.omega = omega;
+    st[0] = s;
+    st[1] = s;
+}
+
+// as after construction; what the stream taught (the mean chain Jacobian, the pass batch) is kept
+int ClockStage::reset(hipStream_t s)
+{
+    hipLaunchKernelGGL(clock_state_reset_kernel, dim3(1), dim3(1), 0, s, st.as<ClockState>(), mu0, par.omega_mid);
+    cur = 0;
+    carry = 0;
+    return XRIT_OK;
+}
+
 void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();

@@ -438,6 +438,17 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     return XRIT_OK;
 }
 
+int CostasStage::reset(hipStream_t s)
+{
+    XR_HIP(hipMemsetAsync(state.p, 0, 2 * sizeof(float2), s));
+    cur = 0;
+    passes = 0;
+    unconverged = 0;
+    stable = 0;
+    last_passes = -1;
+    return XRIT_OK;
+}
+
 void CostasStage::release()
 {
     state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();

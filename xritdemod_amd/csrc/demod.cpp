@@ -216,6 +216,22 @@ void xrit_demod_destroy(xrit_demod *d)
     delete d;
 }
 
+int xrit_demod_reset(xrit_demod *d, void *stream)
+{
+    if (!d) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    XR_TRY(d->dec.reset(s));
+    XR_TRY(d->rrc.reset(s));
+    XR_TRY(d->agc.reset(s));
+    XR_TRY(d->rtl.reset(s));
+    XR_TRY(d->costas.reset(s));
+    XR_TRY(d->clock.reset(s));
+    d->poisoned = false;
+    return XRIT_OK;
+}
+
+void *xrit_demod_stream(xrit_demod *d) { return d ? (void *)d->stream : nullptr; }
 float xrit_demod_sps(const xrit_demod *d) { return d ? d->sps : 0.f; }
 int xrit_demod_decimator_ntaps(const xrit_demod *d) { return d ? d->dec_ntaps : 0; }
 

@@ -546,6 +546,14 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     return XRIT_OK;
 }
 
+int FirStage::reset(hipStream_t s)
+{
+    XR_HIP(hipMemsetAsync(hist[0].p, 0, hist[0].bytes, s));
+    XR_HIP(hipMemsetAsync(hist[1].p, 0, hist[1].bytes, s));
+    cur = 0;
+    return XRIT_OK;
+}
+
 bool FirStage::agc_supported() const
 {
     return !poly && !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs

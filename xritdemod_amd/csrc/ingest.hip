@@ -56,6 +56,13 @@ int RtlIngestStage::init(float sample_rate)
     return XRIT_OK;
 }
 
+int RtlIngestStage::reset(hipStream_t s)
+{
+    XR_HIP(hipMemsetAsync(state.p, 0, 2 * sizeof(float), s));
+    cur = 0;
+    return XRIT_OK;
+}
+
 void RtlIngestStage::release()
 {
     state.release();

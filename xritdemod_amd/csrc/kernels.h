@@ -17,6 +17,7 @@ struct FirStage {
     DevBuf g;        // RC x Wpad window taps (polyphase: D x POLY_NQ phase taps)
     DevBuf hist[2];  // T-1 samples of history (ping-pong)
     int init(const float *taps, int ntaps, int decim);
+    int reset(hipStream_t s);     // zero history, as after construction (no reallocation)
     void release();
     // consumes n_out*D samples of `in` (sample_type as in FrontendDevice.h:11-13)
     // stat (optional): sum z^2 per run of statL outputs, written when stat_supported(statL)
@@ -57,6 +58,7 @@ struct RtlIngestStage {
     DevBuf aggs;
     int cur = 0;
     int init(float sample_rate);
+    int reset(hipStream_t s);
     void release();
     int run(const void *in_u8, float2 *out, size_t n_complex, hipStream_t s, Profiler *prof);
 };
@@ -68,6 +70,8 @@ struct AgcStage {
     DevBuf aggs;     // per-block composed maps
     int cur = 0;
     int init(float rate, float reference, float gain, float max_gain);
+    int reset(hipStream_t s);
+    float gain0 = 1.0f;
     void release();
     int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
     // the same in two halves around the kernel that produces `in` (the decimator): fused_begin() before it
@@ -103,6 +107,7 @@ struct CostasStage {
     unsigned unconverged = 0;
     float max_residual = 0;
     int init(float loop_bw, int chain_len, int max_passes);
+    int reset(hipStream_t s);
     void release();
     // stat_ext (optional): sum z^2 per chain already left by the producer (FIR epilogue); om (optional): receives
     // the clock recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
@@ -160,6 +165,7 @@ struct ClockStage {
     size_t last_symbols = 0;
     int init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
              int max_passes);
+    int reset(hipStream_t s);
     void release();
     // where the producer must write the n new samples of this call
     int input_slot(size_t n, float2 **slot, hipStream_t s);

@@ -64,6 +64,7 @@ struct Options {
     bool drop = false;             // SymbolManager's queue and loss behaviour instead of back-pressure
     size_t queue_symbols = 1024 * 1024;   // SM_MAX_SYMBOL_BUFFER (SymbolManager.h:23)
     int sndbuf = 0;                // > 0: SO_SNDBUF of the decoder socket (the kernel's default grows to megabytes)
+    int gpus = 1;                  // > 1: every block is cut in that many time slices, one per GPU (xrit_group_*)
 };
 
 void usage()
@@ -72,7 +73,8 @@ void usage()
                  "usage: xrit_demod_host --input FILE [--format cf32|s16|s8|u8] [--mode lrit|hrit]\n"
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
                  "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
-                 "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n");
+                 "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n"
+                 "         [--gpus N]   (devices 0..N-1: each block of --block samples is cut in N time slices, RCCL edge exchange)\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -96,12 +98,13 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--diag") { if (!(v = need("--diag"))) return false; o.diag = v; }
         else if (a == "--queue-symbols") { if (!(v = need("--queue-symbols"))) return false; o.queue_symbols = (size_t)std::atoll(v); }
         else if (a == "--sndbuf") { if (!(v = need("--sndbuf"))) return false; o.sndbuf = std::atoi(v); }
+        else if (a == "--gpus") { if (!(v = need("--gpus"))) return false; o.gpus = std::atoi(v); }
         else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
     }
-    return !o.input.empty() && o.block > 0 && o.decimation >= 1;
+    return !o.input.empty() && o.block > 0 && o.decimation >= 1 && o.gpus >= 1;
 }
 
 // ---- sink ------------------------------------------------------------------------------------------------
@@ -306,6 +309,78 @@ struct Diag {
 
 }  // namespace
 
+// --gpus N: one process drives N GPUs (ncclCommInitAll).  A block of the capture is cut in N time slices, one per
+// GPU; the ranks exchange the halo and the boundary symbols over RCCL (xrit_group_process_slice_device) and the
+// symbols are sent on in rank order.  Every block starts from cold chains (a rank's previous slice ended somewhere
+// else in the stream), so blocks should be long: the halo is ~0.5 M input samples per rank at LRIT, decimation 5.
+static int run_multi_gpu(const Options &o, int type, size_t bytes_per_sample, const xrit_demod_config &cfg0)
+{
+    const int W = o.gpus;
+    if (xrit_device_count() < W) { std::fprintf(stderr, "--gpus %d: only %d HIP devices\n", W, xrit_device_count()); return 1; }
+    std::vector<int> devs((size_t)W);
+    for (int i = 0; i < W; ++i) devs[(size_t)i] = i;
+    std::vector<xrit_group *> grp((size_t)W, nullptr);
+    if (xrit_group_create_all(&cfg0, devs.data(), W, grp.data()) != XRIT_OK) {
+        std::fprintf(stderr, "xritdemod_amd: %s\n", xrit_last_error());
+        return 1;
+    }
+    FILE *in = std::fopen(o.input.c_str(), "rb");
+    if (!in) { std::perror("input"); return 1; }
+    Sink sink;
+    sink.sndbuf = o.sndbuf;
+    if (!sink.open(o.sink, o.connect_tries)) { std::fclose(in); return 1; }
+    const size_t halo = xrit_group_halo_samples(grp[0]);
+    const size_t per = o.block / (size_t)W / cfg0.decimation * cfg0.decimation;
+    if (per < halo + 1024) { std::fprintf(stderr, "--block %zu is too short for %d slices with a halo of %zu samples\n", o.block, W, halo); return 2; }
+    std::vector<unsigned char> raw(per * (size_t)W * bytes_per_sample);
+    const size_t cap = per + 1024;
+    std::vector<std::vector<float>> soft((size_t)W, std::vector<float>(cap));
+    std::vector<size_t> count((size_t)W, 0);
+    std::vector<uint64_t> offset((size_t)W, 0);
+    std::vector<int> rcs((size_t)W, 0);
+    std::vector<int8_t> q(cap);
+    size_t total_in = 0, total_sym = 0;
+    int exit_code = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (;;) {
+        const size_t n = std::fread(raw.data(), bytes_per_sample, per * (size_t)W, in);
+        if (n < per * (size_t)W) { std::fprintf(stderr, n ? "EOF (last %zu samples do not fill the slices: dropped)\n" : "EOF\n", n); break; }
+        std::vector<std::thread> th;
+        for (int r = 0; r < W; ++r)
+            th.emplace_back([&, r] {
+                // the slice goes to the rank's GPU through the chain's host entry point's twin: device buffers are the
+                // group's business, so use the simplest route -- a device copy owned by this thread
+                rcs[(size_t)r] = xrit_group_process_slice_host(grp[(size_t)r], raw.data() + (size_t)r * per * bytes_per_sample, per,
+                                                               type, soft[(size_t)r].data(), cap, &count[(size_t)r],
+                                                               &offset[(size_t)r], nullptr);
+            });
+        for (auto &t : th) t.join();
+        for (int r = 0; r < W; ++r)
+            if (rcs[(size_t)r] != XRIT_OK) { std::fprintf(stderr, "rank %d: %s\n", r, xrit_last_error()); exit_code = 1; }
+        if (exit_code) break;
+        for (int r = 0; r < W && !exit_code; ++r) {
+            // SymbolManager.cpp:43-46 on the host: the ranks' pieces are already in stream order (offset[r] ascending)
+            for (size_t i = 0; i < count[(size_t)r]; ++i) {
+                float f = soft[(size_t)r][i] * 127;
+                f = f > 127 ? 127 : f;
+                f = f < -128 ? -128 : f;
+                q[i] = (int8_t)(char)f;
+            }
+            if (!sink.send_all(q.data(), count[(size_t)r])) exit_code = 1;
+            total_sym += count[(size_t)r];
+        }
+        total_in += n;
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (o.stats)
+        std::fprintf(stderr, "samples in %zu, symbols out %zu, %.3f s (%.2f Msamples/s incl. file and PCIe), %d GPUs, halo %zu samples per boundary\n",
+                     total_in, total_sym, secs, secs > 0 ? total_in / secs * 1e-6 : 0.0, W, halo);
+    sink.close_all();
+    std::fclose(in);
+    for (auto g : grp) xrit_group_destroy(g);
+    return exit_code;
+}
+
 int main(int argc, char **argv)
 {
     Options o;
@@ -323,6 +398,7 @@ int main(int argc, char **argv)
     else xrit_demod_config_lrit(&cfg, (float)o.sample_rate, o.decimation);
     int rc = XRIT_OK;
     cfg.device = o.device;
+    if (o.gpus > 1) return run_multi_gpu(o, type, bytes_per_sample, cfg);
     xrit_demod *chain = nullptr;
     if (xrit_demod_create(&cfg, &chain) != XRIT_OK) {
         // e.g. no HIP device: there is no CPU path
