@@ -111,6 +111,9 @@ def main():
                     help="also time the oracle on this many host threads, one independent stream segment each "
                          "(SURVEY.md 8(d)(ii)); 0 = every logical CPU of the host; 1 = off.  The single-thread figure "
                          "stays the cpu_baseline")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="one burst at a time: do not run the front end of the next burst (xrit_demod_prefetch_device, second "
+                         "stream) under the feedback loops of the current one")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
@@ -208,10 +211,22 @@ def main():
 
     if not args.no_profile:
         dem.profile(2)       # events around the decimating FIR only: an event record is a queue barrier
+    # Streaming: the front end (decimator, AGC, matched filter) of burst b + 1 runs on the handle's second stream while
+    # the feedback loops of burst b iterate -- every timed step still pays one front end and one set of loops, all
+    # inside the timed region (nothing is prefetched before the clock starts).
+    prefetch = not args.no_prefetch
+
+    def ahead(b):
+        dem.prefetch_device(bursts[b % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+
     barrier()
     t0 = time.perf_counter()
     nsym_total = 0
+    if prefetch:
+        ahead(W)
     for b in range(W, W + K):
+        if prefetch and b + 1 < W + K:
+            ahead(b + 1)
         nsym_total += step(b)
     barrier()
     t1 = time.perf_counter()
@@ -325,7 +340,8 @@ def main():
                                   mode.upper(), ("decimating LPF %d taps d=%d -> " % (dem.decimator_ntaps, D)) if D > 1 else "",
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
-                   "segments": world, "bursts_reused": bool(W + K > nbuf), "costas_chain_len": args.costas_chain or 256,
+                   "segments": world, "bursts_reused": bool(W + K > nbuf),
+                   "front_end_of_next_burst_overlaps_loops": bool(prefetch), "costas_chain_len": args.costas_chain or 256,
                    "clock_chain_syms": args.clock_chain or "auto: whole generations of resident waves (112 at C2), 64..256"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
         "algorithmic_bytes_per_sample": round(b_alg, 4),

@@ -128,6 +128,14 @@ int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int
 /* Same with device-resident input and output (no PCIe in the call). */
 int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type,
                               float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* Streaming at full rate: run the front end (ingest, decimator, AGC, matched filter) of a LATER call's input now, on
+ * the handle's second stream, so that it overlaps the feedback loops of the call made in between:
+ *     prefetch(b);  prefetch(b+1); process_device(b);  prefetch(b+2); process_device(b+1);  ...
+ * Inputs are taken by the process calls in the order they were prefetched (each must pass exactly the prefetched
+ * pointer, count and type); at most two may be waiting.  The reference's input FIFO plays the same role
+ * (demodulator.cpp:38,54-74: the frontend thread fills it while the DSP thread works).  A no-op while stage copies
+ * or full per-kernel profiling are on. */
+int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type, void *stream);
 /* Back to the state right after xrit_demod_create (filter histories, gain, loop states, unread tail), without
  * giving up the device buffers: the start of another stream.  Also revives a handle a failed call left unusable. */
 int xrit_demod_reset(xrit_demod *d, void *stream);

@@ -345,6 +345,38 @@ def test_capacity_and_argument_errors(xa):
             xa.Demodulator(bad)
 
 
+def test_prefetched_front_ends_give_the_same_symbols(xa):
+    """xrit_demod_prefetch_device: the front end of later bursts runs ahead on the second stream (two may wait);
+    the symbols are bit for bit those of plain consecutive calls, also when plain and prefetched calls mix."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, D, nb = 1500000, 5, 5
+    x = synth_signal(nb * n, fs_in=6.25e6)
+    xt = torch.from_numpy(x.view(np.float32).reshape(nb, n, 2)).to(dev)
+    cap = n // D + 1024
+    soft = torch.empty(cap, dtype=torch.float32, device=dev)
+
+    def run(plan):
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D))
+        out = []
+        for op, b in plan:
+            if op == "pf":
+                dem.prefetch_device(xt[b].data_ptr(), n)
+            else:
+                k = dem.process_device(xt[b].data_ptr(), n, soft.data_ptr(), cap)
+                out.append(soft[:k].cpu().numpy())
+        return out
+
+    plain = run([("go", b) for b in range(nb)])
+    ahead = run([("pf", 0), ("pf", 1), ("go", 0), ("pf", 2), ("go", 1), ("go", 2), ("go", 3), ("pf", 4), ("go", 4)])
+    for a, b in zip(plain, ahead):
+        assert np.array_equal(a, b)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D))
+    dem.prefetch_device(xt[0].data_ptr(), n)
+    with pytest.raises(xa.XritError):                     # inputs are taken in the order they were prefetched
+        dem.process_device(xt[1].data_ptr(), n, soft.data_ptr(), cap)
+
+
 def test_run_to_run_determinism(xa):
     """Two fresh handles on the same input give bit-identical symbols (the hand-off passes, their stop test and
     every reduction are order independent)."""

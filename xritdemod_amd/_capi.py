@@ -59,6 +59,7 @@ _SIGNATURES = {
     "xrit_demod_destroy": (None, [_vp]),
     "xrit_demod_process": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "xrit_demod_process_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),
+    "xrit_demod_prefetch_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "xrit_demod_reset": (C.c_int, [_vp, _vp]),
     "xrit_demod_stream": (_vp, [_vp]),
     "xrit_demod_sps": (C.c_float, [_vp]),
@@ -368,6 +369,11 @@ class Demodulator(_Handle):
                                                C.c_void_p(d_soft_ptr), cap, C.byref(n_out),
                                                C.c_void_p(stream) if stream else None))
         return n_out.value
+
+    def prefetch_device(self, d_samples_ptr, n, sample_type=SAMPLE_FLOATIQ, stream=None):
+        """Start the front end of the NEXT process_device call's input now (it overlaps the loops of the call in between)."""
+        _check(lib().xrit_demod_prefetch_device(self._h, C.c_void_p(d_samples_ptr), n, sample_type,
+                                                C.c_void_p(stream) if stream else None))
 
     def stage(self, name):
         idx = self.STAGES.index(name)

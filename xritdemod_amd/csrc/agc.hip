@@ -127,6 +127,12 @@ void AgcStage::release()
     if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; }
 }
 
+int AgcStage::request_flag_at(const float *flag, hipStream_t s)
+{
+    XR_HIP(hipMemcpyAsync(h_flag, flag, sizeof(float), hipMemcpyDeviceToHost, s));
+    return XRIT_OK;
+}
+
 int AgcStage::request_flag(hipStream_t s)
 {
     XR_HIP(hipMemcpyAsync(h_flag, state.as<float>() + 2 * cur + 1, sizeof(float), hipMemcpyDeviceToHost, s));

@@ -119,9 +119,16 @@ __device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double
 __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, double sps, ClockState *__restrict__ S,
                                    const ClockState *__restrict__ carried, int K, int NS, float omega0,
                                    const float2 *__restrict__ x, const float *__restrict__ table, long long ni,
-                                   double off, int BL, int *__restrict__ dirty, int *__restrict__ ctl)
+                                   double off, int BL, int *__restrict__ dirty, int *__restrict__ ctl, int ctl_words,
+                                   int *__restrict__ terminal)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        // the call's control block and per-pass counters start from zero, "no chain has run out of input yet"
+        for (int i = threadIdx.x; i < ctl_words; i += blockDim.x) ctl[i] = 0;
+        if (threadIdx.x == 0) *terminal = 0x7fffffff;
+        __syncthreads();
+    }
     if (k >= K) return;
     dirty[k] = 1;                       // every chain runs in the first pass
     ClockState s0 = carried[0];
@@ -305,6 +312,12 @@ constexpr int CLK_SLACK = 3;  // head room above the schedule: R >= CLK_M + CLK_
 // then never wraps, its reads are one address and seven immediate offsets instead of eight masked indices
 // (24 of the ~95 vector instructions of a symbol went into those indices).  Row stride WS = R + CLK_MIR float2,
 // odd, so the per-lane ds_read_b64 stay spread over the banks.
+#ifndef XR_NOSTORE
+#define XR_NOSTORE 0
+#endif
+#ifndef XR_LOAD_AUX
+#define XR_LOAD_AUX 0
+#endif
 #ifndef XR_CLK_MIR
 #define XR_CLK_MIR (XR_MM_NTAPS - 1)
 #endif
@@ -385,7 +398,7 @@ template <int NV, int IT> struct ClockFill {
     __device__ __forceinline__ void issue(int first, const ClockSrc &src)
     {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, gb[it], first * 8, 0);
+        for (int it = 0; it < IT; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, gb[it], first * 8, XR_LOAD_AUX);
     }
     template <int R> __device__ __forceinline__ void commit(float2 *tile, float2 *dump, int first, int ncol) const
     {
@@ -705,7 +718,7 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
         const int nv = produced - before;          // symbols of this sub-step that exist
         const unsigned long long o = obase + (unsigned long long)j * SS;
         if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < cap) {
-            if (soft) *reinterpret_cast<float4 *>(soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
+            if (soft && !XR_NOSTORE) *reinterpret_cast<float4 *>(soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
             if (SYM && sym) {
                 *reinterpret_cast<float4 *>(sym + o) = make_float4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
                 *reinterpret_cast<float4 *>(sym + o + 2) = make_float4(ps[2].x, ps[2].y, ps[3].x, ps[3].y);
@@ -1146,7 +1159,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // fill LDS; two waves per SIMD is what the registers allow)
     int waves_cu = 0;
     j.NG = 1;
-    for (int ng = 1; ng <= 8; ++ng) {
+    const int ng_max = getenv("XRIT_CLOCK_NG") ? atoi(getenv("XRIT_CLOCK_NG")) : 8;
+    for (int ng = 1; ng <= 8 && ng <= ng_max; ++ng) {
         const long long need = (long long)clock_tile_bytes(j.WS, ng, 64 * ng);
         if (need > lds_per_cu) break;
         long long wv = (long long)ng * (lds_per_cu / need);
@@ -1205,7 +1219,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     const ClockState *st_in = st.as<ClockState>() + cur;
-    hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), (max_passes + 5) * 8, j.terminal);
+    if (K <= 1) hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), (max_passes + 5) * 8, j.terminal);
     if (K > 1) {
         {
             ProfScope ps(prof, "clock_guess", s);
@@ -1215,12 +1229,11 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
             ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL};
             hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
-            hipLaunchKernelGGL(scan_aggs_kernel<ClkUnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbB);
-            hipLaunchKernelGGL(scan_apply_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
+            hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
                                S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL, j.dirty,
-                               clock_ctl(counters));
+                               clock_ctl(counters), (max_passes + 5) * 8, j.terminal);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {

@@ -100,10 +100,13 @@ struct Profiler {
         (void)hipEventRecord(pending.back().b, s);
         open = false;
     }
-    // call after the stream has been synchronised
+    // call after the stream has been synchronised; records of a stream that is still running (a front end that runs
+    // ahead on the second stream) stay pending until a later call
     void collect()
     {
+        std::vector<Rec> later;
         for (auto &r : pending) {
+            if (hipEventQuery(r.b) != hipSuccess) { later.push_back(r); continue; }
             float ms = 0;
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
                 auto it = acc.find(r.name);
@@ -113,7 +116,7 @@ struct Profiler {
             pool.push_back(r.a);
             pool.push_back(r.b);
         }
-        pending.clear();
+        pending.swap(later);
     }
     void reset() { acc.clear(); order.clear(); }
     ~Profiler()

@@ -88,12 +88,22 @@ struct UnwrapF {
 };
 
 __global__ void costas_guess_kernel(const double *__restrict__ th2, float2 *__restrict__ S, int K, int L,
-                                    int *__restrict__ dirty, int *__restrict__ ctl)
+                                    int *__restrict__ dirty, int *__restrict__ ctl, int ctl_words,
+                                    const float2 *__restrict__ state)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        // the call's control block and per-pass counters start from zero (no launch of its own for that)
+        for (int i = threadIdx.x; i < ctl_words; i += blockDim.x) ctl[i] = 0;
+        __syncthreads();
+    }
     if (k >= K) return;
     dirty[k] = 1;                       // every chain runs in the first pass
-    if (k == 0) { ctl[5] = 1; return; } // first solve: gated (chain 0 starts from the carried state)
+    if (k == 0) {                       // chain 0 starts from the carried state; first solve: gated
+        S[0] = state[0];
+        ctl[5] = 1;
+        return;
+    }
     // boundary k lies between chain centres k-1 and k
     double thb = 0.25 * (th2[k - 1] + th2[k]);
     int a = max(0, k - 2), b = min(K - 1, k + 1);
@@ -555,7 +565,8 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
         job.gated = force_gated;
     }
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);
-    XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)(max_passes + 4) * 8 * sizeof(unsigned), s));
+    const int ctl_words = (max_passes + 4) * 8;
+    if (K <= 1) XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)ctl_words * sizeof(unsigned), s));
     if (K > 1) {
         {
             ProfScope ps(prof, "costas_guess", s);
@@ -568,15 +579,15 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
             UnwrapF uf{st, th2};
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
-            hipLaunchKernelGGL(scan_aggs_kernel<UnwrapF>, dim3(1), dim3(SCAN_BLOCK), 0, s, uf, work.as<double>(), nbK);
-            hipLaunchKernelGGL(scan_apply_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
+            hipLaunchKernelGGL(scan_apply_lookback_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(costas_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, th2, S.as<float2>(), K, L,
-                               flags.as<int>(), costas_ctl(counters));
+                               flags.as<int>(), costas_ctl(counters), ctl_words, st_in);
             // the sequential head model (64 dependent steps, ~20 us) is for calls that start unlocked; a call that
             // follows one which closed in the minimum number of passes starts on a tracking loop: plain guesses do
-            hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
-                               locked ? 0 : COSTAS_HEAD);
+            if (!locked)
+                hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
+                                   COSTAS_HEAD);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {

@@ -51,7 +51,18 @@ struct xrit_demod {
     AgcStage agc;
     CostasStage costas;
     ClockStage clock;
-    DevBuf bufA, bufB, bufC, bufR, stat, in_dev, soft_dev, q_in, q_out;
+    // Two sets of front-end buffers: the front end of the NEXT burst (xrit_demod_prefetch_device, on stream2) fills one
+    // while the feedback loops of the current burst read the other.
+    DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
+    int next_set = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
+    int last_fe_set = -1;       // set of the front end that ran last (its event orders the next one behind it)
+    struct Prefetched {
+        const void *samples = nullptr; size_t n = 0; int type = 0; int set = 0;
+        size_t length = 0; const float2 *rrc = nullptr; bool stat_ready = false; const float *agc_flag = nullptr;
+    } pf[2];                    // front ends that ran ahead, oldest first: the one of the next process call, and
+    int pf_count = 0;           // at most the one after it
     RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
@@ -182,7 +193,10 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
     d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
     int rc = XRIT_OK;
     do {
-        if (hipStreamCreate(&d->stream) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+        if (hipStreamCreate(&d->stream) != hipSuccess || hipStreamCreate(&d->stream2) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
@@ -208,7 +222,11 @@ void xrit_demod_destroy(xrit_demod *d)
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    d->bufA.release(); d->bufB.release(); d->bufC.release(); d->bufR.release(); d->stat.release(); d->rtl.release();
+    if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
+    if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+    for (int i = 0; i < 2; ++i) if (d->ev_fe[i]) (void)hipEventDestroy(d->ev_fe[i]);
+    for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->bufC[i].release(); d->bufR[i].release(); d->stat[i].release(); }
+    d->rtl.release();
     d->in_dev.release(); d->soft_dev.release();
     d->q_in.release(); d->q_out.release();
     for (auto &b : d->stage_buf) b.release();
@@ -221,6 +239,9 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     if (!d) { set_error("null argument"); return XRIT_E_INVALID; }
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
+    d->pf_count = 0;
+    d->last_fe_set = -1;
     XR_TRY(d->dec.reset(s));
     XR_TRY(d->rrc.reset(s));
     XR_TRY(d->agc.reset(s));
@@ -252,24 +273,27 @@ struct SliceIO {
     size_t length = 0;          // circuit-rate samples
     const float2 *rrc = nullptr;
     bool stat_ready = false;
+    int set = 0;                // which set of front-end buffers
+    const float *agc_flag = nullptr;    // the AGC guard flag of THIS front end (the stage's slot moves on with the next)
 };
 
-static int front_end(xrit_demod *d, const void *in, size_t n, int type, hipStream_t s, Profiler *prof, SliceIO *io)
+static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set, hipStream_t s, Profiler *prof, SliceIO *io)
 {
+    io->set = set;
     const unsigned D = d->cfg.decimation;
     if (type == XRIT_SAMPLE_U8IQ) {
         // RtlFrontend::internalCallback (RtlFrontend.cpp:102-116) hands FLOATIQ to onSamplesAvailable
-        XR_TRY(d->bufR.reserve((n + 8) * sizeof(float2)));
-        XR_TRY(d->rtl.run(in, d->bufR.as<float2>(), n, s, prof));
-        in = d->bufR.p;
+        XR_TRY(d->bufR[set].reserve((n + 8) * sizeof(float2)));
+        XR_TRY(d->rtl.run(in, d->bufR[set].as<float2>(), n, s, prof));
+        in = d->bufR[set].p;
         type = XRIT_SAMPLE_FLOATIQ;
     }
     size_t length = n;
     if (D > 1) length = n / D;   // demodulator.cpp:137 -- the remainder of the chunk is dropped
     io->length = length;
-    XR_TRY(d->bufA.reserve((length + 8) * sizeof(float2)));
-    XR_TRY(d->bufB.reserve((length + 8) * sizeof(float2)));
-    float2 *A = d->bufA.as<float2>(), *B = d->bufB.as<float2>();
+    XR_TRY(d->bufA[set].reserve((length + 8) * sizeof(float2)));
+    XR_TRY(d->bufB[set].reserve((length + 8) * sizeof(float2)));
+    float2 *A = d->bufA[set].as<float2>(), *B = d->bufB[set].as<float2>();
     const float2 *cur = nullptr;
     // with a decimator in front, its epilogue leaves the AGC's composed gain maps: the AGC sweeps the stream
     // twice (scan of the maps aside) instead of three times
@@ -296,8 +320,8 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, hipStrea
     AgcFill fill{};
     float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
     if (agc_in_rrc || agc_in_rrc_d1) {
-        XR_TRY(d->bufC.reserve((length + 8) * sizeof(float2)));
-        Cfb = d->bufC.as<float2>();
+        XR_TRY(d->bufC[set].reserve((length + 8) * sizeof(float2)));
+        Cfb = d->bufC[set].as<float2>();
         if (agc_in_rrc_d1) XR_TRY(d->agc.fused_reduce(cur, length, 3, s, prof));
         XR_TRY(d->agc.fused_scan(cur, Cfb, length, agc_in_rrc ? d->dec.RC : 3, s, prof, &fill));    // :143
     }
@@ -308,15 +332,16 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, hipStrea
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
     const int L = d->costas.L;
     const size_t K = (length + (size_t)L - 1) / (size_t)L;
-    XR_TRY(d->stat.reserve((K + 2) * sizeof(float2)));
+    XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
     io->stat_ready = length > 0 && d->rrc.stat_supported(L);
     // (fused: A holds the decimator output, which the fill reads; the filter output goes to B's place instead)
     const bool fill_on = agc_in_rrc || agc_in_rrc_d1;
     float2 *rrc_out = fill_on ? B : A;
-    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat.as<float2>() : nullptr, L,
+    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
                       nullptr, fill_on ? &fill : nullptr)); // :148
     XR_TRY(keep_stage(d, 2, rrc_out, length, s));
     io->rrc = rrc_out;
+    io->agc_flag = d->agc.state.as<float>() + 2 * d->agc.cur + 1;
     return XRIT_OK;
 }
 
@@ -338,10 +363,10 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
         sym = d->stage_buf[4].as<float2>();
     }
     const double inv_sps = 1.0 / (double)d->sps;
-    const float2 *stat = io.stat_ready ? d->stat.as<float2>() : nullptr;
+    const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
     XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
     XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
-    if (length) XR_TRY(d->agc.request_flag(s));        // the AGC's guard flag rides along: no wait of its own
+    if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
     XR_HIP(hipStreamSynchronize(s));
     if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
     bool redone = false;
@@ -381,13 +406,34 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         if (worst > cap && length > 0) {
             set_error("output capacity %zu is below the %zu symbols this call may produce (n / (decimation * sps * (1 - omega limit)) + 2)", cap, worst);
             *n_out = worst;        // the capacity that suffices; nothing has run, the handle is unchanged
+            if (d->pf_count > 0) d->poisoned = true;   // ... unless this call's front end already ran ahead
             return XRIT_E_CAPACITY;
         }
     }
     size_t total_sym = 0, total_len = 0;
     d->agc_fallback_seen = false;
     SliceIO io;
-    int rc = front_end(d, d_samples, n, type, s, prof, &io);
+    int rc = XRIT_OK;
+    if (d->pf_count > 0) {
+        // the front end of this call ran ahead (xrit_demod_prefetch_device): the loops wait for it, nothing else
+        const xrit_demod::Prefetched f = d->pf[0];
+        if (f.samples != d_samples || f.n != n || f.type != type) {
+            set_error("process calls must take the prefetched inputs in the order they were prefetched");
+            d->poisoned = true;
+            return XRIT_E_INVALID;
+        }
+        d->pf[0] = d->pf[1];
+        --d->pf_count;
+        io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+        XR_HIP(hipStreamWaitEvent(s, d->ev_fe[f.set], 0));
+    } else {
+        const int set = d->next_set;
+        d->next_set ^= 1;
+        // (a front end that ran ahead on the other stream earlier must be done before this one touches the stages)
+        if (d->last_fe_set >= 0) XR_HIP(hipStreamWaitEvent(s, d->ev_fe[d->last_fe_set], 0));
+        rc = front_end(d, d_samples, n, type, set, s, prof, &io);
+        if (rc == XRIT_OK) { XR_HIP(hipEventRecord(d->ev_fe[set], s)); d->last_fe_set = set; }
+    }
     if (rc == XRIT_OK) rc = loops(d, io, d_soft, cap, &total_sym, s, prof);
     if (rc != XRIT_OK) {
         // some stage has flipped its ping-pong state, a later one has not: the handle cannot go on
@@ -421,6 +467,35 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         set_error("clock hand-off ended with %u boundaries beyond 0.02 sample or with an open symbol slip", large_k);
         return XRIT_E_NOT_CONVERGED;
     }
+    return XRIT_OK;
+}
+
+int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, int type, void *stream)
+{
+    if (!d || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (type < 0 || type > 3) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    if (d->pf_count >= 2) { set_error("two prefetched inputs are already waiting for their process calls"); return XRIT_E_INVALID; }
+    // stage copies and per-kernel event brackets belong to one call at a time: no running ahead then
+    if (d->keep_stages || d->keep_symbols || (d->prof.enabled && !d->prof.light)) return XRIT_OK;
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    // stream2 may read the input once whatever the caller queued on its stream is done, and may touch the stages once
+    // the previous front end (on either stream) is done
+    XR_HIP(hipEventRecord(d->ev_ready, s));
+    XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_ready, 0));
+    if (d->last_fe_set >= 0) XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_fe[d->last_fe_set], 0));
+    const int set = d->next_set;
+    d->next_set ^= 1;
+    SliceIO io;
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    int rc = front_end(d, d_samples, n, type, set, d->stream2, prof, &io);
+    if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+    XR_HIP(hipEventRecord(d->ev_fe[set], d->stream2));
+    d->last_fe_set = set;
+    xrit_demod::Prefetched &f = d->pf[d->pf_count++];
+    f.samples = d_samples; f.n = n; f.type = type; f.set = set;
+    f.length = io.length; f.rrc = io.rrc; f.stat_ready = io.stat_ready; f.agc_flag = io.agc_flag;
     return XRIT_OK;
 }
 

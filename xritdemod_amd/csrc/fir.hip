@@ -101,12 +101,32 @@ __device__ __forceinline__ void fir_fill_through_agc(float2 *tile, const AgcFill
     }
 }
 
+// new history = last T-1 samples of (hist | in[0..n_in)), converted to float: done by the last workgroup of the
+// filter kernel itself (one launch less per call than a kernel of its own)
+template <int TYPE>
+__device__ __forceinline__ void fir_leave_history(const void *__restrict__ in, const float2 *__restrict__ hist_old,
+                                                  float2 *__restrict__ hist_new, int T, long long n_in)
+{
+    for (int i = threadIdx.x; i < T - 1; i += blockDim.x) {
+        const long long j = n_in - (T - 1) + i;  // index into in, negative -> old history
+        float2 v;
+        if (j >= 0) v = SampleLoad<TYPE>::at(in, (size_t)j);
+        else {
+            const long long hj = (T - 1) + j;
+            v = hj >= 0 ? hist_old[hj] : make_float2(0.f, 0.f);
+        }
+        hist_new[i] = v;
+    }
+}
+
 template <int RC, bool PAD, int TYPE, int APL = 0>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
-                 int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af)
+                 int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af,
+                 float2 *__restrict__ hist_new)
 {
+    if (APL == 0 && hist_new != nullptr && blockIdx.x == gridDim.x - 1) fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
     const int nthr = blockDim.x;
@@ -311,8 +331,10 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
 template <int DP, int PR, int NQ, int TYPE>
 __global__ void __launch_bounds__(256)
 fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
-                const float *__restrict__ hq /* [DP][NQ] */, int T, long long n_out, long long n_in, int tile_len)
+                const float *__restrict__ hq /* [DP][NQ] */, int T, long long n_out, long long n_in, int tile_len,
+                float2 *__restrict__ hist_new)
 {
+    if (hist_new != nullptr && blockIdx.x == 0) fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -414,23 +436,6 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
         const long long m = out_base + (long long)grp * PR + pl;
         if (m < n_out) out[m] = v;
     }
-}
-
-// new history = last T-1 samples of (hist | in[0..n_in)), converted to float
-template <int TYPE>
-__global__ void fir_hist_kernel(const void *__restrict__ in, const float2 *__restrict__ hist_old,
-                                float2 *__restrict__ hist_new, int T, long long n_in)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T - 1) return;
-    long long j = n_in - (T - 1) + i;  // index into in, negative -> old history
-    float2 v;
-    if (j >= 0) v = SampleLoad<TYPE>::at(in, (size_t)j);
-    else {
-        long long hj = (T - 1) + j;
-        v = hj >= 0 ? hist_old[hj] : make_float2(0.f, 0.f);
-    }
-    hist_new[i] = v;
 }
 
 // Fused AGC: new history = the AGC OUTPUT of the last T-1 samples (or older history in front of a short call),
@@ -584,7 +589,8 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     const float *g = f.g.as<float>();
 #define XR_FIR_GO(TY)                                                                                          \
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
-                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af)
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
+                       f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
     if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
@@ -610,7 +616,7 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
         ProfScope ps(prof, "fir_rrc", s);
         hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                            in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
-                           (long long)n, f.tile_len, stat, statL, none, af);
+                           (long long)n, f.tile_len, stat, statL, none, af, (float2 *)nullptr);
     }
     {
         ProfScope ps(prof, "fir_hist", s);
@@ -651,7 +657,8 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
         const float2 *h = hist[cur].as<float2>();
 #define XR_POLY_GO(DPV, TY)                                                                                      \
     hipLaunchKernelGGL((fir_poly_kernel<DPV, POLY_PR, POLY_NQ, TY>), dim3(blocks), dim3(threads), lds_bytes, s, in, h,  \
-                       out, g.as<float>(), T, (long long)n_out, (long long)n_in, tile_len)
+                       out, g.as<float>(), T, (long long)n_out, (long long)n_in, tile_len,                               \
+                       T > 1 ? hist[cur ^ 1].as<float2>() : (float2 *)nullptr)
 #define XR_POLY_TY(DPV)                                                         \
     do {                                                                        \
         if (type == XRIT_SAMPLE_FLOATIQ) XR_POLY_GO(DPV, XRIT_SAMPLE_FLOATIQ);  \
@@ -670,20 +677,7 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
         else if (RC == 3 && !pad) XR_TRY((fir_launch_t<3, false>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
         else XR_TRY((fir_launch_t<3, true>(*this, in, type, out, n_out, n_in, s, stat, statL, agc)));
     }
-    if (T > 1 && n_in > 0) {
-        ProfScope ps(prof, "fir_hist", s);
-        int nb = div_up((size_t)T - 1, 256);
-        float2 *hn = hist[cur ^ 1].as<float2>();
-        const float2 *ho = hist[cur].as<float2>();
-        if (type == XRIT_SAMPLE_FLOATIQ)
-            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_FLOATIQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
-        else if (type == XRIT_SAMPLE_S16IQ)
-            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_S16IQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
-        else
-            hipLaunchKernelGGL(fir_hist_kernel<XRIT_SAMPLE_S8IQ>, dim3(nb), dim3(256), 0, s, in, ho, hn, T, (long long)n_in);
-        XR_HIP(hipGetLastError());
-        cur ^= 1;
-    }
+    if (T > 1 && n_in > 0) cur ^= 1;      // the filter kernel's last workgroup has left the new history
     return XRIT_OK;
 }
 

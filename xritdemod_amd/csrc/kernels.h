@@ -88,6 +88,7 @@ struct AgcStage {
     // the same without a wait of its own: the copy goes into a pinned word behind whatever is queued on s, and
     // the caller reads it after its next synchronise
     int request_flag(hipStream_t s);
+    int request_flag_at(const float *flag, hipStream_t s);      // a given call's flag slot (the stage may have moved on)
     float requested_flag() const { return h_flag ? *h_flag : 0.0f; }
     float *h_flag = nullptr;
 };

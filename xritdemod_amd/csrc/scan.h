@@ -89,6 +89,31 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(F f, long long n
     if (cnt > 0) f.apply_run(i0, cnt, pre);
 }
 
+// The same, taking the RAW block aggregates of scan_reduce_kernel: every block composes the aggregates in front of
+// it by itself (a few hundred at most: one or two per thread, one block scan), which saves the single-block launch
+// that would scan them -- these scans are a chain of launch latencies, not work.
+template <typename F>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_lookback_kernel(F f, long long n, const typename F::T *aggs)
+{
+    __shared__ typename F::T buf[SCAN_BLOCK];
+    const int t = threadIdx.x;
+    const int nbefore = blockIdx.x;
+    const int run = (nbefore + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    typename F::T v = f.identity();
+    for (int b = t * run; b < min(nbefore, (t + 1) * run); ++b) v = f.combine(v, aggs[b]);
+    block_scan_inclusive(f, v, buf);
+    const typename F::T block_pre = buf[SCAN_BLOCK - 1];
+    __syncthreads();
+    long long i0 = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_IPT;
+    int cnt = 0;
+    if (i0 < n) cnt = (int)((n - i0) < SCAN_IPT ? (n - i0) : SCAN_IPT);
+    v = cnt > 0 ? f.reduce_run(i0, cnt) : f.identity();
+    block_scan_inclusive(f, v, buf);
+    typename F::T pre = block_pre;
+    if (threadIdx.x > 0) pre = f.combine(pre, buf[threadIdx.x - 1]);
+    if (cnt > 0) f.apply_run(i0, cnt, pre);
+}
+
 static inline int scan_blocks(long long n) { return (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
 
 // the aggregates of a large scan are scanned with the same three kernels, one level up
@@ -128,8 +153,7 @@ static inline void scan_aggs_launch(const F &f, typename F::T *aggs, int nb, hip
     typename F::T *lvl2 = aggs + nb + 1;
     AggScanF<F> af{f, aggs};
     hipLaunchKernelGGL(scan_reduce_kernel<AggScanF<F>>, dim3(nb2), dim3(SCAN_BLOCK), 0, s, af, (long long)nb, lvl2);
-    hipLaunchKernelGGL(scan_aggs_kernel<AggScanF<F>>, dim3(1), dim3(SCAN_BLOCK), 0, s, af, lvl2, nb2);
-    hipLaunchKernelGGL(scan_apply_kernel<AggScanF<F>>, dim3(nb2), dim3(SCAN_BLOCK), 0, s, af, (long long)nb, lvl2);
+    hipLaunchKernelGGL(scan_apply_lookback_kernel<AggScanF<F>>, dim3(nb2), dim3(SCAN_BLOCK), 0, s, af, (long long)nb, lvl2);
 }
 
 }  // namespace xrit
