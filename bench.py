@@ -245,6 +245,7 @@ def main():
         prof = dem.profile_read()
         dem.profile(False)
         timed = {n: (ms, c) for n, ms, c in prof_timed}
+        alone = {n: ms / c for n, ms, c in prof}          # every kernel by itself (the detail pass does not prefetch)
         prof = [(n, timed[n][0], timed[n][1]) if n in timed else (n, ms, c) for n, ms, c in prof]
 
     if world > 1:
@@ -273,12 +274,18 @@ def main():
     }
     roofline = None
     kernels = {}
+    alone = locals().get("alone", {})
     chain_gbs = b_alg * n_burst * K / elapsed / 1e9
     if prof:
         for name, ms, cnt in prof:
             avg = ms / cnt
             k = {"total_ms": round(ms, 4), "launches": cnt, "avg_launch_ms": round(avg, 4),
-                 "measured": "timed region" if name == "fir_decim" else "detail pass"}
+                 "measured": ("timed region" + (", under the loops of the previous burst (second stream)" if prefetch else ""))
+                 if name == "fir_decim" else "detail pass"}
+            if name == "fir_decim" and name in alone:
+                k["avg_launch_ms_alone"] = round(alone[name], 4)
+                if name in own_bytes:
+                    k["hbm_frac_alone"] = round(own_bytes[name] * n_burst / (alone[name] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if name in own_bytes:
                 gbs = own_bytes[name] * n_burst / (avg * 1e-3) / 1e9
                 k["algorithmic_bytes_per_launch"] = own_bytes[name] * n_burst
@@ -299,7 +306,10 @@ def main():
                     "dominant_kernel": {"kernel": dom_name, "avg_launch_ms": fd["avg_launch_ms"],
                                         "launches_per_step": fd["launches"] / K,
                                         "algorithmic_bytes_per_launch": fd.get("algorithmic_bytes_per_launch"),
-                                        "achieved": fd.get("achieved_gbs"), "frac": fd.get("hbm_frac")},
+                                        "achieved": fd.get("achieved_gbs"), "frac": fd.get("hbm_frac"),
+                                        "measured": fd.get("measured"),
+                                        "avg_launch_ms_alone": fd.get("avg_launch_ms_alone"),
+                                        "frac_alone": fd.get("hbm_frac_alone")},
                     "dominant_kernel_frac": fd.get("hbm_frac")}
         tot = max(prof, key=lambda r: r[1])
         roofline["by_total_time"] = {"kernel": tot[0], "total_ms_per_step": round(tot[1] / K, 4),

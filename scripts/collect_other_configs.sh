@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: bench JSON and rocprofv3 kernel statistics for C5 (40 Msps, d=32), C3 (HRIT) and C1's chain.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

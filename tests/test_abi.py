@@ -117,6 +117,7 @@ def test_integration_md_snippets_compile_against_the_header(tmp_path):
     wrapper = next(b for b in blocks if "namespace XritAmd" in b)
     corr = next(b for b in blocks if "xrit_sync_correlate(" in b)
     fix = next(b for b in blocks if "xrit_sync_fix_frames(" in b)
+    group = next(b for b in blocks if "xrit_group_process_slice_device(" in b)
     a = tmp_path / "wrapper.cpp"
     a.write_text('#include <complex>\n#include <vector>\n#include <stdexcept>\n#include "xritdemod_amd.h"\n' + wrapper +
                  "\nint main() { return 0; }\n")
@@ -126,7 +127,9 @@ def test_integration_md_snippets_compile_against_the_header(tmp_path):
                  "void f(uint8_t *codedData, const int8_t *symbols, size_t nSymbols, size_t nFrames, xrit_sync_hit *hits,\n"
                  "       int8_t *frames, uint8_t *valid, uint8_t *decodedData) {\n    V viterbi;\n" + corr +
                  "\n(void)word; (void)pos; (void)corr;\n" + fix + "\n}\nint main() { return 0; }\n")
-    for src in (a, b):
+    c = tmp_path / "group.cpp"
+    c.write_text('#include <cstdint>\n#include <cstddef>\n#include "xritdemod_amd.h"\n' + group + "\nint main() { return 0; }\n")
+    for src in (a, b, c):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
