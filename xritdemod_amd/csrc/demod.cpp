@@ -220,6 +220,7 @@ void xrit_demod_destroy(xrit_demod *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
