@@ -85,7 +85,10 @@ typedef struct xrit_demod_config {
     /* placement */
     int32_t  device;            /* HIP device ordinal */
     /* time-slice tiling of the feedback loops (0 = library default) */
-    int32_t  costas_chain_len;  /* samples per Costas chain */
+    int32_t  costas_chain_len;  /* samples per Costas chain: 0 = 256, else 16..320 (rejected beyond: a chain that is
+                                 * long against the loop's pull-in time ends in a state that is no longer a smooth
+                                 * function of its start, and the hand-off solve then needs tens of passes or does
+                                 * not close -- fuzz, HRIT at 512: 186 passes and flipped decisions) */
     int32_t  clock_chain_syms;  /* symbols per clock-recovery chain; 0 = chosen per call (64..256) so that the call's
                                  * waves fill whole generations of what the chip holds.  Every chain boundary is a
                                  * place where the recovered clock may differ from the serial loop's by the loop's

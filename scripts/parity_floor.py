@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--chains", default="0,64,112,192,256,512")
     ap.add_argument("--bursts", type=int, default=2, help="consecutive bursts; the last one is compared (steady state)")
     ap.add_argument("--esn0", type=float, default=12.0)
+    ap.add_argument("--passes", default="", help="also: force the clock recovery to exactly these pass counts (e.g. 3,4,5,6,8)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -85,6 +86,13 @@ def main():
         g, ms, st = run(clock_chain_syms=ns_)
         out["tiled"][str(ns_)] = {"vs_oracle": cmp(g, want), "vs_serial_device": cmp(g, ser), "ms_per_call": round(ms, 3),
                                   "clock_passes": st.clock_passes, "Msamples_per_s": round(n / ms / 1e3, 1)}
+    if args.passes:
+        out["forced_passes"] = {}
+        for p_ in [int(v) for v in args.passes.split(",")]:
+            # max_passes caps both loops (the Costas loop needs 2 here), clock_min_passes keeps the stop rule from ending earlier
+            g, ms, st = run(max_passes=max(p_, 3), clock_min_passes=p_) if p_ >= 3 else run(max_passes=p_)
+            out["forced_passes"][str(p_)] = {"vs_oracle": cmp(g, want), "vs_serial_device": cmp(g, ser), "ms_per_call": round(ms, 3),
+                                             "clock_passes": st.clock_passes, "costas_passes": st.costas_passes}
     s = json.dumps(out, indent=1)
     print(s)
     if args.out:

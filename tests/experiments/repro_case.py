@@ -1,0 +1,77 @@
+"""One fuzz case under the microscope (GPU): where the soft symbols leave the oracle's, per call, under a few
+library settings.  python tests/experiments/repro_case.py  (edit CASE)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import oracle
+import xritdemod_amd as xa
+from xritdemod_amd import synth
+
+CASE = dict(seed=798172660, mode="hrit", D=5, n=1988307, typ=2, cuts=[794154, 1968047],
+            extra=dict(esn0_db=18.83, carrier_hz=-44.79, clock_ppm=99.62, timing_offset=0.41, phase0=-0.55))
+
+
+def run(case, label, **cfg):
+    mode, D, n, typ = case["mode"], case["D"], case["n"], case["typ"]
+    base = 1.25e6 if mode == "lrit" else 2.5e6
+    fs = base * D
+    sym, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
+    amp = 0.1 if typ == 0 else 0.3
+    x = synth.generate(synth.SynthParams(fs_in=fs, symbol_rate=sym, alpha=alpha, amplitude=amp, seed=case["seed"], **case["extra"]), n)
+    if typ == 1:
+        xi = np.clip(np.round(x.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    elif typ == 2:
+        xi = np.clip(np.round(x.view(np.float32) * 128), -128, 127).astype(np.int8)
+    else:
+        xi = x
+    per = 1 if typ == 0 else 2
+    cuts = sorted(set([0, n] + case["cuts"]))
+    od = oracle.Demod(oracle.config(mode, fs, D))
+    gd = xa.Demodulator(xa.Demodulator.config(mode, fs, D, **cfg))
+    pos = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        seg = xi[per * lo:per * hi]
+        w, g = od.process(seg, typ), gd.process(seg, typ)
+        st = gd.stats()
+        m = min(len(w), len(g))
+        big = np.abs(w[:m]) > 1e-3
+        bad = np.nonzero(np.sign(w[:m])[big] != np.sign(g[:m])[big])[0]
+        first = int(np.nonzero(big)[0][bad[0]]) if len(bad) else -1
+        if len(bad) > 3:
+            idx = np.nonzero(big)[0][bad]
+            a, b = int(idx[0]), int(idx[-1])
+            seg_w, seg_g = w[a:b + 1], g[a:b + 1]
+            def cc(u, v):
+                k = min(len(u), len(v))
+                return float(np.dot(u[:k], v[:k]) / (np.linalg.norm(u[:k]) * np.linalg.norm(v[:k]) + 1e-30))
+            print(f"   flips span symbols [{a},{b}] ({b - a + 1} symbols, {len(bad)} flips); correlation at lag 0 {cc(seg_w, seg_g):.3f}, "
+                  f"g one later {cc(w[a:b], g[a + 1:b + 1]):.3f}, g one earlier {cc(w[a + 1:b + 1], g[a:b]):.3f}")
+        print(f"{label}: call [{lo},{hi}) symbols {len(w)} {len(g)} rms {np.sqrt(np.mean((w[:m]-g[:m])**2)):.3e} flips {len(bad)} first {first}"
+              f" | costas passes {st.costas_passes} unconv {st.costas_unconverged} clock passes {st.clock_passes} open_large {st.clock_open_large}", flush=True)
+        pos += len(w)
+
+
+CASES = {
+    134: dict(seed=644070913, mode="lrit", D=1, n=260556, typ=1, cuts=[217838],
+              extra=dict(esn0_db=2.52, carrier_hz=542.7, clock_ppm=92.08, timing_offset=0.93, phase0=-2.1)),
+    111: dict(seed=1027498899, mode="hrit", D=8, n=3062143, typ=1, cuts=[],
+              extra=dict(esn0_db=2.04, carrier_hz=-289.9, clock_ppm=81.07, timing_offset=0.55, phase0=2.61)),
+    128: dict(seed=649654837, mode="lrit", D=3, n=1024737, typ=1, cuts=[508478, 883929],
+              extra=dict(esn0_db=2.02, carrier_hz=164.72, clock_ppm=-53.77, timing_offset=0.96, phase0=0.81)),
+}
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for k in sys.argv[1:]:
+            run(CASES[int(k)], f"case {k}")
+            run(CASES[int(k)], f"case {k} serial clock", clock_serial=1)
+            run(CASES[int(k)], f"case {k} 40 passes", clock_min_passes=40)
+        sys.exit(0)
+    run(CASE, "chain 512", costas_chain_len=512)
+    run(CASE, "chain default")
+    run(CASE, "chain 512 serial clock", costas_chain_len=512, clock_serial=1)
+    c2 = dict(CASE); c2["typ"] = 0
+    run(c2, "chain 512 cf32", costas_chain_len=512)
+    c3 = dict(CASE); c3["cuts"] = []
+    run(c3, "chain 512 one call", costas_chain_len=512)

@@ -170,6 +170,11 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         set_error("invalid configuration");
         return XRIT_E_INVALID;
     }
+    if (cfg->costas_chain_len != 0 && (cfg->costas_chain_len < 16 || cfg->costas_chain_len > 320)) {
+        set_error("costas_chain_len = %d: 0 (= 256) or 16..320 samples; beyond that the hand-off solve does not converge reliably",
+                  cfg->costas_chain_len);
+        return XRIT_E_INVALID;
+    }
     if (cfg->rrc_taps < 3) {
         set_error("rrc_taps = %d: the matched filter needs at least 3 taps (RRC_TAPS is 63, Parameters.h:28)", cfg->rrc_taps);
         return XRIT_E_INVALID;

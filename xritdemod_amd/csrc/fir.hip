@@ -13,6 +13,8 @@
 // operands.  RC*D odd gives a conflict-free ds_read_b64 lane stride; for even
 // strides the LDS image is skewed by one sample per D (PAD).
 #include "kernels.h"
+
+#include <cstdlib>
 #include "agc_wave.h"
 
 namespace xrit {
@@ -119,7 +121,10 @@ __device__ __forceinline__ void fir_leave_history(const void *__restrict__ in, c
     }
 }
 
-template <int RC, bool PAD, int TYPE, int APL = 0>
+// TS > 0 (decimation 1, TS taps -- the chain's 63-tap matched filter): the window walk is straight-line code with
+// all taps in scalar registers.  The generic loop fetches RC rows of taps per eight samples through the scalar
+// cache and waits for them and for its LDS reads three times per iteration: 36 % of the vector rate.
+template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
@@ -199,7 +204,38 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     const int lane_base = PAD ? tid * RC * (D + 1) : tid * RC * D;
     const float2 *w = tile + lane_base;
     // PAD: window index i sits at i + i/D; walk it D samples at a time
-    if (PAD) {
+    if (TS > 0) {
+        // row 0 of g is the reversed filter, g[i] = h[TS-1-i] (zero behind it); output c takes sample i with tap
+        // g[i - c].  Taps sit in scalar registers as aligned pairs and v_pk_fma_f32 broadcasts either half of a
+        // pair through op_sel -- written out, because left to itself the compiler builds a (tap, tap) pair per use
+        // and spills scalar registers over it (150 v_readlane + 190 s_nop next to the 315 multiply-adds).
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        constexpr int NP = (TS + 1) / 2;
+        const unsigned long long *gp = reinterpret_cast<const unsigned long long *>(g);
+        unsigned long long tp[NP > 0 ? NP : 1];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) tp[k] = gp[k];
+        v2f a[RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) a[c] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TS + (RC - 1) * DS; ++i) {
+            const float2 xs = w[i];
+            const v2f x = {xs.x, xs.y};
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const int j = i - c * DS;
+                if (j >= 0 && j < TS) {
+                    if (j & 1)
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a[c]) : "s"(tp[j >> 1]), "v"(x));
+                    else
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[c]) : "s"(tp[j >> 1]), "v"(x));
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < RC; ++c) acc[c] = make_float2(a[c].x, a[c].y);
+    } else if (PAD) {
         int i = 0, off = 0;
         while (i < Wpad) {
             int run = min(D, Wpad - i);
@@ -234,9 +270,19 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         }
     }
     const long long m0 = out_base + (long long)tid * RC;
+    // The outputs leave through LDS: a lane holds RC consecutive outputs, so stores straight from registers are
+    // 8-byte pieces RC * 8 bytes apart -- 64 separate write requests per wave instruction, every 128-byte line
+    // written in 16 pieces; re-ordered, a wave instruction writes 512 consecutive bytes.
+    {
+        __syncthreads();                          // the window tile (or the wave maps in it) is dead
+        float2 *ot = tile;
 #pragma unroll
-    for (int c = 0; c < RC; ++c)
-        if (m0 + c < n_out) out[m0 + c] = acc[c];
+        for (int c = 0; c < RC; ++c) ot[tid * RC + c] = acc[c];
+        __syncthreads();
+        const long long left = n_out - out_base;
+        const int cnt = left < OB ? (int)left : (int)OB;
+        for (int k = tid; k < cnt; k += nthr) out[out_base + k] = ot[k];
+    }
     if (!PAD && agc.maps != nullptr) {
         // AGC reduce sweep, fused: the composed gain map g -> min(a g + b, c) of every run of 64 * RC outputs,
         // i.e. of the outputs of one wave.  Composition is not commutative: a lane composes its own outputs in
@@ -256,65 +302,30 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         const int lane = tid & 63;
         if (lane == 0 && m0 < n_out) agc.maps[m0 / (64 * RC)] = v;
     }
-    if (stat != nullptr && statL == 64 * RC) {
-        // one run per wave: sum in registers, DPP row sums, four row totals -- fixed order, no LDS
-        float sr = 0.f, si = 0.f;
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            if (m0 + c < n_out) {
-                const float zr = acc[c].x, zi = acc[c].y;
-                sr += zr * zr - zi * zi;
-                si += 2.0f * zr * zi;
-            }
-        }
-        sr += agc_dpp<0x111>(0.f, sr); si += agc_dpp<0x111>(0.f, si);
-        sr += agc_dpp<0x112>(0.f, sr); si += agc_dpp<0x112>(0.f, si);
-        sr += agc_dpp<0x114>(0.f, sr); si += agc_dpp<0x114>(0.f, si);
-        sr += agc_dpp<0x118>(0.f, sr); si += agc_dpp<0x118>(0.f, si);
-        float tr = 0.f, ti = 0.f;
-#pragma unroll
-        for (int r = 15; r < 64; r += 16) {
-            tr += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sr), r));
-            ti += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(si), r));
-        }
-        if ((tid & 63) == 0 && m0 < n_out) stat[m0 / (64 * RC)] = make_float2(tr, ti);
-    } else if (stat != nullptr) {
-        // per-thread partial sums of z^2, split where the thread's outputs cross into the next run
-        __syncthreads();                      // the window tile is dead: reuse it
-        float2 *pa = tile, *pb = tile + nthr;
-        const int o0 = tid * RC;              // first output of this thread inside the block
-        const int first_run = o0 / statL;
-        float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            if (m0 + c < n_out) {
-                float zr = acc[c].x, zi = acc[c].y;
-                float vr = zr * zr - zi * zi, vi = 2.0f * zr * zi;
-                if ((o0 + c) / statL == first_run) { a.x += vr; a.y += vi; }
-                else { b.x += vr; b.y += vi; }
-            }
-        }
-        pa[tid] = a;
-        pb[tid] = b;
-        __syncthreads();
-        // one wave per run (round robin), one partial per lane, fixed-order shuffle tree: deterministic
-        const int runs = (nthr * RC) / statL;
+    if (stat != nullptr) {
+        // sum z^2 per run of statL outputs, from the outputs staged in LDS above (statL divides the block's outputs):
+        // one wave per run (round robin), lane l adds outputs l, l + 64, ... of the run, then a fixed-order shuffle
+        // tree over the lanes -- deterministic.  (Round 2 took it from per-thread partial sums split at run
+        // boundaries: 0.05 ms of the matched filter's 0.30.)
+        const int runs = (int)(OB / statL);
         const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+        const float2 *ot = tile;
         for (int j = wave; j < runs; j += nwaves) {
-            const int lo = j * statL, hi = lo + statL;              // outputs [lo, hi) of the block
-            const int t0 = lo / RC, t1 = min(nthr - 1, (hi - 1) / RC);
+            const long long first = out_base + (long long)j * statL;      // wave-uniform
+            if (first >= n_out) break;
             float sr = 0.f, si = 0.f;
-            for (int t = t0 + lane; t <= t1; t += 64) {
-                const int fr = (t * RC) / statL;
-                if (fr == j) { sr += pa[t].x; si += pa[t].y; }
-                else if (fr + 1 == j) { sr += pb[t].x; si += pb[t].y; }
+            for (int i = lane; i < statL; i += 64) {
+                if (first + i < n_out) {
+                    const float2 z = ot[j * statL + i];
+                    sr += z.x * z.x - z.y * z.y;
+                    si += 2.0f * z.x * z.y;
+                }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 sr += __shfl_down(sr, off, 64);
                 si += __shfl_down(si, off, 64);
             }
-            const long long run = out_base / statL + j;
-            if (lane == 0 && run * statL < n_out) stat[run] = make_float2(sr, si);
+            if (lane == 0) stat[first / statL] = make_float2(sr, si);
         }
     }
 }
@@ -566,10 +577,9 @@ bool FirStage::agc_supported() const
 
 bool FirStage::stat_supported(int statL) const
 {
-    // runs must not straddle blocks, and the two partial arrays must fit in the window tile
+    // runs must not straddle blocks (the sums are taken from the block's outputs staged in LDS)
     if (poly) return false;
-    if (statL == 64 * RC && !pad && threads % 64 == 0) return true;      // one run per wave
-    return statL > 0 && !pad && (threads * RC) % statL == 0 && statL >= RC && (size_t)2 * threads * sizeof(float2) <= lds_bytes;
+    return statL > 0 && !pad && threads % 64 == 0 && (threads * RC) % statL == 0;
 }
 
 void FirStage::release()
@@ -591,7 +601,15 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
                        out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
                        f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
-    if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
+    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !getenv("XRIT_NO_STATIC_DEC"))
+        hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5>), dim3(blocks),
+                           dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
+                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
+    else if (RC == 5 && !PAD && f.T == 63 && f.D == 1 && type == XRIT_SAMPLE_FLOATIQ && !getenv("XRIT_NO_STATIC_MF"))
+        hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 5 && !PAD) ? 63 : 0>), dim3(blocks),
+                           dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
+                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
+    else if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
 #undef XR_FIR_GO
@@ -614,6 +632,11 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
     const unsigned blocks = div_up(n, (size_t)f.threads * 5);
     {
         ProfScope ps(prof, "fir_rrc", s);
+        if (f.T == 63 && !getenv("XRIT_NO_STATIC_MF"))
+            hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3, 63>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
+                               in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
+                               (long long)n, f.tile_len, stat, statL, none, af, (float2 *)nullptr);
+        else
         hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                            in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
                            (long long)n, f.tile_len, stat, statL, none, af, (float2 *)nullptr);
