@@ -9,11 +9,12 @@ def run(nh, log2):
     n = 1 << log2
     D, fs = 5, 6.25e6
     dev = torch.device("cuda:0")
-    bufs = torch.empty((nh, 3, n, 2), dtype=torch.float32, device=dev)
+    nb = int(os.environ.get("STEPS", "12")) + 1
+    bufs = torch.empty((nh, nb, n, 2), dtype=torch.float32, device=dev)
     st0 = torch.cuda.current_stream().cuda_stream
     for h in range(nh):
         sp = _capi.synth_params(fs_in=fs, seed=0x58524954 + 2 * h)
-        for b in range(3):
+        for b in range(nb):
             _capi.synth_generate_device(sp, b * n, n, bufs[h, b].data_ptr(), device=0, stream=st0)
     torch.cuda.synchronize()
     dems = [xa.Demodulator(xa.Demodulator.config("lrit", fs, D)) for _ in range(nh)]
@@ -25,15 +26,17 @@ def run(nh, log2):
     for h in range(nh):
         work(h, [0])
     torch.cuda.synchronize()
+    steps = list(range(1, nb))          # consecutive bursts of one stream per handle (the loops stay locked)
     t0 = time.perf_counter()
-    ths = [threading.Thread(target=work, args=(h, [1, 2])) for h in range(nh)]
+    ths = [threading.Thread(target=work, args=(h, steps)) for h in range(nh)]
     for t in ths: t.start()
     for t in ths: t.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{nh} handle(s) x 2 bursts of 2^{log2}: {dt*1e3:.2f} ms -> {nh*2*n/dt/1e6:.0f} Msamples/s")
+    print(f"{nh} handle(s) x {len(steps)} bursts of 2^{log2}: {dt*1e3:.2f} ms -> {nh*len(steps)*n/dt/1e6:.0f} Msamples/s", flush=True)
 
 run(1, 28)
-run(2, 27)
-run(4, 26)
 run(2, 28)
+run(2, 27)
+run(3, 27)
+run(1, 28)

@@ -88,6 +88,7 @@ __device__ __forceinline__ void fir_fill_through_agc(float2 *tile, const AgcFill
                 agc_step(v[it][k].x, v[it][k].y, gg, af.rate, af.ref, af.maxg, yr, yi);
                 const long long idx = i0 + k - tile_start;
                 if (idx >= 0 && idx < tile_len) tile[idx] = make_float2(yr, yi);
+                if (i0 + k == n_in - 1) af.state_out[0] = gg;         // the AGC's gain after the call
             }
         }
     }
@@ -131,7 +132,9 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
                  int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af,
                  float2 *__restrict__ hist_new)
 {
-    if (APL == 0 && hist_new != nullptr && blockIdx.x == gridDim.x - 1) fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
+    // (AGC in the window fill: `in` is the serially produced AGC output if the guard has tripped, else see below)
+    if (hist_new != nullptr && blockIdx.x == gridDim.x - 1 && (APL == 0 || af.state_out[1] != 0.0f))
+        fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
     const int nthr = blockDim.x;
@@ -196,6 +199,11 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         }
     }
     __syncthreads();
+    if (APL > 0 && hist_new != nullptr && blockIdx.x == gridDim.x - 1 && af.state_out[1] == 0.0f) {
+        // the new history is AGC OUTPUT, which exists nowhere but in the window tiles: the last workgroup's tile
+        // ends with it (D == 1: the tile starts T - 1 samples in front of the workgroup's first output)
+        for (int i = tid; i < T - 1; i += nthr) hist_new[i] = tile[(int)(n_in - (T - 1) + i - tile_start)];
+    }
 
     float2 acc[RC];
 #pragma unroll
@@ -449,54 +457,6 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
     }
 }
 
-// Fused AGC: new history = the AGC OUTPUT of the last T-1 samples (or older history in front of a short call),
-// and the AGC's gain after the call.  One block; the waves take the last runs of the stream.
-template <int APL>
-__global__ void __launch_bounds__(256) fir_agc_hist_kernel(AgcFill af, const float2 *__restrict__ fallback,
-                                                           const float2 *__restrict__ hist_old,
-                                                           float2 *__restrict__ hist_new, int T, long long n)
-{
-    constexpr int RL = 64 * APL;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long h0 = n - (T - 1);                     // first stream index of the new history (may be < 0)
-    for (int i = tid; i < T - 1; i += blockDim.x) {
-        const long long j = h0 + i;
-        if (j < 0) {
-            const long long hj = (T - 1) + j;
-            hist_new[i] = hj >= 0 ? hist_old[hj] : make_float2(0.f, 0.f);
-        } else if (af.state_out[1] != 0.0f) {
-            hist_new[i] = fallback[j];                    // guard tripped: the serial kernel wrote output and gain
-        }
-    }
-    if (af.state_out[1] != 0.0f || n <= 0) return;
-    const long long last_run = (n - 1) / RL;
-    const long long first_run = (h0 > 0 ? h0 : 0) / RL;
-    for (long long rr = first_run + wave; rr <= last_run; rr += blockDim.x >> 6) {
-        const long long i0 = rr * RL + (long long)lane * APL;
-        int cnt = 0;
-        if (i0 < n) cnt = (int)((n - i0) < APL ? (n - i0) : APL);
-        float2 v[APL];
-#pragma unroll
-        for (int k = 0; k < APL; ++k) v[k] = k < cnt ? af.x[i0 + k] : make_float2(0.f, 0.f);
-        AgcMap m = agc_identity();
-#pragma unroll
-        for (int k = 0; k < APL; ++k)
-            if (k < cnt) m = agc_compose(m, agc_sample_map(v[k].x, v[k].y, af.rate, af.ref, af.maxg));
-        const AgcMap ex = agc_wave_exclusive(m);
-        float gg = agc_apply(agc_compose(af.pre_run[rr], ex), af.state_in[0]);
-#pragma unroll
-        for (int k = 0; k < APL; ++k) {
-            if (k < cnt) {
-                float yr, yi;
-                agc_step(v[k].x, v[k].y, gg, af.rate, af.ref, af.maxg, yr, yi);
-                const long long i = i0 + k - h0;
-                if (i >= 0 && i < T - 1) hist_new[i] = make_float2(yr, yi);
-            }
-        }
-        if (cnt > 0 && i0 + cnt == n) af.state_out[0] = gg;
-    }
-}
-
 int FirStage::init(const float *taps, int ntaps, int decim)
 {
     T = ntaps;
@@ -635,16 +595,11 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
         if (f.T == 63 && !getenv("XRIT_NO_STATIC_MF"))
             hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3, 63>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                                in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
-                               (long long)n, f.tile_len, stat, statL, none, af, (float2 *)nullptr);
+                               (long long)n, f.tile_len, stat, statL, none, af, f.hist[f.cur ^ 1].as<float2>());
         else
         hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                            in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
-                           (long long)n, f.tile_len, stat, statL, none, af, (float2 *)nullptr);
-    }
-    {
-        ProfScope ps(prof, "fir_hist", s);
-        hipLaunchKernelGGL(fir_agc_hist_kernel<3>, dim3(1), dim3(256), 0, s, af, in, f.hist[f.cur].as<float2>(),
-                           f.hist[f.cur ^ 1].as<float2>(), f.T, (long long)n);
+                           (long long)n, f.tile_len, stat, statL, none, af, f.hist[f.cur ^ 1].as<float2>());
     }
     XR_HIP(hipGetLastError());
     f.cur ^= 1;
