@@ -20,4 +20,5 @@ python scripts/timeline_print.py gpurun_out/tl_$TAG/t_kernel_trace.csv > $OUT/ti
 python scripts/small_call_latency.py 2>&1 | grep "^D=" > $OUT/small_calls.txt
 python scripts/parity_floor.py --burst-log2 28 --chains 0,256 --out $OUT/parity_floor_c2.json > /dev/null 2>&1
 python scripts/parity_floor.py --burst-log2 25 --chains 0,64,112,192,256,512 --out $OUT/parity_floor_chain_sweep.json > /dev/null 2>&1
+python scripts/parity_floor.py --burst-log2 27 --chains 0 --passes 2,3,4,5,6,7,8,10,14 --out $OUT/parity_floor_passes_sweep.json > /dev/null 2>&1
 ls -R $OUT | head -40

@@ -37,6 +37,7 @@ copy("timeline.txt", f"{tag}_c2_timeline.txt")
 copy("small_calls.txt", f"{tag}_small_calls.txt")
 copy("parity_floor_c2.json", f"{tag}_parity_floor_c2.json")
 copy("parity_floor_chain_sweep.json", f"{tag}_parity_floor_chain_sweep.json")
+copy("parity_floor_passes_sweep.json", f"{tag}_parity_floor_passes_sweep.json")
 for name in ("c1", "c3", "c5"):
     if os.path.exists(os.path.join(src, f"bench_{name}.json")):
         json.dump(last_json(os.path.join(src, f"bench_{name}.json")), open(os.path.join(dst, f"{tag}_bench_{name}.json"), "w"), indent=1)
@@ -70,7 +71,7 @@ if os.path.exists(fpath) and os.path.exists(wpath):
 
     def last_burst(acc):
         """sum over the dispatches of the run's LAST burst (steady state; the first one, cold-started, runs more passes)"""
-        starts = sorted(d for d, _ in acc.get("fir_decim_kernel<3, false, 0, 0>", []))
+        starts = sorted(d for k, vals in acc.items() if k.startswith("fir_decim_kernel<3, false, 0, 0") for d, _ in vals)
         lo = starts[-1] if starts else 0
         return sum(v for k, vals in acc.items() if "synth_kernel" not in k and "read_bw" not in k for d, v in vals if d >= lo)
 
@@ -90,15 +91,16 @@ if os.path.exists(fpath) and os.path.exists(wpath):
         fo.write("kernel,dispatches,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,hbm_bytes_corrected_per_dispatch\n")
         for k, n, fv, wv, _, _ in rows:
             fo.write(f"{k},{n},{fv:.1f},{wv:.1f},{(2 * fv + wv) * 1024:.0f}\n")
-    names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0>", "clock_pass": "clock_pass_kernel<1, 32, 20>",
+    names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0", "clock_pass": "clock_pass_kernel<1, 32, 20>",
              "clock_pass_jac": "clock_pass_kernel<3, 32, 20>", "costas_pass": "costas_pass_kernel<false>",
-             "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0, 3>",
+             "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0, 3",
              "clock_output": "clock_output_kernel<32, 20, false>"}
     d = {r[0]: r for r in rows}
     out = {}
     src_note = (f"profiles/{tag}_c2_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE "
                 "doubled per the gfx950 correction)")
     for s, full in names.items():
+        full = next((k for k in d if k.startswith(full)), full)      # (template arguments behind the listed ones vary)
         if full in d:
             _, n, fv, wv, _, _ = d[full]
             out[s] = {"burst_log2": 28, "hbm_bytes_per_launch": round((2 * fv + wv) * 1024), "fetch_kib_raw": round(fv, 1),
