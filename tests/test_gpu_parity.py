@@ -75,6 +75,33 @@ def test_fir_stage(xa, oracle_mod, D, kind):
             assert np.abs(a - b).max() <= 4e-6 * max(1.0, np.abs(a).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,kind,switch", [(5, "lp5", "XRIT_NO_STATIC_DEC"), (1, "rrc", "XRIT_NO_STATIC_MF")])
+def test_fir_straight_line_kernels_are_the_generic_ones_bit_for_bit(xa, oracle_mod, D, kind, switch, monkeypatch):
+    """The chain's two filters (151 taps at decimation 5, the 63-tap matched filter) run as straight-line code with
+    the taps in scalar registers (fir_decim_kernel<..., TS, DS>, inline-asm v_pk_fma_f32); every other tap count runs
+    the generic loop.  Same products added in the same order (the generic loop's extra terms are zero taps): the
+    outputs must be identical bit for bit, over several calls (history) and ragged lengths."""
+    o = oracle_mod
+    taps = {"rrc": o.rrc_taps(1, 1.25e6, 293883, 0.5, 63), "lp5": o.lowpass_taps(1, 6.25e6, 625e3, 100e3)}[kind]
+    assert len(taps) == (151 if D == 5 else 63)
+    rng = np.random.default_rng(7 + D)
+    n_out = [100003, 5, 0, 4097, 70000]
+    x = (rng.standard_normal(sum(n_out) * D) + 1j * rng.standard_normal(sum(n_out) * D)).astype(np.complex64)
+
+    def run():
+        f, pos, out = xa.FirFilter(D, taps), 0, []
+        for n in n_out:
+            out.append(f.Work(x[pos:pos + n * D], n))
+            pos += n * D
+        return np.concatenate(out)
+
+    fast = run()
+    monkeypatch.setenv(switch, "1")
+    generic = run()
+    assert len(fast) == sum(n_out) and np.array_equal(fast.view(np.uint32), generic.view(np.uint32))
+
+
 def test_agc_stage(xa, oracle_mod):
     o = oracle_mod
     rng = np.random.default_rng(11)
