@@ -174,7 +174,10 @@ typedef struct xrit_demod_stats {
     uint32_t clock_open_large;    /* boundaries left with a timing residual beyond 0.02 sample or an unresolved symbol
                                    * slip when the passes ended: 0 on a healthy call; non-zero means acquisition did
                                    * not finish within max_passes (symbol count or decisions may be off) */
-    int32_t  reserved[4];
+    int32_t  costas_serial_walk;  /* 1 if the carrier hand-off was still open after 32 passes (pull-in through cycle
+                                   * slips closes a chain or two per pass) and the open region was walked by one
+                                   * serial wave instead: exact, ~0.1 us per sample of the region, once per acquisition */
+    int32_t  reserved[3];
 } xrit_demod_stats;
 int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s);
 

@@ -74,6 +74,7 @@ for c in range(cases):
             ser_msg = " | serial-device COUNT %d" % len(ser)
     if os.environ.get("FUZZ_DUMP") and only:
         np.save(f"/tmp/fuzz_case{c}.npy", xi)
+        print("   exact parameters", repr(extra))
         print("   seed", seed, "stats", gd.stats().costas_passes, gd.stats().clock_passes, gd.stats().costas_unconverged, gd.stats().clock_unconverged, gd.stats().agc_serial_fallback)
     if ok and len(w):
         big = np.abs(w) > 1e-3

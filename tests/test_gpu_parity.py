@@ -1150,3 +1150,29 @@ def test_low_snr_regression_seeds(xa, oracle_mod, seed, esn0, carrier, ppm, toff
     big = np.abs(w) > 1e-3
     assert np.array_equal(np.sign(w[big]), np.sign(ser[big])) and rms(w - ser) <= 5e-4
     assert int(np.sum(np.sign(w[big]) != np.sign(g[big]))) <= 3 and rms(w - g) <= 1.5e-3
+
+
+def test_pull_in_through_cycle_slips_is_walked_serially(xa, oracle_mod, monkeypatch):
+    """A cold start at the edge of the Costas loop's lock-in range at low Es/N0 (fuzz, round 2: LRIT, decimation 5,
+    +417 Hz, 6.5 dB): the loop slips cycles for most of the 960 chains of the call, the hand-off closes a chain or
+    two per pass and ran out of its 192 passes with 136 boundaries open -- 137 hard decisions off.  Past 32 passes
+    the open region is now walked by one serial wave (costas_serial_states_kernel), which leaves every chain of it
+    the exact start state: same decisions and soft symbols as the oracle, stats.costas_serial_walk = 1.  With the
+    walk switched off the old behaviour (and its honest statistics) is still there."""
+    p = synth.SynthParams(fs_in=6.25e6, symbol_rate=293883.0, alpha=0.5, amplitude=0.1, seed=337516533,
+                          esn0_db=6.48861985477674, carrier_hz=417.12013004884477, clock_ppm=50.690832545210355,
+                          timing_offset=0.6751554701191533, phase0=0.4357498268346536)
+    n = 1228445
+    x = synth.generate(p, n)
+    want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, 5)).process(x)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    got = dem.process(x)
+    st = dem.stats()
+    assert len(got) == len(want)
+    assert st.costas_serial_walk == 1 and st.costas_unconverged == 0 and st.costas_passes < 64
+    big = np.abs(want) > 1e-3
+    assert np.array_equal(np.sign(got[big]), np.sign(want[big])) and rms(got - want) <= 6e-4
+    monkeypatch.setenv("XRIT_NO_SERIAL_WALK", "1")
+    dem2 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    dem2.process(x)
+    assert dem2.stats().costas_serial_walk == 0 and dem2.stats().costas_unconverged > 0

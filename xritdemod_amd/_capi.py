@@ -34,7 +34,7 @@ class DemodStats(C.Structure):
                 ("costas_passes", C.c_int32), ("clock_passes", C.c_int32),
                 ("costas_unconverged", C.c_uint32), ("clock_unconverged", C.c_uint32),
                 ("costas_max_residual", C.c_float), ("clock_max_residual", C.c_float),
-                ("agc_serial_fallback", C.c_int32), ("clock_open_large", C.c_uint32), ("reserved", C.c_int32 * 4)]
+                ("agc_serial_fallback", C.c_int32), ("clock_open_large", C.c_uint32), ("costas_serial_walk", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class SynthParams(C.Structure):

@@ -462,7 +462,7 @@ int CostasStage::reset(hipStream_t s)
 void CostasStage::release()
 {
     state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();
-    work.release(); flags.release(); counters.release(); wsolve.release();
+    work.release(); flags.release(); counters.release(); wsolve.release(); rescue.release();
     if (h_counters) (void)hipHostFree(h_counters);
     h_counters = nullptr;
 }
@@ -480,6 +480,58 @@ int CostasStage::get_state(float *phase, float *freq, hipStream_t s)
 // control block: counters[0..16) = ctl words, per-pass counter slots after it
 
 static inline int *costas_ctl(const DevBuf &b) { return b.as<int>(); }
+// ---- serial rescue -----------------------------------------------------------------------------------------------
+// While the loop pulls in through cycle slips the hand-off closes a chain or two per pass: a cold start at the
+// edge of the lock-in range and at low Es/N0 can slip for a thousand chains (fuzz: LRIT, +417 Hz, 6.5 dB, 960
+// chains -- 136 boundaries still open after 192 passes, 137 hard decisions off).  Such a region is cheaper to walk
+// than to iterate: ONE wave runs the recurrence through it sample by sample (every lane the same arithmetic on
+// v_readlane'd samples, ~0.1 us per sample) and leaves the exact start state of every chain on the way; the
+// passes then only have to confirm the closure and carry a parity change to the chains behind the region.
+__global__ void costas_open_range_kernel(const float2 *__restrict__ E, const float2 *__restrict__ S, int K,
+                                         float tol_p, float tol_f, int *__restrict__ range)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;       // boundary between chains k and k + 1
+    if (k >= K - 1) return;
+    const float2 e = E[k], s = S[k + 1];
+    const float rp = e.x - s.x;
+    const float m = rintf(rp * (float)(1.0 / XR_PI_D));
+    const float r1 = rp - m * (float)XR_PI_D, r2 = e.y - s.y;
+    const bool open = !(fabsf(r1) <= tol_p) || !(fabsf(r2) <= tol_f) || (((int)m) & 1);
+    if (open) {
+        atomicMin(&range[0], k);
+        atomicMax(&range[1], k);
+    }
+}
+
+__global__ void __launch_bounds__(64) costas_serial_states_kernel(const float2 *__restrict__ z, float2 *__restrict__ S,
+                                                                  int *__restrict__ dirty, long long n, int L, int K,
+                                                                  int k_first, int k_last, CostasGains g)
+{
+    const int lane = threadIdx.x;
+    const float2 st = S[k_first];
+    float phase = costas_prewrap(st.x), freq = st.y;
+    CostasTan tan_unused{1.f, 0.f, 0.f, 1.f};
+    for (int k = k_first; k <= k_last; ++k) {
+        const long long base = (long long)k * L;
+        const int len = (int)min((long long)L, n - base);
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const long long j = base + i0 + lane;
+            const float2 v = j < n ? z[j] : make_float2(0.f, 0.f);
+            const int cnt = min(64, len - i0);
+            for (int q = 0; q < cnt; ++q) {                                     // wave-uniform
+                const float zr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), q));
+                const float zi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), q));
+                float yr, yi;
+                costas_step<false>(zr, zi, phase, freq, g, yr, yi, tan_unused);
+            }
+        }
+        if (k + 1 < K && lane == 0) {
+            S[k + 1] = make_float2(phase, freq);
+            dirty[k + 1] = 1;
+        }
+    }
+}
+
 static inline unsigned *costas_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + COSTAS_CTL_WORDS + (size_t)pass * 8; }
 
 int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
@@ -545,6 +597,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     unconverged = 0;
     max_residual = 0;
     job = Job{};
+    walked = false;
     job.in = in; job.out = out; job.n = n; job.om = om; job.om_off = om_off; job.inv_sps = inv_sps;
     if (n == 0) return XRIT_OK;
     const int K = (int)((n + (size_t)L - 1) / (size_t)L);
@@ -613,6 +666,7 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         if (redone) *redone = true;
         while (h_counters[0] == 0 && job.enqueued < max_passes) {
             if (h_counters[NEWTON_CTL_TAKEOVER]) job.gated = true;     // a boundary outside the trust region
+            if (!job.rescued && job.enqueued >= rescue_after) XR_TRY(serial_rescue(s, prof));
             XR_TRY(enqueue_passes(2, s, prof));
             XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
@@ -649,6 +703,35 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         }
     }
     cur ^= 1;     // the carried state now is the one the final pass left
+    return XRIT_OK;
+}
+
+// The region between the first and the last boundary still open, walked serially (see costas_serial_states_kernel).
+// Called from finish() with the stream idle; regions beyond rescue_max_samples are left to the passes.
+int CostasStage::serial_rescue(hipStream_t s, Profiler *prof)
+{
+    job.rescued = true;
+    if (job.K <= 2 || getenv("XRIT_NO_SERIAL_WALK")) return XRIT_OK;
+    XR_TRY(rescue.reserve(2 * sizeof(int)));
+    const int init[2] = {0x7fffffff, -1};
+    XR_HIP(hipMemcpyAsync(rescue.p, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(costas_open_range_kernel, dim3(div_up((size_t)job.K, 256)), dim3(256), 0, s, E.as<float2>(),
+                       S.as<float2>(), job.K, tol_phase, tol_freq, rescue.as<int>());
+    int range[2];
+    XR_HIP(hipMemcpyAsync(range, rescue.p, sizeof range, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    if (range[1] < 0) return XRIT_OK;                       // nothing open after all
+    // chain range[0] ends at the first open boundary: it started from a closed one, so its start is good
+    const int k_first = range[0], k_last = range[1];
+    if ((long long)(k_last - k_first + 1) * L > rescue_max_samples) return XRIT_OK;
+    {
+        ProfScope ps(prof, "costas_serial", s);
+        hipLaunchKernelGGL(costas_serial_states_kernel, dim3(1), dim3(64), 0, s, job.in, S.as<float2>(), flags.as<int>(),
+                           (long long)job.n, L, job.K, k_first, k_last, gains);
+    }
+    XR_HIP(hipGetLastError());
+    rescues += 1;
+    walked = true;
     return XRIT_OK;
 }
 

@@ -464,6 +464,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.clock_max_residual = res_k;
     d->stats.agc_serial_fallback = d->agc_fallback_seen;
     d->stats.clock_open_large = large_k;
+    d->stats.costas_serial_walk = d->costas.job.rescued && d->costas.walked ? 1 : 0;
     *n_out = total_sym;
     if (d->cfg.strict && unc_c) {
         set_error("Costas hand-off did not close: %u boundaries above tolerance", unc_c);

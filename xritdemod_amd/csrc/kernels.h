@@ -100,8 +100,15 @@ struct CostasStage {
     int max_passes = 32;
     float trust = 1.0f, tol_phase = 1e-5f, tol_freq = 3e-8f;
     DevBuf state;           // float2 (phase, freq) carried across calls
-    DevBuf S, E, J, stat, dlin, work, flags, counters, wsolve;
+    DevBuf S, E, J, stat, dlin, work, flags, counters, wsolve, rescue;
     bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1)
+    // a hand-off still open after rescue_after passes is walked serially between its first and last open boundary
+    // (costas_serial_states_kernel), if that is at most rescue_max_samples samples
+    int rescue_after = 32;
+    long long rescue_max_samples = 4 << 20;
+    unsigned rescues = 0;             // calls of this handle that took the serial walk
+    bool walked = false;              // ... the last call did
+    int serial_rescue(hipStream_t s, Profiler *prof);
     unsigned *h_counters = nullptr;   // pinned
     int cur = 0;
     int passes = 0;
@@ -126,6 +133,7 @@ struct CostasStage {
         const float2 *in = nullptr; float2 *out = nullptr; size_t n = 0; int K = 0; int enqueued = 0;
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
         bool gated = false;     // this call has gone over to the gated solve
+        bool rescued = false;   // the serial walk has been tried
     } job;
     int batch = 4;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
@@ -189,6 +197,7 @@ struct ClockStage {
         int NG = 1;
         bool mean_j = false;    // the passes use the stream's mean Jacobian: no finite-difference pass
         bool gated = false;     // this call has gone over to the gated solve
+        bool rescued = false;   // the serial walk has been tried
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
     } job;
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
