@@ -84,7 +84,8 @@ for c in range(cases):
             ok = False
         msg = f"rms {r:.2e} sign {sgn}" + ser_msg
     print(("ok  " if ok else "FAIL"), c, "seed", seed, mode, "D", D, "n", n, "type", typ, "cuts", cuts[1:-1], "keep", keep, "symbols", len(w), len(g), msg,
-          {k: round(v, 2) for k, v in extra.items()}, knobs, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged, flush=True)
+          {k: round(v, 2) for k, v in extra.items()}, knobs, "unconv", gd.stats().costas_unconverged, gd.stats().clock_unconverged,
+          "large", gd.stats().clock_open_large, "passes", gd.stats().costas_passes, gd.stats().clock_passes, "walk", gd.stats().costas_serial_walk, flush=True)
     bad += 0 if ok else 1
 print("failures:", bad)
 sys.exit(1 if bad else 0)
