@@ -108,7 +108,16 @@ typedef struct xrit_demod_config {
                                  * against the CPU chain is what any float32 M&M fed by this chain's Costas output
                                  * shows (the recurrence lives on a 2^-21-sample lattice and keeps a one-ulp
                                  * difference for ~1e5 symbols).  A diagnostic, not a production mode. */
-    int32_t  reserved[5];
+    int32_t  clock_exact;       /* exact closure of the clock recovery's time tiling (csrc/clock_relay.h): the call is cut
+                                 * into segments that are walked with the literal recurrence, 64 symbols per step, and
+                                 * relayed until a pass changes nothing -- the symbols are then bit for bit those of
+                                 * the serial trajectory (clock_serial = 1), at a few ms per 256 Mi-sample burst instead
+                                 * of 3.9 s.  0: off (the hand-off passes stop at their ~1e-4-sample floor, DESIGN.md
+                                 * section 6); 1: until closed; n > 1: at most n relay passes -- every pass roughly
+                                 * halves what is left of the tiling's error (stats.clock_relay_closed says whether n
+                                 * sufficed) */
+    int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
+    int32_t  reserved[3];
 } xrit_demod_config;
 
 /* setLRITMode / setHRITMode + Parameters.h defaults (demodulator.cpp:177-197) */
@@ -177,7 +186,10 @@ typedef struct xrit_demod_stats {
     int32_t  costas_serial_walk;  /* 1 if the carrier hand-off was still open after 32 passes (pull-in through cycle
                                    * slips closes a chain or two per pass) and the open region was walked by one
                                    * serial wave instead: exact, ~0.1 us per sample of the region, once per acquisition */
-    int32_t  reserved[3];
+    int32_t  clock_relay_passes;  /* clock_exact: relay passes of the last call (the closing one included) */
+    int32_t  clock_relay_closed;  /* ... 1 if they ended with a pass that changed nothing: the symbols are the serial
+                                   * trajectory's, bit for bit */
+    int32_t  clock_relay_segments;/* ... segments the call was cut into */
 } xrit_demod_stats;
 int xrit_demod_get_stats(const xrit_demod *d, xrit_demod_stats *s);
 
@@ -271,6 +283,8 @@ int  xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, f
 int  xrit_clock_work(xrit_clock *c, const float *in, size_t n, float *out, size_t cap, size_t *n_out);
 /* serial = 1: one trajectory on a single wave (see xrit_demod_config.clock_serial); 0: time-tiled chains (default) */
 int  xrit_clock_set_serial(xrit_clock *c, int serial);
+/* exact closure of the tiled evaluation (see xrit_demod_config.clock_exact / clock_exact_window) */
+int  xrit_clock_set_exact(xrit_clock *c, int exact, int window);
 void xrit_clock_destroy(xrit_clock *c);
 
 /* ------------------------------------------------------------------------

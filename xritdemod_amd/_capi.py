@@ -26,7 +26,8 @@ class DemodConfig(C.Structure):
                 ("clock_omega_limit", C.c_float),
                 ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
                 ("max_passes", C.c_int32), ("strict", C.c_int32), ("clock_min_passes", C.c_int32),
-                ("slices", C.c_int32), ("clock_serial", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("slices", C.c_int32), ("clock_serial", C.c_int32), ("clock_exact", C.c_int32),
+                ("clock_exact_window", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class DemodStats(C.Structure):
@@ -34,7 +35,8 @@ class DemodStats(C.Structure):
                 ("costas_passes", C.c_int32), ("clock_passes", C.c_int32),
                 ("costas_unconverged", C.c_uint32), ("clock_unconverged", C.c_uint32),
                 ("costas_max_residual", C.c_float), ("clock_max_residual", C.c_float),
-                ("agc_serial_fallback", C.c_int32), ("clock_open_large", C.c_uint32), ("costas_serial_walk", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("agc_serial_fallback", C.c_int32), ("clock_open_large", C.c_uint32), ("costas_serial_walk", C.c_int32),
+                ("clock_relay_passes", C.c_int32), ("clock_relay_closed", C.c_int32), ("clock_relay_segments", C.c_int32)]
 
 
 class SynthParams(C.Structure):
@@ -89,6 +91,7 @@ _SIGNATURES = {
     "xrit_clock_create": (C.c_int, [C.c_float] * 5 + [C.c_int, C.POINTER(_vp)]),
     "xrit_clock_work": (C.c_int, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "xrit_clock_set_serial": (C.c_int, [_vp, C.c_int]),
+    "xrit_clock_set_exact": (C.c_int, [_vp, C.c_int, C.c_int]),
     "xrit_clock_destroy": (None, [_vp]),
     "xrit_group_unique_id": (C.c_int, [_vp]),
     "xrit_group_create": (C.c_int, [C.POINTER(DemodConfig), C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
@@ -272,11 +275,13 @@ class ClockRecovery(_Handle):
     """SatHelper::ClockRecovery(omega, gainOmega, mu, gainMu, omegaRelativeLimit); Work(in, out, n) -> symbols."""
     _destroy = "xrit_clock_destroy"
 
-    def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit, device=0, serial=False):
+    def __init__(self, omega, gain_omega, mu, gain_mu, omega_rel_limit, device=0, serial=False, exact=0, window=0):
         super().__init__()
         _check(lib().xrit_clock_create(omega, gain_omega, mu, gain_mu, omega_rel_limit, device, C.byref(self._h)))
         if serial:
             _check(lib().xrit_clock_set_serial(self._h, 1))
+        if exact:
+            _check(lib().xrit_clock_set_exact(self._h, int(exact), int(window)))
 
     def Work(self, x):
         x = _c64(x)

@@ -456,6 +456,10 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
     }
 }
 
+}  // namespace xrit
+#include "clock_relay.h"
+namespace xrit {
+
 // SS symbols of one lane.  Fast path: every running lane of the wave stays inside its ring for the whole
 // sub-step and cannot reach the end of the input -> no per-symbol guards, LDS reads only.  Otherwise the wave
 // computes the sub-step from global memory with the guards.  orow (output pass): where the symbols go.
@@ -463,11 +467,14 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 __device__ __forceinline__ void clock_put(cf32 &d, const cf32 &p) { d = p; }
 __device__ __forceinline__ void clock_put(float &d, const cf32 &p) { d = p.x; }
 
+// trow (output pass of the exact mode): the state in front of every symbol, 3 words per symbol (ii, mu, omega)
+struct ClockTraceRow { int ii[4]; float mu[4], om[4]; };
+
 template <int WP, bool OUT, typename OutT>
 __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *__restrict__ x, int WS, int lane,
                                               int origin, int cum, int lim, int SS, int A, long long ni,
                                               const ClockPar &par, ClockState &s, int &off, bool &alive,
-                                              int &produced, OutT *orow)
+                                              int &produced, OutT *orow, ClockTraceRow *trow = nullptr)
 {
     const int rel = off - cum;
     const bool safe = !alive || (lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
@@ -480,11 +487,13 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
                 // register renaming instead of a dozen moves per symbol
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if (OUT && trow) { trow->ii[i] = origin + off; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                     cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
                     if (OUT) clock_put(orow[i], p);
                 }
             } else {
                 for (int i = 0; i < SS; ++i) {
+                    if (OUT && trow) { trow->ii[i] = origin + off; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                     cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
                     if (OUT) clock_put(orow[i], p);
                 }
@@ -496,6 +505,7 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
         for (int i = 0; i < lim; ++i) {
             if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
             if (alive) {
+                if (OUT && trow) { trow->ii[i] = (int)s.ii; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                 cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
                 if (OUT) clock_put(orow[i], p);
                 ++produced;
@@ -679,14 +689,16 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
 // output pass: base trajectories only; symbol i of chain k goes to k*NS + i.  A lane's symbols of one sub-step
 // leave as one 16-byte store (soft) -- consecutive sub-steps fill the rest of the 128-byte line, which the L2 holds
 // until then (the lines in flight, 64 chains x 128 B per wave, fit it many times over).
-template <int WP, int NCM, bool SYM>
+struct ClockTrace { int *ii; float *mu, *om; };
+
+template <int WP, int NCM, bool SYM, bool TRACE = false>
 __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
                                                           long long ni, int K, int NS, ClockPar par,
                                                           int *__restrict__ terminal, int SS, int W, int WS, int A,
-                                                          int STEP)
+                                                          int STEP, ClockTrace tr = ClockTrace{nullptr, nullptr, nullptr})
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ngroups = (int)(blockDim.x >> 6), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -713,10 +725,17 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
         for (int i = 0; i < 4; ++i) ps[i] = cf32{0.f, 0.f};
         const int before = produced;
         // (sub-steps have at most 4 symbols, see ClockStage::begin)
+        ClockTraceRow trow;
         clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                produced, ps);
+                                produced, ps, TRACE ? &trow : nullptr);
         const int nv = produced - before;          // symbols of this sub-step that exist
         const unsigned long long o = obase + (unsigned long long)j * SS;
+        if (TRACE) {
+            // (the trace is a predictor for clock_relay_kernel, sized for every chain: no capacity test)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) { tr.ii[o + i] = trow.ii[i]; tr.mu[o + i] = trow.mu[i]; tr.om[o + i] = trow.om[i]; }
+        }
         if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < cap) {
             if (soft && !XR_NOSTORE) *reinterpret_cast<float4 *>(soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
             if (SYM && sym) {
@@ -936,6 +955,8 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     cur = 0;
     carry = 0;
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
+    relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
+    trace_env = getenv("XRIT_TRACE") != nullptr;
     return XRIT_OK;
 }
 
@@ -960,6 +981,7 @@ void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
+    relay.release(); trace.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -997,6 +1019,116 @@ template <typename KernelT> static void clock_allow_lds(KernelT kernel, size_t b
 {
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---- exact closure: host side ---------------------------------------------------------------------------------
+// After a batch of relay passes: how many ran, whether they closed, and -- from the end states of the last pass
+// that did something -- the call's result as clock_finalize_kernel leaves it (symbol count, carried state, tail).
+__global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelaySeg *__restrict__ e0,
+                                                                    const RelaySeg *__restrict__ e1,
+                                                                    const unsigned *__restrict__ changed, int enq, int G,
+                                                                    int Lseg, const ClockState *__restrict__ carried_in,
+                                                                    ClockState *__restrict__ carried_out,
+                                                                    ClockResult *__restrict__ res,
+                                                                    const float2 *__restrict__ x,
+                                                                    float2 *__restrict__ tail_out, long long N, int *ctl)
+{
+    if (!ctl[0]) return;        // the tiled hand-off did not close in its batch: ClockStage::finish starts over
+    __shared__ int s_term, s_buf;
+    __shared__ long long s_ii;
+    if (threadIdx.x == 0) {
+        int ran = enq, closed = 0;
+        for (int p = 0; p < enq; ++p)
+            if (changed[4 * p] == 0u) { ran = p + 1; closed = 1; break; }
+        ctl[10] = ran;
+        ctl[11] = closed;
+        s_buf = (ran - 1) & 1;
+        s_term = 0x7fffffff;
+    }
+    __syncthreads();
+    const RelaySeg *e = s_buf ? e1 : e0;
+    for (int i = threadIdx.x; i < G; i += 1024)
+        if (e[i].flags & RELAY_EXHAUSTED) atomicMin(&s_term, i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ClockState s;
+        const int k = s_term;
+        if (k >= G) {
+            res->ok = 0;
+            res->n_symbols = 0;
+            res->terminal_chain = -1;
+            s = carried_in[0];
+        } else {
+            res->ok = 1;
+            res->terminal_chain = k;
+            res->n_symbols = (unsigned long long)k * (unsigned long long)Lseg + (unsigned long long)e[k].n_done;
+            s = e[k].s;
+        }
+        long long ii = s.ii;
+        if (ii > N) ii = N;
+        if (ii < 0) ii = 0;
+        res->ii_final = ii;
+        s_ii = ii;
+        s.ii = 0;
+        carried_out[0] = s;
+    }
+    __syncthreads();
+    const long long ii = s_ii;
+    const long long carry = N - ii;
+    if (threadIdx.x < carry) tail_out[threadIdx.x] = x[ii + threadIdx.x];
+}
+
+// predictor entries: every symbol of every segment, and what the walkers' prefetch reads beyond the last one
+size_t ClockStage::trace_len() const { return (size_t)job.G * job.cps * NS + 1024; }
+
+int ClockStage::relay_limit() const
+{
+    // a pass moves the exact front by at least one segment: G + 1 passes always close
+    const int hard = job.G + 1;
+    return exact > 1 ? (exact < hard ? exact : hard) : hard;
+}
+
+// `restart`: first batch of a call (or the tiled evaluation was redone): nothing has been walked.  Every batch ends
+// with the finalize kernel and the copy of the control block.
+int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof)
+{
+    Job &j = job;
+    const int limit = relay_limit();
+    const size_t nsym = trace_len();
+    RelaySeg *segs = relay.as<RelaySeg>();
+    unsigned *changed = reinterpret_cast<unsigned *>(segs + 3 * (size_t)j.G);
+    RelayArgs a{};
+    a.x = xbase(); a.table = table.as<float>(); a.N = j.N; a.ni = j.ni;
+    a.first = st.as<ClockState>() + cur; a.S = S.as<ClockState>();
+    a.K = j.K; a.cps = j.cps; a.NS = NS; a.G = j.G;
+    a.start = segs; a.ends[0] = segs + j.G; a.ends[1] = segs + 2 * (size_t)j.G;
+    a.tr_ii = trace.as<int>(); a.tr_mu = trace.as<float>() + nsym; a.tr_om = trace.as<float>() + 2 * nsym;
+    a.soft = j.soft; a.sym = j.sym; a.cap = (unsigned long long)j.cap; a.par = par;
+    a.changed = changed; a.ctl = clock_ctl(counters);
+    if (restart) {
+        j.relay_enq = 0;
+        const int words = 4 * (limit + 2) > j.G ? 4 * (limit + 2) : j.G;
+        hipLaunchKernelGGL(clock_relay_init_kernel, dim3(div_up((size_t)words, 256)), dim3(256), 0, s, segs, j.G, changed,
+                           limit + 2, clock_ctl(counters));
+    }
+    // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
+    const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
+    const bool lds_walk = span + 8 <= RELAY_RX - RELAY_XCH - 64 && !relay_global;
+    {
+        ProfScope ps(prof, "clock_relay", s);
+        for (int q = 0; q < count && j.relay_enq < limit; ++q, ++j.relay_enq) {
+            if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_lds_kernel<true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+            else if (lds_walk) hipLaunchKernelGGL((clock_relay_lds_kernel<false>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+            else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq);
+            else hipLaunchKernelGGL((clock_relay_kernel<false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq);
+        }
+        hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(1024), 0, s, a.ends[0], a.ends[1], changed,
+                           j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
+                           clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters));
+    }
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return XRIT_OK;
 }
 
 int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
@@ -1064,18 +1196,23 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         ProfScope ps(prof, "clock_output", s);
         // (the first output pass of a call finds the marker set by clock_reset_kernel)
         if (again) hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
-#define XR_CLK_OUT_S(WPV, NCM, SYMV)                                                                                  \
+        const size_t nsym = trace_len();
+        const ClockTrace tr = exact ? ClockTrace{trace.as<int>(), trace.as<float>() + nsym, trace.as<float>() + 2 * nsym}
+                                    : ClockTrace{nullptr, nullptr, nullptr};
+#define XR_CLK_OUT_S(WPV, NCM, SYMV, TRV)                                                                             \
     do {                                                                                                              \
-        clock_allow_lds(clock_output_kernel<WPV, NCM, SYMV>, j.tile_bytes);                                           \
-        hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),            \
+        clock_allow_lds(clock_output_kernel<WPV, NCM, SYMV, TRV>, j.tile_bytes);                                      \
+        hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV, TRV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),       \
                            j.tile_bytes, s, x, table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts,   \
                            j.soft, j.sym, (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W,  \
-                           j.WS, j.A, j.STEP);                                                                        \
+                           j.WS, j.A, j.STEP, tr);                                                                    \
     } while (0)
-#define XR_CLK_OUT(WPV, NCM)                              \
-    do {                                                  \
-        if (j.sym) XR_CLK_OUT_S(WPV, NCM, true);          \
-        else XR_CLK_OUT_S(WPV, NCM, false);               \
+#define XR_CLK_OUT(WPV, NCM)                                        \
+    do {                                                            \
+        if (exact && j.sym) XR_CLK_OUT_S(WPV, NCM, true, true);     \
+        else if (exact) XR_CLK_OUT_S(WPV, NCM, false, true);        \
+        else if (j.sym) XR_CLK_OUT_S(WPV, NCM, true, false);        \
+        else XR_CLK_OUT_S(WPV, NCM, false, false);                  \
     } while (0)
         const bool narrow = (j.STEP >> 16) + 1 <= 20;
         if (!j.wide && narrow) XR_CLK_OUT(32, 20);
@@ -1212,6 +1349,18 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         j.gated = force_gated;
         j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !getenv("XRIT_NO_MEANJ");
     }
+    if (exact) {
+        // segments of the exact closure: 3 per CU (what its LDS holds of the staged walk) unless a window is given; the trace holds one predictor entry per
+        // symbol of every chain, the relay buffer three segment records per segment and one counter per pass
+        int cps = relay_window > 0 ? relay_window : (K + 3 * cu_count - 1) / (3 * cu_count);
+        if (cps < 1) cps = 1;
+        j.cps = cps;
+        j.G = (K + cps - 1) / cps;
+        XR_TRY(trace.reserve(trace_len() * 3 * sizeof(float)));
+        XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)relay_limit() + 8) * 4 * sizeof(unsigned)));
+        relay_segments = j.G;
+        relay_seg_chains = cps;
+    }
     j.dirty = flags.as<int>();
     j.counts = flags.as<int>() + K;
     j.nrun = flags.as<int>() + 2 * K;
@@ -1239,7 +1388,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
     }
-    return enqueue_output(s, prof);
+    XR_TRY(enqueue_output(s, prof));
+    if (exact && K > 1) XR_TRY(enqueue_relay(relay_batch, true, s, prof));
+    return XRIT_OK;
 }
 
 bool ClockStage::closed() const
@@ -1270,7 +1421,30 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             XR_HIP(hipStreamSynchronize(s));
         }
         XR_TRY(enqueue_output(s, prof, true));
+        if (exact && job.K > 1) XR_TRY(enqueue_relay(relay_batch, true, s, prof));
         XR_HIP(hipStreamSynchronize(s));
+    }
+    relay_passes = 0;
+    relay_closed = false;
+    if (exact && job.K > 1) {
+        // the relay goes on until a pass changes nothing (or the pass budget of a partial closure is used up)
+        while (hctl[11] == 0 && job.relay_enq < relay_limit()) {
+            XR_TRY(enqueue_relay(relay_batch < 32 ? 32 : relay_batch, false, s, prof));
+            XR_HIP(hipStreamSynchronize(s));
+        }
+        relay_passes = hctl[10];
+        relay_closed = hctl[11] != 0;
+        if (trace_env) {
+            std::vector<unsigned> hc((size_t)relay_passes * 4);
+            const unsigned *changed = reinterpret_cast<const unsigned *>(relay.as<RelaySeg>() + 3 * (size_t)job.G);
+            XR_HIP(hipMemcpy(hc.data(), changed, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (int p = 0; p < relay_passes; ++p)
+                fprintf(stderr, "[xrit] relay pass %d: segments walked %u of %d, iterations %u, symbols %u (%.1f per iteration); slowest: %u iterations (segment %u)\n", p,
+                        hc[4 * p], job.G, hc[4 * p + 1], hc[4 * p + 2], hc[4 * p + 1] ? (double)hc[4 * p + 2] / hc[4 * p + 1] : 0.0,
+                        hc[4 * p + 3] >> 12, hc[4 * p + 3] & 0xfff);
+        }
+        const int want = relay_passes + relay_passes / 4 + 8;
+        relay_batch = want < 32 ? 32 : (want > 4096 ? 4096 : want);
     }
     passes = job.K > 1 ? hctl[1] : 0;
     if (job.K > 1) {
@@ -1294,7 +1468,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     unconverged = job.K > 1 ? (unsigned)hctl[2] : 0;
     large_open = job.K > 1 ? (unsigned)hctl[9] : 0;
     memcpy(&max_residual, &hctl[3], sizeof(float));
-    if (getenv("XRIT_TRACE") && job.K > 1) {
+    if (trace_env && job.K > 1) {
         std::vector<unsigned> hc((size_t)passes * 8);
         XR_HIP(hipMemcpy(hc.data(), clock_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (int p = 0; p < passes; ++p) {

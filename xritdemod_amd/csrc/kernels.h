@@ -199,10 +199,25 @@ struct ClockStage {
         bool gated = false;     // this call has gone over to the gated solve
         bool rescued = false;   // the serial walk has been tried
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
+        int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
     } job;
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int last_passes = -1;
                             // (5-6 in steady state)
+    // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
+    // serial trajectory is reproduced bit for bit
+    int exact = 0;              // 0: off; 1: relay until closed; n > 1: at most n relay passes (partial closure)
+    int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
+    DevBuf relay, trace;        // segment records + per-pass counters; per-symbol predictor (ii, mu, omega)
+    int relay_batch = 96;       // relay passes enqueued before the host looks
+    int relay_passes = 0;       // relay passes the last call ran (the closing, change-free one included)
+    bool relay_closed = false;  // ... and whether they reproduced the serial trajectory
+    int relay_segments = 0, relay_seg_chains = 0;
+    bool trace_env = false;     // XRIT_TRACE=1 (read at init): per-pass statistics on stderr
+    bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
+    int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
+    int relay_limit() const;
+    size_t trace_len() const;
 };
 
 // ---- helpers ---------------------------------------------------------------

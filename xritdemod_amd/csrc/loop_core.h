@@ -208,19 +208,25 @@ struct ClockState {
     } while (0)
 #endif
 
-// One symbol.  w points at the 8-sample window x[ii .. ii+7] (global memory or an
-// LDS copy of it), table at the 129x8 MMSE taps.
+// The step in two halves, so that a kernel which gets a symbol's history from somewhere else (clock_relay.h:
+// the two previous symbols sit in neighbouring lanes) runs the very same float operations.
+// First half: the interpolated sample at (window, mu).
 template <typename TableT>
-XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
+XR_HD cf32 clock_interp(const cf32 *w, const TableT *table, float mu_now, int *arm_out = nullptr)
 {
-    cf32 p2 = s.p1, p1 = s.p0;
-    cf32 c2 = s.c1, c1 = s.c0;
-    int imu = (int)rintf(s.mu * (float)XR_MM_NSTEPS);
+    int imu = (int)rintf(mu_now * (float)XR_MM_NSTEPS);
     if (arm_out) *arm_out = imu;
     const TableT *row = table + imu * XR_MM_NTAPS;
     float ar = 0.0f, ai = 0.0f;
     XR_MM_INTERPOLATE(row, w, ar, ai);
-    cf32 p0{ar, ai};
+    return cf32{ar, ai};
+}
+
+// Second half: timing error from (p0, the history in s), loop filters, advance.  s.ii moves by floor(mu).
+XR_HD void clock_update(const cf32 p0, ClockState &s, const ClockPar &par)
+{
+    cf32 p2 = s.p1, p1 = s.p0;
+    cf32 c2 = s.c1, c1 = s.c0;
     cf32 c0{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
     float dcr = c0.x - c2.x, dci = c0.y - c2.y;
     float xr = dcr * p1.x + dci * p1.y;
@@ -237,6 +243,15 @@ XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const
     s.omega = omega;
     s.p1 = p1; s.p0 = p0;
     s.c1 = c1; s.c0 = c0;
+}
+
+// One symbol.  w points at the 8-sample window x[ii .. ii+7] (global memory or an
+// LDS copy of it), table at the 129x8 MMSE taps.
+template <typename TableT>
+XR_HD cf32 clock_step_w(const cf32 *w, const TableT *table, ClockState &s, const ClockPar &par, int *arm_out = nullptr)
+{
+    const cf32 p0 = clock_interp(w, table, s.mu, arm_out);
+    clock_update(p0, s, par);
     return p0;
 }
 
