@@ -467,14 +467,11 @@ namespace xrit {
 __device__ __forceinline__ void clock_put(cf32 &d, const cf32 &p) { d = p; }
 __device__ __forceinline__ void clock_put(float &d, const cf32 &p) { d = p.x; }
 
-// trow (output pass of the exact mode): the state in front of every symbol, 3 words per symbol (ii, mu, omega)
-struct ClockTraceRow { int ii[4]; float mu[4], om[4]; };
-
 template <int WP, bool OUT, typename OutT>
 __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *__restrict__ x, int WS, int lane,
                                               int origin, int cum, int lim, int SS, int A, long long ni,
                                               const ClockPar &par, ClockState &s, int &off, bool &alive,
-                                              int &produced, OutT *orow, ClockTraceRow *trow = nullptr)
+                                              int &produced, OutT *orow)
 {
     const int rel = off - cum;
     const bool safe = !alive || (lim == SS && rel >= 0 && rel + A + XR_MM_NTAPS <= WP &&
@@ -487,13 +484,11 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
                 // register renaming instead of a dozen moves per symbol
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (OUT && trow) { trow->ii[i] = origin + off; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                     cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
                     if (OUT) clock_put(orow[i], p);
                 }
             } else {
                 for (int i = 0; i < SS; ++i) {
-                    if (OUT && trow) { trow->ii[i] = origin + off; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                     cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
                     if (OUT) clock_put(orow[i], p);
                 }
@@ -505,7 +500,6 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
         for (int i = 0; i < lim; ++i) {
             if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
             if (alive) {
-                if (OUT && trow) { trow->ii[i] = (int)s.ii; trow->mu[i] = s.mu; trow->om[i] = s.omega; }
                 cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
                 if (OUT) clock_put(orow[i], p);
                 ++produced;
@@ -689,16 +683,14 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
 // output pass: base trajectories only; symbol i of chain k goes to k*NS + i.  A lane's symbols of one sub-step
 // leave as one 16-byte store (soft) -- consecutive sub-steps fill the rest of the 128-byte line, which the L2 holds
 // until then (the lines in flight, 64 chains x 128 B per wave, fit it many times over).
-struct ClockTrace { int *ii; float *mu, *om; };
-
-template <int WP, int NCM, bool SYM, bool TRACE = false>
+template <int WP, int NCM, bool SYM>
 __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                           const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                           int *__restrict__ counts, float *__restrict__ soft,
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
                                                           long long ni, int K, int NS, ClockPar par,
                                                           int *__restrict__ terminal, int SS, int W, int WS, int A,
-                                                          int STEP, ClockTrace tr = ClockTrace{nullptr, nullptr, nullptr})
+                                                          int STEP)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ngroups = (int)(blockDim.x >> 6), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -725,17 +717,10 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
         for (int i = 0; i < 4; ++i) ps[i] = cf32{0.f, 0.f};
         const int before = produced;
         // (sub-steps have at most 4 symbols, see ClockStage::begin)
-        ClockTraceRow trow;
         clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                produced, ps, TRACE ? &trow : nullptr);
+                                produced, ps);
         const int nv = produced - before;          // symbols of this sub-step that exist
         const unsigned long long o = obase + (unsigned long long)j * SS;
-        if (TRACE) {
-            // (the trace is a predictor for clock_relay_kernel, sized for every chain: no capacity test)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nv) { tr.ii[o + i] = trow.ii[i]; tr.mu[o + i] = trow.mu[i]; tr.om[o + i] = trow.om[i]; }
-        }
         if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < cap) {
             if (soft && !XR_NOSTORE) *reinterpret_cast<float4 *>(soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
             if (SYM && sym) {
@@ -981,7 +966,7 @@ void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
-    relay.release(); trace.release();
+    relay.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -1078,9 +1063,6 @@ __global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelayS
     if (threadIdx.x < carry) tail_out[threadIdx.x] = x[ii + threadIdx.x];
 }
 
-// predictor entries: every symbol of every segment, and what the walkers' prefetch reads beyond the last one
-size_t ClockStage::trace_len() const { return (size_t)job.G * job.cps * NS + 1024; }
-
 int ClockStage::relay_limit() const
 {
     // a pass moves the exact front by at least one segment: G + 1 passes always close
@@ -1094,7 +1076,6 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
 {
     Job &j = job;
     const int limit = relay_limit();
-    const size_t nsym = trace_len();
     RelaySeg *segs = relay.as<RelaySeg>();
     unsigned *changed = reinterpret_cast<unsigned *>(segs + 3 * (size_t)j.G);
     RelayArgs a{};
@@ -1102,7 +1083,15 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     a.first = st.as<ClockState>() + cur; a.S = S.as<ClockState>();
     a.K = j.K; a.cps = j.cps; a.NS = NS; a.G = j.G;
     a.start = segs; a.ends[0] = segs + j.G; a.ends[1] = segs + 2 * (size_t)j.G;
-    a.tr_ii = trace.as<int>(); a.tr_mu = trace.as<float>() + nsym; a.tr_om = trace.as<float>() + 2 * nsym;
+    // steps of the float32 lattice omega and mu + omega live on, in units of 2^-24 sample (the walkers' integer model)
+    {
+        const float om = par.omega_mid, su = par.omega_mid + 0.5f;
+        const double u = 1.0 / 16777216.0;
+        a.q_om = (int)((double)(nextafterf(om, INFINITY) - om) / u);
+        a.q_mu = (int)((double)(nextafterf(su, INFINITY) - su) / u);
+        if (a.q_om < 1) a.q_om = 1;
+        if (a.q_mu < 1) a.q_mu = 1;
+    }
     a.soft = j.soft; a.sym = j.sym; a.cap = (unsigned long long)j.cap; a.par = par;
     a.changed = changed; a.ctl = clock_ctl(counters);
     if (restart) {
@@ -1113,14 +1102,14 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     }
     // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
     const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
-    const bool lds_walk = span + 8 <= RELAY_RX - RELAY_XCH - 64 && !relay_global;
+    const bool lds_walk = span + 8 <= RELAY_RX - RELAY_XCH - 72 && !relay_global;
     {
         ProfScope ps(prof, "clock_relay", s);
         for (int q = 0; q < count && j.relay_enq < limit; ++q, ++j.relay_enq) {
-            if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_lds_kernel<true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
-            else if (lds_walk) hipLaunchKernelGGL((clock_relay_lds_kernel<false>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
-            else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq);
-            else hipLaunchKernelGGL((clock_relay_kernel<false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq);
+            if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+            else if (lds_walk) hipLaunchKernelGGL((clock_relay_kernel<false, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+            else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
+            else hipLaunchKernelGGL((clock_relay_kernel<false, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
         }
         hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(1024), 0, s, a.ends[0], a.ends[1], changed,
                            j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
@@ -1196,23 +1185,18 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         ProfScope ps(prof, "clock_output", s);
         // (the first output pass of a call finds the marker set by clock_reset_kernel)
         if (again) hipLaunchKernelGGL(clk_fill_int_kernel, dim3(1), dim3(1), 0, s, j.terminal, 0x7fffffff, 1);
-        const size_t nsym = trace_len();
-        const ClockTrace tr = exact ? ClockTrace{trace.as<int>(), trace.as<float>() + nsym, trace.as<float>() + 2 * nsym}
-                                    : ClockTrace{nullptr, nullptr, nullptr};
-#define XR_CLK_OUT_S(WPV, NCM, SYMV, TRV)                                                                             \
+#define XR_CLK_OUT_S(WPV, NCM, SYMV)                                                                                  \
     do {                                                                                                              \
-        clock_allow_lds(clock_output_kernel<WPV, NCM, SYMV, TRV>, j.tile_bytes);                                      \
-        hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV, TRV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),       \
+        clock_allow_lds(clock_output_kernel<WPV, NCM, SYMV>, j.tile_bytes);                                           \
+        hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),            \
                            j.tile_bytes, s, x, table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts,   \
                            j.soft, j.sym, (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W,  \
-                           j.WS, j.A, j.STEP, tr);                                                                    \
+                           j.WS, j.A, j.STEP);                                                                        \
     } while (0)
-#define XR_CLK_OUT(WPV, NCM)                                        \
-    do {                                                            \
-        if (exact && j.sym) XR_CLK_OUT_S(WPV, NCM, true, true);     \
-        else if (exact) XR_CLK_OUT_S(WPV, NCM, false, true);        \
-        else if (j.sym) XR_CLK_OUT_S(WPV, NCM, true, false);        \
-        else XR_CLK_OUT_S(WPV, NCM, false, false);                  \
+#define XR_CLK_OUT(WPV, NCM)                              \
+    do {                                                  \
+        if (j.sym) XR_CLK_OUT_S(WPV, NCM, true);          \
+        else XR_CLK_OUT_S(WPV, NCM, false);               \
     } while (0)
         const bool narrow = (j.STEP >> 16) + 1 <= 20;
         if (!j.wide && narrow) XR_CLK_OUT(32, 20);
@@ -1350,13 +1334,12 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !getenv("XRIT_NO_MEANJ");
     }
     if (exact) {
-        // segments of the exact closure: 3 per CU (what its LDS holds of the staged walk) unless a window is given; the trace holds one predictor entry per
-        // symbol of every chain, the relay buffer three segment records per segment and one counter per pass
+        // segments of the exact closure: 3 per CU (what its LDS holds of the staged walk) unless a window is given; the relay
+        // buffer holds three segment records per segment and four counters per pass
         int cps = relay_window > 0 ? relay_window : (K + 3 * cu_count - 1) / (3 * cu_count);
         if (cps < 1) cps = 1;
         j.cps = cps;
         j.G = (K + cps - 1) / cps;
-        XR_TRY(trace.reserve(trace_len() * 3 * sizeof(float)));
         XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)relay_limit() + 8) * 4 * sizeof(unsigned)));
         relay_segments = j.G;
         relay_seg_chains = cps;
@@ -1388,9 +1371,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
     }
-    XR_TRY(enqueue_output(s, prof));
-    if (exact && K > 1) XR_TRY(enqueue_relay(relay_batch, true, s, prof));
-    return XRIT_OK;
+    // (exact closure: the first relay pass walks every segment and writes every symbol; there is no output pass)
+    if (exact && K > 1) return enqueue_relay(relay_batch, true, s, prof);
+    return enqueue_output(s, prof);
 }
 
 bool ClockStage::closed() const
@@ -1420,8 +1403,8 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
         }
-        XR_TRY(enqueue_output(s, prof, true));
         if (exact && job.K > 1) XR_TRY(enqueue_relay(relay_batch, true, s, prof));
+        else XR_TRY(enqueue_output(s, prof, true));
         XR_HIP(hipStreamSynchronize(s));
     }
     relay_passes = 0;
@@ -1439,7 +1422,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             const unsigned *changed = reinterpret_cast<const unsigned *>(relay.as<RelaySeg>() + 3 * (size_t)job.G);
             XR_HIP(hipMemcpy(hc.data(), changed, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
             for (int p = 0; p < relay_passes; ++p)
-                fprintf(stderr, "[xrit] relay pass %d: segments walked %u of %d, iterations %u, symbols %u (%.1f per iteration); slowest: %u iterations (segment %u)\n", p,
+                fprintf(stderr, "[xrit] relay pass %d: segments walked %u of %d, steps %u, symbols %u (%.1f per step); slowest: %u steps (segment %u)\n", p,
                         hc[4 * p], job.G, hc[4 * p + 1], hc[4 * p + 2], hc[4 * p + 1] ? (double)hc[4 * p + 2] / hc[4 * p + 1] : 0.0,
                         hc[4 * p + 3] >> 12, hc[4 * p + 3] & 0xfff);
         }

@@ -3,34 +3,38 @@
 // Why the hand-off passes of clock.hip stall at ~1e-4 sample: in float32 the M&M recurrence
 // (ClockRecovery::Work, /root/reference/demodulator/src/demodulator.cpp:156,449) is an integer recurrence on a
 // lattice -- omega and mu move by whole units of 2^-21 sample -- that sees its own state only through the
-// interpolator arm rint(mu * 128).  Two trajectories whose arms agree stay an exact translation of one another for
-// ever (same symbols, same timing errors), and one arm that differs kicks them ~60 units apart; brought together
-// they take ~8e4 symbols (1 % of the pairs: 4e5) to meet bit for bit.  A Newton step that moves 1e5 chain starts by
-// 1e-4 sample flips arms in most chains, so the passes hover; nothing short of walking the recurrence closes it.
+// interpolator arm rint(mu * 128) and the read index.  Two trajectories whose arms agree stay an exact translation
+// of one another for ever (same symbols, same timing errors), and one arm that differs kicks them ~60 units apart;
+// brought together they take ~8e4 symbols (1 % of the pairs: 4e5) to meet bit for bit.  A Newton step that moves
+// 1e5 chain starts by 1e-4 sample flips arms in most chains, so the passes hover; nothing short of walking the
+// recurrence closes it.
 //
-// So it is walked, but 64 symbols per step and in many places at once:
-//  * The call is cut into G segments of `cps` chains.  Every segment is walked EXACTLY -- the literal recurrence,
-//    one wave per segment -- from a start state: the carried state for segment 0, the tiled evaluation's hand-off
-//    state in the first relay pass, and from then on the end state its predecessor reached in the pass before.
-//    A pass in which no segment's start changed has reproduced the serial trajectory: segment 0 starts from the
-//    exact state, so by induction every segment does.  Segments forget their start like any two trajectories do
-//    (bit for bit, after ~1e5 symbols), so the passes needed are ~5e5 symbols / segment length, not G.
-//  * The walk itself is speculative: the wave holds a predictor -- the trajectory this segment took last time (the
-//    tiled evaluation's in the first pass), one (ii, mu, omega) per symbol -- and lane i takes symbol n + i from
-//    the predictor's state translated by the walker's current offset from it.  Every lane does one literal step;
-//    lane i is right if lane i - 1's step ended exactly on lane i's start.  The verified prefix (all 64 symbols
-//    between arm flips, ~1 in 400 symbols once the predictor is itself an exact trajectory) is committed, the
-//    state after it is the walker's new state.  Lane 0 starts from the walker's own state, so a useless predictor
-//    costs speed, never correctness.
-//  * A walker that finds itself ON its predictor (same state for a whole block, and the predictor is this
-//    segment's own earlier exact walk) stops: the rest of the segment is what it already was.
+// So it is walked -- 64 symbols per step, and in many places at once:
+//  * Relay.  The call is cut into G segments of `cps` chains.  Every segment is walked EXACTLY, one wave per
+//    segment, from a start state: the carried state for segment 0, the tiled evaluation's hand-off state in the
+//    first relay pass, and from then on the end state its predecessor reached in the pass before.  A pass in which
+//    no segment's start changed has reproduced the serial trajectory: segment 0 starts from the exact state, so
+//    by induction every segment does.  Trajectories forget their start (bit for bit, see above), so the passes
+//    needed are ~5e5 symbols / segment length, not G; a segment whose start did not change is not walked again.
+//  * The walk, 64 symbols per step.  Given the interpolator arm and read index of every symbol of a block, the
+//    timing errors mm_i are independent of one another (symbol i needs the samples and the interpolated values of
+//    symbols i - 1, i - 2), and (omega, mu) follow from them by ADDITIONS on the lattice: two integer prefix sums
+//    over the wave.  So lane i guesses where symbol n + i sits (first from the nominal rate), interpolates,
+//    forms mm_i; the sums give every lane its state; a lane whose arm or index came out different interpolates
+//    again (two or three rounds settle all 64 -- a wrong arm moves mm by 1e-3, mu by 4e-6).  Then every lane runs
+//    the LITERAL float32 step from its state and compares the result with its neighbour's state, bit for bit:
+//    the verified prefix is committed.  The integer model is only a guess generator -- ties, the omega clip, a
+//    binade boundary make it differ from the float arithmetic, the comparison then ends the block early and the
+//    next block starts from the literal result.  Lane 0 always starts from the walker's own state.
+//  * The samples are streamed into an LDS ring by a second wave of the workgroup that runs ahead of the walker
+//    (the walker itself reads LDS only and issues stores nobody waits for).
 #pragma once
 
 #include "kernels.h"
 
 namespace xrit {
 
-constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exactly from start[].s (tr[] holds that walk)
+constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exactly from start[].s
 constexpr int RELAY_EXHAUSTED = 2;   // ends[]: the input ran out inside this segment (n_done symbols exist)
 constexpr int RELAY_DEAD = 4;        // the input ran out before this segment
 
@@ -51,13 +55,13 @@ struct RelayArgs {
     int K, cps, NS, G;
     RelaySeg *start;              // [G] what each segment was last walked from
     RelaySeg *ends[2];            // [G] end states, ping-pong between passes
-    int *tr_ii;                   // per symbol: the state in front of it (predictor, rewritten by every walk)
-    float *tr_mu, *tr_om;
     float *soft;
     float2 *sym;
     unsigned long long cap;
     ClockPar par;
-    unsigned *changed;            // [4 * pass] segments whose start changed in that pass, [+1] iterations, [+2] symbols walked
+    int q_om, q_mu;               // lattice steps of omega and of mu + omega, in units of 2^-24 sample
+    unsigned *changed;            // [4 * pass] segments whose start changed in that pass, [+1] steps, [+2] symbols walked,
+                                  // [+3] slowest walker (steps << 12 | segment) or a watchdog mark
     const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed
 };
 
@@ -68,182 +72,34 @@ __device__ __forceinline__ bool relay_same_state(const ClockState &a, const Cloc
            a.c1.y == b.c1.y;
 }
 
-__device__ __forceinline__ cf32 relay_shfl(const cf32 &v, int src)
+// ---- wave helpers (DPP: no LDS round trip) ---------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ int relay_dpp(int v)
 {
-    return cf32{__shfl(v.x, src, 64), __shfl(v.y, src, 64)};
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);      // lanes without a source lane get 0
 }
-
-// predictor entry (bii, bmu, bom) moved by dm units of 2^-24 sample in time and dw units in omega
-__device__ __forceinline__ void relay_translate(int bii, float bmu, float bom, int dm, int dw, int &ii, float &mu, float &om)
-{
-    const int m = (int)(bmu * 16777216.0f) + dm;
-    ii = bii + (m >> 24);
-    mu = (float)(m & 0xffffff) * (1.0f / 16777216.0f);
-    om = bom + (float)dw * (1.0f / 16777216.0f);
-}
-
-template <bool SYM>
-__global__ void __launch_bounds__(64) clock_relay_kernel(RelayArgs a, int pass)
-{
-    if (!a.ctl[0]) return;                                   // the tiled hand-off has not closed: nothing to refine yet
-    if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;        // closed in an earlier pass
-    __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    clock_table_to_lds(table, a.table);
-    __syncthreads();
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const RelaySeg *ein = a.ends[(pass + 1) & 1];
-    RelaySeg *eout = a.ends[pass & 1];
-    const int Lseg = a.cps * a.NS;
-    const long long obase = (long long)s * Lseg;
-
-    ClockState T{};
-    bool dead = false;
-    if (s == 0) T = a.first[0];
-    else if (pass == 0) {
-        const int k = s * a.cps;
-        if (k < a.K) T = a.S[k];
-        else dead = true;
-    } else {
-        const RelaySeg e = ein[s - 1];
-        T = e.s;
-        dead = (e.flags & (RELAY_EXHAUSTED | RELAY_DEAD)) != 0;
-    }
-    const RelaySeg prev = a.start[s];
-    if (dead) {
-        if (pass > 0 && (prev.flags & RELAY_DEAD)) { if (lane == 0) eout[s] = ein[s]; return; }
-        if (lane == 0) {
-            RelaySeg e{};
-            e.flags = RELAY_DEAD;
-            eout[s] = e;
-            a.start[s] = e;
-            atomicAdd(&a.changed[4 * pass], 1u);
-        }
-        return;
-    }
-    const bool have_exact = pass > 0 && (prev.flags & RELAY_WALKED) != 0;
-    if (have_exact && relay_same_state(prev.s, T)) { if (lane == 0) eout[s] = ein[s]; return; }
-    if (lane == 0) atomicAdd(&a.changed[4 * pass], 1u);
-    const ClockState T0 = T;
-
-    const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
-    int n = 0;
-    unsigned iters = 0;
-    bool exhausted = false, merged = false;
-    while (n < Lseg) {
-        ++iters;
-        const long long idx = obase + n + lane;
-        const int bii = a.tr_ii[idx], bii1 = a.tr_ii[idx + 1];
-        const float bmu = a.tr_mu[idx], bmu1 = a.tr_mu[idx + 1];
-        const float bom = a.tr_om[idx], bom1 = a.tr_om[idx + 1];
-        const int bii0 = __shfl(bii, 0, 64);
-        const float bmu0 = __shfl(bmu, 0, 64), bom0 = __shfl(bom, 0, 64);
-        const long long dii = T.ii - (long long)bii0;
-        const bool usable = dii > -32 && dii < 32 && fabsf(T.omega - bom0) < 1e-3f;
-        const int dm = usable ? (int)dii * 16777216 + ((int)(T.mu * 16777216.0f) - (int)(bmu0 * 16777216.0f)) : 0;
-        const int dw = usable ? (int)((T.omega - bom0) * 16777216.0f) : 0;
-        const bool on_predictor = T.ii == (long long)bii0 && T.mu == bmu0 && T.omega == bom0;
-        // this lane's start (the state in front of symbol n + lane) and the start of the symbol after it
-        int cii, cii1;
-        float cmu, com, cmu1, com1;
-        relay_translate(bii, bmu, bom, dm + lane * dw, dw, cii, cmu, com);
-        relay_translate(bii1, bmu1, bom1, dm + (lane + 1) * dw, dw, cii1, cmu1, com1);
-        if (lane == 0) { cii = (int)T.ii; cmu = T.mu; com = T.omega; }
-        const bool exists = cii >= 0 && (long long)cii < a.ni;
-        long long wi = cii;
-        wi = wi < 0 ? 0 : (wi >= a.ni ? a.ni - 1 : wi);
-        cf32 w[XR_MM_NTAPS];
-#pragma unroll
-        for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xs[wi + q];
-        const cf32 p0 = clock_interp(w, table, cmu);
-        // history: the two symbols in front of this one sit in the lanes below (the walker's own for lanes 0, 1)
-        ClockState st;
-        st.ii = cii; st.mu = cmu; st.omega = com;
-        cf32 h0 = cf32{__shfl_up(p0.x, 1, 64), __shfl_up(p0.y, 1, 64)};
-        cf32 h1 = cf32{__shfl_up(p0.x, 2, 64), __shfl_up(p0.y, 2, 64)};
-        st.p0 = h0; st.p1 = h1;
-        st.c0 = cf32{h0.x > 0.f ? 1.f : 0.f, h0.y > 0.f ? 1.f : 0.f};
-        st.c1 = cf32{h1.x > 0.f ? 1.f : 0.f, h1.y > 0.f ? 1.f : 0.f};
-        if (lane == 0) { st.p0 = T.p0; st.p1 = T.p1; st.c0 = T.c0; st.c1 = T.c1; }
-        if (lane == 1) { st.p1 = T.p0; st.c1 = T.c0; }
-        clock_update(p0, st, a.par);
-        const bool ok = exists && st.ii == (long long)cii1 && st.mu == cmu1 && st.omega == com1;
-        const unsigned long long okm = __ballot(ok), exm = __ballot(exists);
-        const int m = ~okm ? __builtin_ctzll(~okm) : 64;        // lanes 0 .. m start from verified states
-        const int e = ~exm ? __builtin_ctzll(~exm) : 64;        // first lane whose symbol does not exist
-        int nv = m + 1 < 64 ? m + 1 : 64;
-        const int lim = Lseg - n;
-        nv = nv < lim ? nv : lim;
-        if (e < nv) { nv = e; exhausted = true; }
-        if (lane < nv) {
-            const unsigned long long o = (unsigned long long)idx;
-            if (o < a.cap) {
-                if (a.soft) a.soft[o] = p0.x;
-                if (SYM && a.sym) a.sym[o] = make_float2(p0.x, p0.y);
-            }
-            a.tr_ii[idx] = cii; a.tr_mu[idx] = cmu; a.tr_om[idx] = com;
-        }
-        if (nv > 0) {
-            const int src = nv - 1;
-            ClockState nt;
-            nt.ii = __shfl((int)st.ii, src, 64);
-            nt.mu = __shfl(st.mu, src, 64);
-            nt.omega = __shfl(st.omega, src, 64);
-            nt.p0 = relay_shfl(st.p0, src); nt.p1 = relay_shfl(st.p1, src);
-            nt.c0 = relay_shfl(st.c0, src); nt.c1 = relay_shfl(st.c1, src);
-            T = nt;
-            n += nv;
-        }
-        if (exhausted || nv == 0) { exhausted = true; break; }
-        // a whole block walked on the predictor, and the predictor is this segment's own exact walk from another
-        // start: from here on the two are one trajectory
-        if (have_exact && on_predictor && nv == 64 && n < Lseg) { merged = true; break; }
-    }
-    if (lane == 0) {
-        atomicAdd(&a.changed[4 * pass + 1], iters);
-        atomicAdd(&a.changed[4 * pass + 2], (unsigned)n);
-        RelaySeg st0{};
-        st0.s = T0;
-        st0.flags = RELAY_WALKED;
-        a.start[s] = st0;
-        if (merged) eout[s] = ein[s];
-        else {
-            RelaySeg e{};
-            e.s = T;
-            e.n_done = n;
-            e.flags = exhausted ? RELAY_EXHAUSTED : 0;
-            eout[s] = e;
-        }
-    }
-}
-
-
-// ---- the same walk with its inputs staged in LDS ---------------------------------------------------------------
-// An iteration of the kernel above waits for two dependent global loads (predictor entry, then the sample window it
-// points at) that miss every cache and most of the TLB -- 1021 walkers stride through five arrays --: ~4 us against
-// ~0.3 us of arithmetic (measured: 10 k iterations of the slowest walker, 44 ms per 256 Mi-sample burst).  Here a
-// workgroup is two waves: wave 1 does nothing but stream the samples and the predictor entries ahead of the
-// walker's position into two LDS rings (about ten iterations ahead), wave 0 walks and never waits for memory -- it
-// reads LDS and issues stores nobody waits for.  The two talk through four words of LDS.
-// span = samples a block of 64 symbols can cover (<= RELAY_RX - RELAY_XCH - 8).
-constexpr int RELAY_RX = 4096;       // sample ring
-constexpr int RELAY_XCH = 1024;      // samples per refill (16 per lane)
-constexpr int RELAY_RT = 1024;       // predictor ring
-constexpr int RELAY_TCH = 256;       // entries per refill (4 per lane)
-
-__device__ __forceinline__ float relay_shr1(float v)
-{
-    // lane i <- lane i - 1 across the whole wave (DPP wave_shr:1), no LDS round trip
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
+__device__ __forceinline__ float relay_shr1(float v) { return __int_as_float(relay_dpp<0x138>(__float_as_int(v))); }   // lane i <- i - 1
+__device__ __forceinline__ float relay_shl1(float v) { return __int_as_float(relay_dpp<0x130>(__float_as_int(v))); }   // lane i <- i + 1
 __device__ __forceinline__ float relay_lane(float v, int src)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
-// The hand-shake words live in LDS and order LDS traffic only.  A wave's DS operations are executed in the order
-// it issued them and the LDS serves one CU, so all that is needed is that the COMPILER keeps the order.  Release /
-// acquire atomics (also with the "local" fence scope) and volatile accesses both make this compiler wait for the
-// wave's outstanding global stores (s_waitcnt vmcnt(0)) at every publish -- measured: 2.5 us per iteration, the whole
-// gain of the staging -- hence the two instructions by hand, each a compiler barrier.
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int relay_scan(int v, int lane)
+{
+    v += relay_dpp<0x111>(v);       // row_shr:1 .. 8 inside every row of 16
+    v += relay_dpp<0x112>(v);
+    v += relay_dpp<0x114>(v);
+    v += relay_dpp<0x118>(v);
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+
+// The hand-shake words between the two waves live in LDS and order LDS traffic only.  A wave's DS operations are
+// executed in the order it issued them and the LDS serves one CU, so all that is needed is that the COMPILER keeps
+// the order.  Release / acquire atomics (also with the "local" fence scope) and volatile accesses both make this
+// compiler wait for the wave's outstanding global stores (s_waitcnt vmcnt(0)) at every publish -- measured: 2.5 us
+// per step -- hence the two instructions by hand, each a compiler barrier.
 __device__ __forceinline__ unsigned relay_lds_addr(const void *p)
 {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char *)p;
@@ -259,20 +115,24 @@ __device__ __forceinline__ void relay_st(int *p, int v)
     asm volatile("ds_write_b32 %0, %1" : : "v"(relay_lds_addr(p)), "v"(v) : "memory");
 }
 
-template <bool SYM>
-__global__ void __launch_bounds__(128) clock_relay_lds_kernel(RelayArgs a, int pass, int span)
+constexpr int RELAY_RX = 4096;       // sample ring (RING): about ten steps of lead for the prefetching wave
+constexpr int RELAY_XCH = 1024;      // samples per refill (16 per lane)
+constexpr int RELAY_ROUNDS = 4;      // guess rounds per step at most
+
+// RING: two waves per workgroup, samples through the LDS ring (span = samples a block of 64 symbols can cover
+// <= RELAY_RX - RELAY_XCH - 72); else one wave that reads its windows from global memory (any symbol rate).
+template <bool SYM, bool RING>
+__global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs a, int pass, int span)
 {
-    if (!a.ctl[0]) return;
-    if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;
+    if (!a.ctl[0]) return;                                       // the tiled hand-off has not closed: nothing to refine yet
+    if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;      // closed in an earlier pass
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    __shared__ cf32 xr[RELAY_RX];
-    __shared__ int r_ii[RELAY_RT];
-    __shared__ float r_mu[RELAY_RT], r_om[RELAY_RT];
-    __shared__ int sh_xhi, sh_thi, sh_pos_ii, sh_pos_n, sh_done;
+    __shared__ cf32 xr[RING ? RELAY_RX : 1];
+    __shared__ int sh_xhi, sh_pos_ii, sh_done;
     clock_table_to_lds(table, a.table);
     const int s = blockIdx.x, lane = threadIdx.x & 63;
     // (wave-uniform by construction; said so, so that the two roles are two scalar branches and not two exec masks)
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = RING ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const RelaySeg *ein = a.ends[(pass + 1) & 1];
     RelaySeg *eout = a.ends[pass & 1];
     const int Lseg = a.cps * a.NS;
@@ -292,7 +152,7 @@ __global__ void __launch_bounds__(128) clock_relay_lds_kernel(RelayArgs a, int p
     }
     const RelaySeg prev = a.start[s];
     const int x_lo = (int)(T.ii > 4 ? T.ii - 4 : 0);
-    if (threadIdx.x == 0) { sh_xhi = x_lo; sh_thi = 0; sh_pos_ii = (int)T.ii; sh_pos_n = 0; sh_done = 0; }
+    if (threadIdx.x == 0) { sh_xhi = x_lo; sh_pos_ii = (int)T.ii; sh_done = 0; }
     __syncthreads();      // (the only barrier: both waves pass it before either can leave)
     if (dead) {
         if (pass > 0 && (prev.flags & RELAY_DEAD)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
@@ -305,54 +165,30 @@ __global__ void __launch_bounds__(128) clock_relay_lds_kernel(RelayArgs a, int p
         }
         return;
     }
-    const bool have_exact = pass > 0 && (prev.flags & RELAY_WALKED) != 0;
-    if (have_exact && relay_same_state(prev.s, T)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
+    if (pass > 0 && (prev.flags & RELAY_WALKED) && relay_same_state(prev.s, T)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
     const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
 
-    if (role == 1) {
-        // ---- the prefetcher: keeps [position, position + RX - XCH) of the samples and [n, n + RT - TCH) of the
-        // predictor entries in the rings; a slot is overwritten only when the walker's published position is past it
+    if (RING && role == 1) {
+        // ---- the prefetcher: keeps [position, position + RX - XCH) of the samples in the ring; a slot is overwritten
+        // only when the walker's published position is past it
         const long long nlast = a.N > 0 ? a.N - 1 : 0;
-        int x_hi = x_lo, t_hi = 0;
-        const int t_end = Lseg + 65;          // entries the walker can ask for
+        int x_hi = x_lo;
         unsigned rounds = 0;
         while (!relay_ld(&sh_done)) {
-            if (++rounds > (1u << 24)) { if (lane == 0) a.changed[4 * pass + 3] = 0x40000000u | (unsigned)s; break; }
-            const int pii = relay_ld(&sh_pos_ii), pn = relay_ld(&sh_pos_n);
+            if (++rounds > (1u << 24)) { if (lane == 0) a.changed[4 * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
+            const int pii = relay_ld(&sh_pos_ii);
             const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= nlast + RELAY_XCH;
-            const bool ft = t_hi + RELAY_TCH - RELAY_RT <= pn && t_hi < t_end;
-            if (!fx && !ft) { __builtin_amdgcn_s_sleep(4); continue; }
+            if (!fx) { __builtin_amdgcn_s_sleep(4); continue; }
             cf32 vx[RELAY_XCH / 64];
-            int vti[RELAY_TCH / 64];
-            float vtm[RELAY_TCH / 64], vto[RELAY_TCH / 64];
-            if (fx) {
 #pragma unroll
-                for (int q = 0; q < RELAY_XCH / 64; ++q) {
-                    const long long i = (long long)x_hi + lane + 64 * q;
-                    vx[q] = xs[i < nlast ? i : nlast];
-                }
+            for (int q = 0; q < RELAY_XCH / 64; ++q) {
+                const long long i = (long long)x_hi + lane + 64 * q;
+                vx[q] = xs[i < nlast ? i : nlast];
             }
-            if (ft) {
 #pragma unroll
-                for (int q = 0; q < RELAY_TCH / 64; ++q) {
-                    const long long i = obase + t_hi + lane + 64 * q;
-                    vti[q] = a.tr_ii[i]; vtm[q] = a.tr_mu[i]; vto[q] = a.tr_om[i];
-                }
-            }
-            if (fx) {
-#pragma unroll
-                for (int q = 0; q < RELAY_XCH / 64; ++q) xr[(x_hi + lane + 64 * q) & (RELAY_RX - 1)] = vx[q];
-                x_hi += RELAY_XCH;
-            }
-            if (ft) {
-#pragma unroll
-                for (int q = 0; q < RELAY_TCH / 64; ++q) {
-                    const int i = (t_hi + lane + 64 * q) & (RELAY_RT - 1);
-                    r_ii[i] = vti[q]; r_mu[i] = vtm[q]; r_om[i] = vto[q];
-                }
-                t_hi += RELAY_TCH;
-            }
-            if (lane == 0) { relay_st(&sh_xhi, x_hi); relay_st(&sh_thi, t_hi); }
+            for (int q = 0; q < RELAY_XCH / 64; ++q) xr[(x_hi + lane + 64 * q) & (RELAY_RX - 1)] = vx[q];
+            x_hi += RELAY_XCH;
+            if (lane == 0) relay_st(&sh_xhi, x_hi);
         }
         return;
     }
@@ -360,82 +196,108 @@ __global__ void __launch_bounds__(128) clock_relay_lds_kernel(RelayArgs a, int p
     // ---- the walker
     if (lane == 0) atomicAdd(&a.changed[4 * pass], 1u);
     const ClockState T0 = T;
+    const float kw = 16777216.0f / (float)a.q_om, km = 16777216.0f / (float)a.q_mu;
     int n = 0;
-    unsigned iters = 0;
-    bool exhausted = false, merged = false;
+    unsigned steps = 0;
+    bool exhausted = false;
     while (n < Lseg) {
-        ++iters;
-        if (iters > 2u * (unsigned)Lseg + 1000u) { if (lane == 0) a.changed[4 * pass + 3] = 0x20000000u | (unsigned)s; exhausted = true; break; }
+        ++steps;
+        if (steps > 64u * (unsigned)Lseg + 1000u) { if (lane == 0) a.changed[4 * pass + 3] = 0xa0000000u | (unsigned)s; exhausted = true; break; }
         // (a walker that stands beyond the input has nothing to wait for: the prefetcher stops at the end of the input)
         if (T.ii < 0 || T.ii >= a.ni) { exhausted = true; break; }
-        // wait until the rings hold this iteration's inputs (they do, unless memory is slower than ten iterations)
-        const int need_x = (int)T.ii + span + 8, need_t = n + 65;
-        int x_hi = relay_ld(&sh_xhi), t_hi = relay_ld(&sh_thi);
-        int spins = 0;
-        while (x_hi < need_x || t_hi < need_t) {
-            __builtin_amdgcn_s_sleep(2);
-            x_hi = relay_ld(&sh_xhi); t_hi = relay_ld(&sh_thi);
-            if (++spins > (1 << 22)) {       // watchdog (seconds): leave a diagnostic instead of hanging the queue
-                if (lane == 0) {
-                    a.changed[4 * pass + 3] = 0x80000000u | (unsigned)s;
-                }
-                exhausted = true;
-                break;
+        const int need_x = (int)T.ii + span + 8;
+        if (RING) {
+            // wait until the ring holds this step's samples (it does, unless memory is slower than ten steps)
+            int x_hi = relay_ld(&sh_xhi), spins = 0;
+            while (x_hi < need_x) {
+                __builtin_amdgcn_s_sleep(2);
+                x_hi = relay_ld(&sh_xhi);
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[4 * pass + 3] = 0x80000000u | (unsigned)s; exhausted = true; break; }
             }
+            if (exhausted) break;
         }
-        if (exhausted) break;
-        const long long idx = obase + n + lane;
-        const int r0 = (n + lane) & (RELAY_RT - 1), r1 = (n + lane + 1) & (RELAY_RT - 1);
-        const int bii = r_ii[r0], bii1 = r_ii[r1];
-        const float bmu = r_mu[r0], bmu1 = r_mu[r1];
-        const float bom = r_om[r0], bom1 = r_om[r1];
-        const int bii0 = __builtin_amdgcn_readfirstlane(bii);
-        const float bmu0 = relay_lane(bmu, 0), bom0 = relay_lane(bom, 0);
-        const long long dii = T.ii - (long long)bii0;
-        const bool usable = dii > -32 && dii < 32 && fabsf(T.omega - bom0) < 1e-3f;
-        const int dm = usable ? (int)dii * 16777216 + ((int)(T.mu * 16777216.0f) - (int)(bmu0 * 16777216.0f)) : 0;
-        const int dw = usable ? (int)((T.omega - bom0) * 16777216.0f) : 0;
-        const bool on_predictor = T.ii == (long long)bii0 && T.mu == bmu0 && T.omega == bom0;
-        int cii, cii1;
-        float cmu, com, cmu1, com1;
-        relay_translate(bii, bmu, bom, dm + lane * dw, dw, cii, cmu, com);
-        relay_translate(bii1, bmu1, bom1, dm + (lane + 1) * dw, dw, cii1, cmu1, com1);
-        if (lane == 0) { cii = (int)T.ii; cmu = T.mu; com = T.omega; }
-        const bool exists = cii >= 0 && (long long)cii < a.ni;
-        const bool inrange = cii >= (int)T.ii && cii + XR_MM_NTAPS <= need_x;
-        cf32 w[XR_MM_NTAPS];
+        // the walker's state on the lattice; the first guess puts symbol n + lane at the nominal rate
+        const int ii0 = (int)T.ii;
+        const int mu0u = (int)(T.mu * 16777216.0f), W0 = (int)(T.omega * 16777216.0f);
+        const int wint = W0 >> 24, wfrac = W0 & 0xffffff;
+        int cii, uarm = -1;
+        float cmu, com = T.omega;
+        {
+            const int fr = mu0u + lane * wfrac;
+            cii = ii0 + lane * wint + (fr >> 24);
+            cmu = (float)(fr & 0xffffff) * (1.0f / 16777216.0f);
+        }
+        if (lane == 0) cmu = T.mu;
+        cf32 p0{0.f, 0.f};
+        float mm = 0.f;
+        ClockState hs{};               // the history symbol n + lane sees: (p0, p1) of the two symbols in front of it
+        bool stale = false, inrange = true;
+        for (int round = 0; round < RELAY_ROUNDS; ++round) {
+            const int arm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
+            // (re)interpolate where the read index or the arm moved
+            inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
+            cf32 w[XR_MM_NTAPS];
+            if (RING) {
 #pragma unroll
-        for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xr[(cii + q) & (RELAY_RX - 1)];
-        const cf32 p0 = clock_interp(w, table, cmu);
-        ClockState st;
+                for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xr[(cii + q) & (RELAY_RX - 1)];
+            } else {
+                long long wi = cii;
+                wi = wi < 0 ? 0 : (wi >= a.ni ? a.ni - 1 : wi);
+#pragma unroll
+                for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xs[wi + q];
+                inrange = true;
+            }
+            p0 = clock_interp(w, table, cmu);
+            uarm = arm;
+            cf32 h0 = cf32{relay_shr1(p0.x), relay_shr1(p0.y)};
+            cf32 h1 = cf32{relay_shr1(h0.x), relay_shr1(h0.y)};
+            if (lane == 0) { h0 = T.p0; h1 = T.p1; }
+            if (lane == 1) { h1 = T.p0; }
+            hs.p0 = h0; hs.p1 = h1;
+            hs.c0 = cf32{h0.x > 0.f ? 1.f : 0.f, h0.y > 0.f ? 1.f : 0.f};
+            hs.c1 = cf32{h1.x > 0.f ? 1.f : 0.f, h1.y > 0.f ? 1.f : 0.f};
+            if (lane == 0) { hs.c0 = T.c0; hs.c1 = T.c1; }
+            if (lane == 1) { hs.c1 = T.c0; }
+            mm = clock_timing_error(p0, hs);
+            // omega and mu on the lattice: additions of rounded increments, i.e. two prefix sums
+            const int dW = (int)rintf(a.par.gain_omega * mm * kw) * a.q_om;
+            const int dM = (int)rintf(a.par.gain_mu * mm * km) * a.q_mu;
+            const int C = relay_scan(dW, lane);                  // omega after symbol n + lane, minus W0
+            const int E = C + dM;
+            const int D = relay_scan(E, lane) - E;               // position in front of symbol n + lane, minus the nominal one
+            const int fr = mu0u + lane * wfrac + D;
+            int nii = ii0 + lane * wint + (fr >> 24);
+            float nmu = (float)(fr & 0xffffff) * (1.0f / 16777216.0f);
+            float nom = (float)(W0 + C - dW) * (1.0f / 16777216.0f);
+            if (lane == 0) { nii = ii0; nmu = T.mu; nom = T.omega; }
+            stale = nii != cii || (int)rintf(nmu * (float)XR_MM_NSTEPS) != uarm;
+            cii = nii; cmu = nmu; com = nom;
+            if (!__any(stale)) break;
+        }
+        // the literal step from every lane's state, compared with the neighbour's state bit for bit
+        ClockState st = hs;
         st.ii = cii; st.mu = cmu; st.omega = com;
-        cf32 h0 = cf32{relay_shr1(p0.x), relay_shr1(p0.y)};
-        cf32 h1 = cf32{relay_shr1(h0.x), relay_shr1(h0.y)};
-        st.p0 = h0; st.p1 = h1;
-        if (lane == 0) { st.p0 = T.p0; st.p1 = T.p1; }
-        if (lane == 1) { st.p1 = T.p0; }
-        st.c0 = cf32{st.p0.x > 0.f ? 1.f : 0.f, st.p0.y > 0.f ? 1.f : 0.f};
-        st.c1 = cf32{st.p1.x > 0.f ? 1.f : 0.f, st.p1.y > 0.f ? 1.f : 0.f};
-        if (lane == 0) { st.c0 = T.c0; st.c1 = T.c1; }
-        if (lane == 1) { st.c1 = T.c0; }
-        clock_update(p0, st, a.par);
-        const bool ok = exists && st.ii == (long long)cii1 && st.mu == cmu1 && st.omega == com1;
-        const unsigned long long okm = __ballot(ok), exm = __ballot(exists), inm = __ballot(inrange);
-        const int m = ~okm ? __builtin_ctzll(~okm) : 64;
-        const int e = ~exm ? __builtin_ctzll(~exm) : 64;
-        const int b = ~inm ? __builtin_ctzll(~inm) : 64;        // first lane whose window is not in the ring
+        clock_advance(mm, p0, st, a.par);
+        const int nxt_ii = relay_dpp<0x130>(cii);
+        const float nxt_mu = relay_shl1(cmu), nxt_om = relay_shl1(com);
+        const bool exists = cii >= 0 && (long long)cii < a.ni;
+        const bool good = !stale && inrange;                      // this lane's interpolation belongs to its state
+        const bool ok = good && exists && lane < 63 && (int)st.ii == nxt_ii && st.mu == nxt_mu && st.omega == nxt_om;
+        const unsigned long long okm = __ballot(ok), exm = __ballot(exists), gdm = __ballot(good);
+        const int m = ~okm ? __builtin_ctzll(~okm) : 64;         // lanes 0 .. m start from verified states
+        const int e = ~exm ? __builtin_ctzll(~exm) : 64;         // first lane whose symbol does not exist
+        const int g = ~gdm ? __builtin_ctzll(~gdm) : 64;         // first lane whose own step is not to be trusted
         int nv = m + 1 < 64 ? m + 1 : 64;
         const int lim = Lseg - n;
         nv = nv < lim ? nv : lim;
-        nv = nv < b ? nv : b;
+        nv = nv < g ? nv : g;
         if (e < nv) { nv = e; exhausted = true; }
         if (lane < nv) {
-            const unsigned long long o = (unsigned long long)idx;
+            const unsigned long long o = (unsigned long long)(obase + n + lane);
             if (o < a.cap) {
                 if (a.soft) a.soft[o] = p0.x;
                 if (SYM && a.sym) a.sym[o] = make_float2(p0.x, p0.y);
             }
-            a.tr_ii[idx] = cii; a.tr_mu[idx] = cmu; a.tr_om[idx] = com;
         }
         if (nv > 0) {
             const int src = nv - 1;
@@ -449,28 +311,24 @@ __global__ void __launch_bounds__(128) clock_relay_lds_kernel(RelayArgs a, int p
             nt.c1 = cf32{relay_lane(st.c1.x, src), relay_lane(st.c1.y, src)};
             T = nt;
             n += nv;
-            if (lane == 0) { relay_st(&sh_pos_ii, (int)T.ii); relay_st(&sh_pos_n, n); }
+            if (RING && lane == 0) relay_st(&sh_pos_ii, (int)T.ii);
         }
-        if (exhausted || nv == 0) { exhausted = true; break; }      // (nv == 0 without exhaustion cannot happen: lane 0 is in range)
-        if (have_exact && on_predictor && nv == 64 && n < Lseg) { merged = true; break; }
+        if (exhausted || nv == 0) { exhausted = true; break; }      // (nv == 0 without exhaustion cannot happen: lane 0 is good)
     }
     if (lane == 0) {
-        relay_st(&sh_done, 1);
-        atomicMax(&a.changed[4 * pass + 3], (iters << 12) | (unsigned)(s & 0xfff));      // slowest walker: iterations, segment
-        atomicAdd(&a.changed[4 * pass + 1], iters);
+        if (RING) relay_st(&sh_done, 1);
+        atomicMax(&a.changed[4 * pass + 3], (steps << 12) | (unsigned)(s & 0xfff));
+        atomicAdd(&a.changed[4 * pass + 1], steps);
         atomicAdd(&a.changed[4 * pass + 2], (unsigned)n);
         RelaySeg st0{};
         st0.s = T0;
         st0.flags = RELAY_WALKED;
         a.start[s] = st0;
-        if (merged) eout[s] = ein[s];
-        else {
-            RelaySeg e{};
-            e.s = T;
-            e.n_done = n;
-            e.flags = exhausted ? RELAY_EXHAUSTED : 0;
-            eout[s] = e;
-        }
+        RelaySeg e{};
+        e.s = T;
+        e.n_done = n;
+        e.flags = exhausted ? RELAY_EXHAUSTED : 0;
+        eout[s] = e;
     }
 }
 

@@ -208,7 +208,7 @@ struct ClockStage {
     // serial trajectory is reproduced bit for bit
     int exact = 0;              // 0: off; 1: relay until closed; n > 1: at most n relay passes (partial closure)
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
-    DevBuf relay, trace;        // segment records + per-pass counters; per-symbol predictor (ii, mu, omega)
+    DevBuf relay;               // segment records + per-pass counters
     int relay_batch = 96;       // relay passes enqueued before the host looks
     int relay_passes = 0;       // relay passes the last call ran (the closing, change-free one included)
     bool relay_closed = false;  // ... and whether they reproduced the serial trajectory
@@ -217,7 +217,6 @@ struct ClockStage {
     bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
     int relay_limit() const;
-    size_t trace_len() const;
 };
 
 // ---- helpers ---------------------------------------------------------------

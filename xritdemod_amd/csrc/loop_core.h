@@ -222,8 +222,8 @@ XR_HD cf32 clock_interp(const cf32 *w, const TableT *table, float mu_now, int *a
     return cf32{ar, ai};
 }
 
-// Second half: timing error from (p0, the history in s), loop filters, advance.  s.ii moves by floor(mu).
-XR_HD void clock_update(const cf32 p0, ClockState &s, const ClockPar &par)
+// Second half, again in two: the Mueller & Mueller timing error of the symbol p0 given the history in s ...
+XR_HD float clock_timing_error(const cf32 p0, const ClockState &s)
 {
     cf32 p2 = s.p1, p1 = s.p0;
     cf32 c2 = s.c1, c1 = s.c0;
@@ -233,7 +233,12 @@ XR_HD void clock_update(const cf32 p0, ClockState &s, const ClockPar &par)
     float dpr = p0.x - p2.x, dpi = p0.y - p2.y;
     float yr = dpr * c1.x + dpi * c1.y;
     float mm = yr - xr;
-    mm = bclip(mm, 1.0f);
+    return bclip(mm, 1.0f);
+}
+
+// ... and the loop filters: omega and mu move, s.ii advances by floor(mu), the history shifts.
+XR_HD void clock_advance(float mm, const cf32 p0, ClockState &s, const ClockPar &par)
+{
     float omega = s.omega + par.gain_omega * mm;
     omega = par.omega_mid + bclip(omega - par.omega_mid, par.omega_lim);
     float mu = s.mu + omega + par.gain_mu * mm;
@@ -241,8 +246,14 @@ XR_HD void clock_update(const cf32 p0, ClockState &s, const ClockPar &par)
     s.ii += (int)fl;            // |mu + omega| is a few samples: the 32-bit conversion is exact and one instruction
     s.mu = mu - fl;
     s.omega = omega;
-    s.p1 = p1; s.p0 = p0;
-    s.c1 = c1; s.c0 = c0;
+    s.p1 = s.p0; s.p0 = p0;
+    s.c1 = s.c0; s.c0 = cf32{p0.x > 0.0f ? 1.0f : 0.0f, p0.y > 0.0f ? 1.0f : 0.0f};
+}
+
+XR_HD void clock_update(const cf32 p0, ClockState &s, const ClockPar &par)
+{
+    const float mm = clock_timing_error(p0, s);
+    clock_advance(mm, p0, s, par);
 }
 
 // One symbol.  w points at the 8-sample window x[ii .. ii+7] (global memory or an
