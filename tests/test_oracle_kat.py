@@ -51,6 +51,40 @@ def test_rrc_taps_properties(oracle_mod):
     assert np.all(np.abs(isi) < 0.02 * rc[c])
 
 
+def test_tap_designers_against_third_party_and_an_independent_closed_form(oracle_mod):
+    """Pins for the two restated designers that do not come from this repo's author:
+      * Filters::lowPass (demodulator.cpp:444) = GNU Radio firdes::low_pass with a Hamming window: scipy.signal.firwin
+        (installed in the image, written by others) designs the same thing -- windowed sinc, symmetric Hamming,
+        unity gain at DC -- so the two must agree to float32 rounding for the decimators of C2 (151 taps) and C5 (963).
+      * Filters::RRC (demodulator.cpp:443): the textbook root-raised-cosine impulse response
+        h(t) = [sin(pi t (1 - a)) + 4 a t cos(pi t (1 + a))] / [pi t (1 - (4 a t)^2)], t in symbol periods, with its
+        two removable singularities, coded here from the formula (not from firdes' statement order) and normalised
+        to the same DC gain.
+    The oracle stays "parity unpinned" against upstream libSatHelper; this only says the restatement designs the
+    filters the reference's call sites name."""
+    import scipy.signal
+    o = oracle_mod
+    for fs, D in ((6.25e6, 5), (40e6, 32), (2.5e6 * 4, 4)):
+        circuit = fs / D
+        got = o.lowpass_taps(1.0, fs, circuit / 2, 100e3).astype(np.float64)
+        ref = scipy.signal.firwin(len(got), circuit / 2, window="hamming", fs=fs)
+        assert len(got) % 2 == 1
+        assert np.max(np.abs(got - ref)) <= 1.2e-7 * np.max(np.abs(ref)), (fs, D, np.max(np.abs(got - ref)))   # one float32 ulp of the centre tap (measured: 0.35 ulp)
+    for fs, rs, a in ((1.25e6, 293883.0, 0.5), (2.5e6, 927000.0, 0.3), (1.25e6, 293883.0, 0.35)):
+        got = o.rrc_taps(1.0, fs, rs, a, 63).astype(np.float64)
+        t = (np.arange(63) - 31) * rs / fs
+        h = np.empty(63)
+        for i, ti in enumerate(t):
+            if abs(ti) < 1e-12:
+                h[i] = 1 - a + 4 * a / np.pi
+            elif abs(abs(4 * a * ti) - 1) < 1e-9:
+                h[i] = a / np.sqrt(2) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * a)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * a)))
+            else:
+                h[i] = (np.sin(np.pi * ti * (1 - a)) + 4 * a * ti * np.cos(np.pi * ti * (1 + a))) / (np.pi * ti * (1 - (4 * a * ti) ** 2))
+        h /= h.sum()
+        assert np.max(np.abs(got - h)) <= 1.2e-7 * np.max(np.abs(h)), (fs, rs, a, np.max(np.abs(got - h)))
+
+
 def test_mmse_table_known_rows(oracle_mod):
     tb = oracle_mod.mmse_table()
     assert tb.shape == (129, 8)

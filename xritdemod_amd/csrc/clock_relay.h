@@ -108,7 +108,9 @@ __device__ __forceinline__ int relay_ld(const int *p)
 {
     int v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(relay_lds_addr(p)) : "memory");
-    return v;
+    // every lane read the same word: said so, else every branch on it is an exec-mask region and the walker's state
+    // lives in vector registers
+    return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void relay_st(int *p, int v)
 {
@@ -150,6 +152,12 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         T = e.s;
         dead = (e.flags & (RELAY_EXHAUSTED | RELAY_DEAD)) != 0;
     }
+    // (the walker's state is wave-uniform: kept in scalar registers, branches on it are scalar branches)
+    T.ii = __builtin_amdgcn_readfirstlane((int)T.ii);
+    T.mu = relay_lane(T.mu, 0); T.omega = relay_lane(T.omega, 0);
+    T.p0 = cf32{relay_lane(T.p0.x, 0), relay_lane(T.p0.y, 0)}; T.p1 = cf32{relay_lane(T.p1.x, 0), relay_lane(T.p1.y, 0)};
+    T.c0 = cf32{relay_lane(T.c0.x, 0), relay_lane(T.c0.y, 0)}; T.c1 = cf32{relay_lane(T.c1.x, 0), relay_lane(T.c1.y, 0)};
+    dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;
     const RelaySeg prev = a.start[s];
     const int x_lo = (int)(T.ii > 4 ? T.ii - 4 : 0);
     if (threadIdx.x == 0) { sh_xhi = x_lo; sh_pos_ii = (int)T.ii; sh_done = 0; }
@@ -198,7 +206,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const ClockState T0 = T;
     const float kw = 16777216.0f / (float)a.q_om, km = 16777216.0f / (float)a.q_mu;
     int n = 0;
-    unsigned steps = 0;
+    unsigned steps = 0, rounds_total = 0;
     bool exhausted = false;
     while (n < Lseg) {
         ++steps;
@@ -233,6 +241,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         ClockState hs{};               // the history symbol n + lane sees: (p0, p1) of the two symbols in front of it
         bool stale = false, inrange = true;
         for (int round = 0; round < RELAY_ROUNDS; ++round) {
+            ++rounds_total;
             const int arm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
             // (re)interpolate where the read index or the arm moved
             inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         if (RING) relay_st(&sh_done, 1);
         atomicMax(&a.changed[4 * pass + 3], (steps << 12) | (unsigned)(s & 0xfff));
         atomicAdd(&a.changed[4 * pass + 1], steps);
-        atomicAdd(&a.changed[4 * pass + 2], (unsigned)n);
+        atomicAdd(&a.changed[4 * pass + 2], rounds_total);
         RelaySeg st0{};
         st0.s = T0;
         st0.flags = RELAY_WALKED;

@@ -444,6 +444,9 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_counters, COSTAS_CTL_WORDS * sizeof(unsigned)));
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
+    keep_spare = getenv("XRIT_KEEP_SPARE") != nullptr;
+    trace_env = getenv("XRIT_TRACE") != nullptr;
+    no_serial_walk = getenv("XRIT_NO_SERIAL_WALK") != nullptr;
     cur = 0;
     return XRIT_OK;
 }
@@ -682,13 +685,13 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         // and rewrites its output, see above) brings it back.
         stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
         last_passes = passes;
-        const int want = passes + ((stable >= 2 && !getenv("XRIT_KEEP_SPARE")) ? 0 : 1);
+        const int want = passes + ((stable >= 2 && !keep_spare) ? 0 : 1);
         batch = want < 2 ? 2 : (want > 6 ? 6 : want);
     }
     unconverged = job.K > 1 && h_counters[0] == 0 ? h_counters[2] : 0;
     uint32_t bits = h_counters[3];
     memcpy(&max_residual, &bits, sizeof(float));
-    if (getenv("XRIT_TRACE") && job.K > 1) {
+    if (trace_env && job.K > 1) {
         std::vector<unsigned> hc((size_t)passes * 8);
         XR_HIP(hipMemcpy(hc.data(), costas_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (int p = 0; p < passes; ++p) {
@@ -711,7 +714,7 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
 int CostasStage::serial_rescue(hipStream_t s, Profiler *prof)
 {
     job.rescued = true;
-    if (job.K <= 2 || getenv("XRIT_NO_SERIAL_WALK")) return XRIT_OK;
+    if (job.K <= 2 || no_serial_walk) return XRIT_OK;
     XR_TRY(rescue.reserve(2 * sizeof(int)));
     const int init[2] = {0x7fffffff, -1};
     XR_HIP(hipMemcpyAsync(rescue.p, init, sizeof init, hipMemcpyHostToDevice, s));

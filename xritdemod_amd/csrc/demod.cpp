@@ -213,7 +213,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;
-        d->clock.exact = cfg->clock_exact > 0 ? cfg->clock_exact : 0;
+        d->clock.exact = cfg->clock_exact;
         d->clock.relay_window = cfg->clock_exact_window > 0 ? cfg->clock_exact_window : 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
@@ -469,7 +469,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.costas_serial_walk = d->costas.job.rescued && d->costas.walked ? 1 : 0;
     d->stats.clock_relay_passes = d->clock.relay_passes;
     d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
-    d->stats.clock_relay_segments = d->clock.exact ? d->clock.relay_segments : 0;
+    d->stats.clock_relay_segments = d->clock.job.relay ? d->clock.relay_segments : 0;
     *n_out = total_sym;
     if (d->cfg.strict && unc_c) {
         set_error("Costas hand-off did not close: %u boundaries above tolerance", unc_c);
@@ -818,7 +818,7 @@ int xrit_clock_set_serial(xrit_clock *c, int serial)
 int xrit_clock_set_exact(xrit_clock *c, int exact, int window)
 {
     if (!c) return XRIT_E_INVALID;
-    c->st.exact = exact > 0 ? exact : 0;
+    c->st.exact = exact;
     c->st.relay_window = window > 0 ? window : 0;
     return XRIT_OK;
 }

@@ -459,6 +459,9 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
 
 int FirStage::init(const float *taps, int ntaps, int decim)
 {
+    // diagnostic switches are read once, here: never on the launch path (a host that calls setenv races with getenv)
+    no_static_dec = getenv("XRIT_NO_STATIC_DEC") != nullptr;
+    no_static_mf = getenv("XRIT_NO_STATIC_MF") != nullptr;
     T = ntaps;
     D = decim < 1 ? 1 : decim;
     // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
@@ -561,11 +564,11 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
                        out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
                        f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
-    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !getenv("XRIT_NO_STATIC_DEC"))
+    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
                            f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
-    else if (RC == 5 && !PAD && f.T == 63 && f.D == 1 && type == XRIT_SAMPLE_FLOATIQ && !getenv("XRIT_NO_STATIC_MF"))
+    else if (RC == 5 && !PAD && f.T == 63 && f.D == 1 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_mf)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 5 && !PAD) ? 63 : 0>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
                            f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
@@ -592,7 +595,7 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
     const unsigned blocks = div_up(n, (size_t)f.threads * 5);
     {
         ProfScope ps(prof, "fir_rrc", s);
-        if (f.T == 63 && !getenv("XRIT_NO_STATIC_MF"))
+        if (f.T == 63 && !f.no_static_mf)
             hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3, 63>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                                in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
                                (long long)n, f.tile_len, stat, statL, none, af, f.hist[f.cur ^ 1].as<float2>());

@@ -11,6 +11,7 @@ namespace xrit {
 struct FirStage {
     int T = 0, D = 1, RC = 3, W = 0, Wpad = 0, threads = 256, tile_len = 0, cur = 0;
     bool pad = false;
+    bool no_static_dec = false, no_static_mf = false;   // XRIT_NO_STATIC_DEC / XRIT_NO_STATIC_MF, read once in init (A/B runs)
     bool poly = false;   // polyphase kernel (lanes = phases) for decimation 16 / 32 / 64
     static constexpr int POLY_PR = 16, POLY_NQ = 32;     // outputs per lane group, taps per phase (T <= 32 * D)
     size_t lds_bytes = 0;
@@ -102,6 +103,7 @@ struct CostasStage {
     DevBuf state;           // float2 (phase, freq) carried across calls
     DevBuf S, E, J, stat, dlin, work, flags, counters, wsolve, rescue;
     bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1)
+    bool keep_spare = false, trace_env = false, no_serial_walk = false;   // XRIT_KEEP_SPARE, XRIT_TRACE, XRIT_NO_SERIAL_WALK (read in init)
     // a hand-off still open after rescue_after passes is walked serially between its first and last open boundary
     // (costas_serial_states_kernel), if that is at most rescue_max_samples samples
     int rescue_after = 32;
@@ -200,13 +202,17 @@ struct ClockStage {
         bool rescued = false;   // the serial walk has been tried
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
+        bool relay = false;                     // ... is on for this call
     } job;
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int last_passes = -1;
                             // (5-6 in steady state)
     // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
     // serial trajectory is reproduced bit for bit
-    int exact = 0;              // 0: off; 1: relay until closed; n > 1: at most n relay passes (partial closure)
+    int exact = 0;              // 0: when the hand-off stalls above auto_rms; 1: always, until closed; n > 1: always, at most n
+                                // relay passes (partial closure); < 0: never
+    float auto_rms = 3e-4f;     // rms hand-off residual (samples) beyond which a call is closed exactly on its own
+    bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
     DevBuf relay;               // segment records + per-pass counters
     int relay_batch = 96;       // relay passes enqueued before the host looks
@@ -214,9 +220,12 @@ struct ClockStage {
     bool relay_closed = false;  // ... and whether they reproduced the serial trajectory
     int relay_segments = 0, relay_seg_chains = 0;
     bool trace_env = false;     // XRIT_TRACE=1 (read at init): per-pass statistics on stderr
+    bool no_meanj = false;      // XRIT_NO_MEANJ=1: finite-difference Jacobians in every call
+    int ng_max = 8;             // XRIT_CLOCK_NG: one-wave groups per clock workgroup at most
     bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
     int relay_limit() const;
+    int relay_plan();
 };
 
 // ---- helpers ---------------------------------------------------------------
