@@ -1254,6 +1254,7 @@ def test_low_snr_regression_seeds(xa, oracle_mod, seed, esn0, carrier, ppm, toff
                           carrier_hz=carrier, clock_ppm=ppm, timing_offset=toff, phase0=ph)
     case = ("hrit", 5, 12.5e6, n, 0, p, [0, n], False)
     w, g = _run_case(xa, oracle_mod, *case)
+    relayed = _run_case.relay_passes > 0
     _, ser = _run_case(xa, oracle_mod, *case, clock_serial=1)
     big = np.abs(w) > 1e-3
     assert np.array_equal(np.sign(w[big]), np.sign(ser[big])) and rms(w - ser) <= 5e-4
@@ -1261,7 +1262,6 @@ def test_low_snr_regression_seeds(xa, oracle_mod, seed, esn0, carrier, ppm, toff
     # default configuration then IS the serial device run, word for word (the second seed: residuals stall at 1e-3;
     # round 2: a flipped decision, rms 1.0e-3).  The first seed's hand-off settles at 8e-5 like a clean signal's and
     # stays the tiled result (2.5e-4 from the serial run, no decision differs).
-    relayed = _run_case.relay_passes > 0
     assert relayed == (seed == 151577245)
     if relayed:
         assert np.array_equal(g.view(np.uint32), ser.view(np.uint32))
