@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="one burst at a time: do not run the front end of the next burst (xrit_demod_prefetch_device, second "
                          "stream) under the feedback loops of the current one")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode leg (cfg.clock_exact = 1)")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
@@ -235,14 +236,29 @@ def main():
     prof_timed = dem.profile_read() if not args.no_profile else []
     dem.profile(False)
     prof = []
+    dec_samples = {}
     if detail:
-        # per-kernel table: the next K bursts of the stream with every launch bracketed (outside the timed region)
+        # per-kernel table: the next K bursts of the stream with every launch bracketed (outside the timed region).
+        # As many of them as the buffers hold are generated BEFORE the steps run: in round 2 every step of this pass
+        # followed the 39 ms FP64 generator of its own burst, and the decimator -- the first kernel behind it -- then
+        # read 0.79 ms where every other run of it reads 0.55 (profiles/r3_decimator_ab.txt reproduces both).
         dem.profile(1)
-        for b in range(W + K, W + 2 * K):
-            generate(b)
-            step(b)
+        b = W + K
+        while b < W + 2 * K:
+            chunk = min(nbuf - 1 if nbuf > 1 else 1, W + 2 * K - b)
+            for q in range(chunk):
+                generate(b + q)
+            torch.cuda.synchronize(dev)
+            for q in range(chunk):
+                step(b + q)
+            b += chunk
         torch.cuda.synchronize(dev)
         prof = dem.profile_read()
+        for nm in ("fir_decim", "fir_rrc", "clock_pass", "costas_pass"):
+            v = sorted(dem.profile_samples(nm))
+            if v:
+                dec_samples[nm] = {"min_ms": round(v[0], 4), "median_ms": round(v[len(v) // 2], 4), "max_ms": round(v[-1], 4),
+                                   "launches": len(v)}
         dem.profile(False)
         timed = {n: (ms, c) for n, ms, c in prof_timed}
         alone = {n: ms / c for n, ms, c in prof}          # every kernel by itself (the detail pass does not prefetch)
@@ -282,6 +298,8 @@ def main():
             k = {"total_ms": round(ms, 4), "launches": cnt, "avg_launch_ms": round(avg, 4),
                  "measured": ("timed region" + (", under the loops of the previous burst (second stream)" if prefetch else ""))
                  if name == "fir_decim" else "detail pass"}
+            if name in dec_samples:
+                k["alone"] = dec_samples[name]       # detail pass: one burst at a time, every launch bracketed
             if name == "fir_decim" and name in alone:
                 k["avg_launch_ms_alone"] = round(alone[name], 4)
                 if name in own_bytes:
@@ -366,6 +384,37 @@ def main():
         out["roofline"] = roofline
         out["kernels"] = kernels
 
+    # ---- the exact mode beside it (cfg.clock_exact = 1, csrc/clock_relay.h): the same stream from its first burst through
+    # a second handle whose clock recovery is relayed to closure -- bit for bit the serial trajectory -- timed over
+    # its own steady-state steps.  Not `value`: the headline stays the default configuration.
+    soft0_exact = None
+    if rank == 0 and world == 1 and not args.no_exact:
+        xd = xa.Demodulator(xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
+                                                   clock_chain_syms=args.clock_chain, clock_exact=1))
+        Kx, Wx = min(K, 5), 2
+        for b in range(min(Wx + Kx, nbuf)):
+            generate(b)
+        torch.cuda.synchronize(dev)
+        closed, rp = True, []
+        for b in range(Wx):
+            ns = xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
+            if b == 0:
+                soft0_exact = soft[:ns].clone()
+        torch.cuda.synchronize(dev)
+        x0 = time.perf_counter()
+        for b in range(Wx, Wx + Kx):
+            xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
+            sx = xd.stats()
+            closed = closed and bool(sx.clock_relay_closed)
+            rp.append(int(sx.clock_relay_passes))
+        torch.cuda.synchronize(dev)
+        x1 = time.perf_counter()
+        out["exact_mode"] = {"what": "cfg.clock_exact = 1: clock recovery relayed to closure, symbols bit-identical to the serial "
+                                     "float32 recurrence on this chain's Costas output (no front-end prefetch)",
+                             "value": round(n_burst * Kx / (x1 - x0) / 1e6, 2), "unit": "Msamples/s", "steps": Kx,
+                             "ms_per_step": round((x1 - x0) / Kx * 1e3, 3), "relay_passes": rp, "closed": closed,
+                             "relay_segments": int(sx.clock_relay_segments)}
+
     # ---- CPU baseline: the oracle (a CPU restatement; the reference binary cannot be built here) on a
     # bounded sample of the same workload, one thread like the reference's DSP thread.
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -428,6 +477,13 @@ def main():
                 out["parity_vs_oracle"]["serial_gpu_rms"] = fl["rms"]
                 out["parity_vs_oracle"]["serial_gpu"] = fl
                 out["parity_vs_oracle"]["tiled_vs_serial_gpu_rms"] = compare(g, ser)["rms"]
+                if soft0_exact is not None:
+                    ge = soft0_exact[:len(so)].cpu().numpy()
+                    ex = compare(ge, so)
+                    ex["vs_serial_gpu_rms"] = compare(ge, ser)["rms"]
+                    ex["words_differing_from_serial_gpu"] = int((ge[:min(len(ge), len(ser))].view(np.uint32) !=
+                                                                 ser[:min(len(ge), len(ser))].view(np.uint32)).sum())
+                    out["parity_vs_oracle"]["exact_mode"] = ex
                 out["parity_vs_oracle"]["target_rms"] = 1e-4
                 out["parity_vs_oracle"]["floor_note"] = ("serial_gpu_rms is the measured floor of a hand-off-free float32 "
                                                          "M&M on this chain's Costas output; the time-tiled evaluation "

@@ -205,6 +205,9 @@ int xrit_demod_profile(xrit_demod *d, int enable);
 /* name/ms arrays are filled with up to cap entries (accumulated since enable);
  * launches[] = number of launches per kernel.  Returns entries written. */
 int xrit_demod_profile_read(xrit_demod *d, const char **names, float *total_ms, int *launches, int cap);
+/* every bracket of one kernel name since enable, in launch order (min / median of a kernel, not only its mean);
+ * returns the number written */
+int xrit_demod_profile_samples(xrit_demod *d, const char *name, float *ms, int cap);
 
 /* SymbolManager::process quantiser (SymbolManager.cpp:43-46): f=s*127, clamp
  * [-128,127], C cast (truncation).  Device kernel on device pointers. */

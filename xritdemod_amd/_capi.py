@@ -71,6 +71,7 @@ _SIGNATURES = {
     "xrit_demod_get_stats": (C.c_int, [_vp, C.POINTER(DemodStats)]),
     "xrit_demod_profile": (C.c_int, [_vp, C.c_int]),
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "xrit_demod_profile_samples": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     "xrit_quantize_i8_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "xrit_quantize_i8": (C.c_int, [_vp, _vp, _vp, _sz]),
     "xrit_sync_correlate_device": (C.c_int, [_vp, _sz, _vp, C.c_int, C.c_uint32, _vp, C.c_int, _vp]),
@@ -405,6 +406,12 @@ class Demodulator(_Handle):
         cnt = (C.c_int * cap)()
         n = lib().xrit_demod_profile_read(self._h, names, ms, cnt, cap)
         return [(names[i].decode(), float(ms[i]), int(cnt[i])) for i in range(n)]
+
+    def profile_samples(self, name, cap=4096):
+        """Every bracket of one kernel name since profile(enable), in launch order (ms)."""
+        ms = (C.c_float * cap)()
+        n = lib().xrit_demod_profile_samples(self._h, name.encode(), ms, cap)
+        return [float(ms[i]) for i in range(max(n, 0))]
 
     def quantize_i8(self, soft):
         soft = np.ascontiguousarray(soft, np.float32)

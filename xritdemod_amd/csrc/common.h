@@ -72,6 +72,7 @@ struct Profiler {
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
     std::map<std::string, std::pair<double, int>> acc;
+    std::map<std::string, std::vector<float>> samples;      // every bracket's duration, in launch order
     std::vector<std::string> order;
 
     hipEvent_t get()
@@ -112,13 +113,14 @@ struct Profiler {
                 auto it = acc.find(r.name);
                 if (it == acc.end()) { acc[r.name] = {ms, 1}; order.push_back(r.name); }
                 else { it->second.first += ms; it->second.second += 1; }
+                samples[r.name].push_back(ms);
             }
             pool.push_back(r.a);
             pool.push_back(r.b);
         }
         pending.swap(later);
     }
-    void reset() { acc.clear(); order.clear(); }
+    void reset() { acc.clear(); samples.clear(); order.clear(); }
     ~Profiler()
     {
         for (auto &r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -585,6 +585,20 @@ int xrit_demod_profile_read(xrit_demod *d, const char **names, float *total_ms, 
     return n;
 }
 
+int xrit_demod_profile_samples(xrit_demod *d, const char *name, float *ms, int cap)
+{
+    if (!d || !name) return XRIT_E_INVALID;
+    auto it = d->prof.samples.find(name);
+    if (it == d->prof.samples.end()) return 0;
+    int n = 0;
+    for (float v : it->second) {
+        if (n >= cap) break;
+        if (ms) ms[n] = v;
+        ++n;
+    }
+    return n;
+}
+
 int xrit_quantize_i8_device(const float *d_soft, int8_t *d_out, size_t n, int device, void *stream)
 {
     XR_TRY(select_device(device));
