@@ -120,7 +120,7 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
                                    const ClockState *__restrict__ carried, int K, int NS, float omega0,
                                    const float2 *__restrict__ x, const float *__restrict__ table, long long ni,
                                    double off, int BL, int *__restrict__ dirty, int *__restrict__ ctl, int ctl_words,
-                                   int *__restrict__ terminal)
+                                   int *__restrict__ terminal, int *__restrict__ written)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {
@@ -131,6 +131,7 @@ __global__ void clock_guess_kernel(const double *__restrict__ cnt, int nb, doubl
     }
     if (k >= K) return;
     dirty[k] = 1;                       // every chain runs in the first pass
+    written[k] = 0;                     // ... and none has left its symbols yet
     ClockState s0 = carried[0];
     if (k == 0) { S[0] = s0; ctl[5] = 1; return; }     // first solve: gated
     double t0 = (double)s0.ii + (double)s0.mu;
@@ -586,17 +587,30 @@ __device__ __forceinline__ int clock_origin_min(const int *wb)
 // wave 2 = omega shifted by h_w; the base lane forms the finite-difference Jacobian.  NV == 1: base trajectories
 // only -- the Jacobian of an earlier pass is kept, or the stream's mean Jacobian is used (quasi-Newton, see
 // ClockStage::begin) -- and the workgroup holds blockDim.x / 64 groups of 64 chains that share the table.
-template <int NV, int WP, int NCM>
+// what a pass that also leaves the symbols needs (OUTP): from the pass the stop test usually fires after, the passes
+// write every symbol they compute -- the pass after which the hand-off closes then IS the output pass, and
+// clock_output_kernel (a whole extra sweep of the stream) returns at once.  The first such pass runs every chain.
+struct ClockPassOut {
+    float *soft;
+    float2 *sym;
+    unsigned long long cap;
+    int *valid;          // ctl word: the symbols in soft / sym belong to the end states in E
+    int *written;        // per chain: its symbols have been written in this call (a chain that has not runs, dirty or not)
+};
+constexpr int CLK_CTL_SYMBOLS = 13;
+
+template <int NV, int WP, int NCM, bool OUTP = false>
 __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(const float2 *__restrict__ x, const float *__restrict__ table_g,
                                                              const ClockState *__restrict__ S, ClockState *__restrict__ E,
                                                              float4 *__restrict__ J, int *__restrict__ dirty,
                                                              int *__restrict__ nrun, long long N, long long ni, int K,
                                                              int NS, ClockPar par, int SS, int W, int WS, int A,
                                                              int STEP, const int *__restrict__ ctl, ClockPolicy pol,
-                                                             AffMap *__restrict__ aggs)
+                                                             AffMap *__restrict__ aggs, ClockPassOut po = ClockPassOut{})
 {
     // the hand-off already closed (later passes of the batch are no-ops), or the gated solve has taken over
     if (ctl[0] || (aggs != nullptr && ctl[NEWTON_CTL_TAKEOVER])) return;
+    if (OUTP && blockIdx.x == 0 && threadIdx.x == 0) *po.valid = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 endv[2][NV > 1 ? 64 : 1];
     __shared__ long long ref_ii[NV > 1 ? 64 : 1];
@@ -607,7 +621,7 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
     const int wv = blockIdx.x * ngroups + grp;      // which 64 chains
     const int k = wv * 64 + lane;
     bool run = k < K;
-    if (run) run = dirty[k] != 0;
+    if (run) run = dirty[k] != 0 || (OUTP && po.written[k] == 0);
     if (threadIdx.x == 0) any_run = 0;
     __syncthreads();
     if (run && variant == 0) any_run = 1;
@@ -633,9 +647,37 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
         int off = (int)(s.ii - origin);
         const int nsub = (NS + SS - 1) / SS;
         const ClockSrc src = clock_src(x, N, clock_origin_min(t.wb));
+        const unsigned long long obase = (unsigned long long)k * NS;
         clock_pipeline<NV, WP, (NCM + NV - 1) / NV>(t, src, WS, nsub, STEP, [&](int j, int cum) {
-            clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
-                                     produced, (float *)nullptr);
+            if (!OUTP) {
+                clock_substep<WP, false>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                         produced, (float *)nullptr);
+                return;
+            }
+            // (as in clock_output_kernel: a lane's symbols of one sub-step leave as one 16-byte store)
+            cf32 ps[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ps[i] = cf32{0.f, 0.f};
+            const int before = produced;
+            clock_substep<WP, true>(t, x, WS, lane, origin, cum, min(SS, NS - j * SS), SS, A, ni, par, s, off, alive,
+                                    produced, ps);
+            const int nv = produced - before;
+            const unsigned long long o = obase + (unsigned long long)j * SS;
+            if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < po.cap) {
+                if (po.soft) *reinterpret_cast<float4 *>(po.soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
+                if (po.sym) {
+                    *reinterpret_cast<float4 *>(po.sym + o) = make_float4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
+                    *reinterpret_cast<float4 *>(po.sym + o + 2) = make_float4(ps[2].x, ps[2].y, ps[3].x, ps[3].y);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nv && o + i < po.cap) {
+                        if (po.soft) po.soft[o + i] = ps[i].x;
+                        if (po.sym) po.sym[o + i] = make_float2(ps[i].x, ps[i].y);
+                    }
+                }
+            }
         });
         if (NV > 1) {
             // hand the perturbed end states to the base lane as (t - t_ref, omega) with a common reference
@@ -657,6 +699,7 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
             E[k] = s;
             nrun[k] = produced;
             dirty[k] = 0;
+            if (OUTP) po.written[k] = 1;
         }
     }
     if (aggs == nullptr || variant != 0 || wv * 64 >= K) return;
@@ -690,8 +733,9 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
                                                           float2 *__restrict__ sym, unsigned long long cap, long long N,
                                                           long long ni, int K, int NS, ClockPar par,
                                                           int *__restrict__ terminal, int SS, int W, int WS, int A,
-                                                          int STEP)
+                                                          int STEP, const int *__restrict__ ctl)
 {
+    if (ctl[CLK_CTL_SYMBOLS]) return;        // the last pass wrote the symbols (ClockPassOut): E, nrun hold the rest
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ngroups = (int)(blockDim.x >> 6), grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ClockTile t = clock_tile_carve(smem, grp, ngroups, WS);
@@ -745,8 +789,9 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
 
 // result of the call + the state and the unread tail carried to the next call
 __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *__restrict__ E,
-                                                              const int *__restrict__ counts,
-                                                              const int *__restrict__ terminal,
+                                                              const int *__restrict__ counts_out,
+                                                              const int *__restrict__ nrun,
+                                                              const int *__restrict__ ctl,
                                                               const ClockState *__restrict__ carried_in,
                                                               ClockState *__restrict__ carried_out,
                                                               ClockResult *__restrict__ res,
@@ -754,8 +799,21 @@ __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *
                                                               float2 *__restrict__ tail_out, long long N, int K, int NS)
 {
     __shared__ long long s_ii;
+    __shared__ int s_term;
+    // symbols per chain: what the output pass counted, or -- when a hand-off pass left the symbols -- what that pass did
+    const int *counts = ctl[CLK_CTL_SYMBOLS] ? nrun : counts_out;
+    if (threadIdx.x == 0) s_term = 0x7fffffff;
+    __syncthreads();
+    // the first chain that ran out of input ends the call
+    int first = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 1024) {      // (no early exit: the loads stay independent of one another)
+        const int c = counts[k];
+        first = (c < NS && k < first) ? k : first;
+    }
+    if (first != 0x7fffffff) atomicMin(&s_term, first);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        int k = *terminal;
+        int k = s_term;
         ClockState s;
         if (k < 0 || k >= K) {
             // no chain reached the end of the input: the chain budget was too small
@@ -943,6 +1001,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
+    pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
     ng_max = getenv("XRIT_CLOCK_NG") ? atoi(getenv("XRIT_CLOCK_NG")) : 8;
     return XRIT_OK;
 }
@@ -1158,24 +1217,29 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
         const bool jac = p < jac_passes && !j.mean_j;
         {
             ProfScope ps(prof, jac ? "clock_pass_jac" : "clock_pass", s);
-#define XR_CLK_PASS(NV, WPV, NCM)                                                                                     \
+#define XR_CLK_PASS(NV, WPV, NCM, OUTV)                                                                               \
     do {                                                                                                              \
         const size_t lds = NV > 1 ? j.tile_bytes3 : j.tile_bytes;                                                     \
-        clock_allow_lds(clock_pass_kernel<NV, WPV, NCM>, lds);                                                        \
-        hipLaunchKernelGGL((clock_pass_kernel<NV, WPV, NCM>), dim3(NV > 1 ? nw : div_up(nw, j.NG)),                   \
+        clock_allow_lds(clock_pass_kernel<NV, WPV, NCM, OUTV>, lds);                                                  \
+        hipLaunchKernelGGL((clock_pass_kernel<NV, WPV, NCM, OUTV>), dim3(NV > 1 ? nw : div_up(nw, j.NG)),             \
                            dim3(NV > 1 ? 64 * NV : 64 * j.NG), lds, s, x, table.as<float>(), S.as<ClockState>(),      \
                            E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, j.N, j.ni, j.K, NS, par, j.SS, j.W,   \
-                           j.WS, j.A, j.STEP, clock_ctl(counters), pol, aggs);                                        \
+                           j.WS, j.A, j.STEP, clock_ctl(counters), pol, aggs, po);                                    \
     } while (0)
-#define XR_CLK_PASS_NV(NV)                                                                                            \
+#define XR_CLK_PASS_NV(NV, OUTV)                                                                                      \
     do {                                                                                                              \
-        if (!j.wide && narrow) XR_CLK_PASS(NV, 32, 20);                                                               \
-        else if (!j.wide) XR_CLK_PASS(NV, 32, 32);                                                                    \
-        else XR_CLK_PASS(NV, 64, 64);                                                                                 \
+        if (!j.wide && narrow) XR_CLK_PASS(NV, 32, 20, OUTV);                                                         \
+        else if (!j.wide) XR_CLK_PASS(NV, 32, 32, OUTV);                                                              \
+        else XR_CLK_PASS(NV, 64, 64, OUTV);                                                                           \
     } while (0)
             const bool narrow = (j.STEP >> 16) + 1 <= 20;      // columns a sub-step adds to a ring
-            if (jac) XR_CLK_PASS_NV(3);
-            else XR_CLK_PASS_NV(1);
+            // from the pass the stop test is expected to fire after (what the previous call needed, never before the
+            // fourth: ClockPolicy::decide stops no earlier) the passes leave the symbols themselves
+            const bool writes = !jac && !j.relay && p >= j.write_from && (j.SS == 4 || j.SS == 2 || j.SS == 1);
+            const ClockPassOut po{j.soft, j.sym, (unsigned long long)j.cap, clock_ctl(counters) + CLK_CTL_SYMBOLS, j.written};
+            if (jac) XR_CLK_PASS_NV(3, false);
+            else if (writes) XR_CLK_PASS_NV(1, true);
+            else XR_CLK_PASS_NV(1, false);
 #undef XR_CLK_PASS_NV
 #undef XR_CLK_PASS
         }
@@ -1211,7 +1275,7 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         hipLaunchKernelGGL((clock_output_kernel<WPV, NCM, SYMV>), dim3(div_up(nw, j.NG)), dim3(64 * j.NG),            \
                            j.tile_bytes, s, x, table.as<float>(), S.as<ClockState>(), E.as<ClockState>(), j.counts,   \
                            j.soft, j.sym, (unsigned long long)j.cap, j.N, j.ni, j.K, NS, par, j.terminal, j.SS, j.W,  \
-                           j.WS, j.A, j.STEP);                                                                        \
+                           j.WS, j.A, j.STEP, clock_ctl(counters));                                                   \
     } while (0)
 #define XR_CLK_OUT(WPV, NCM)                              \
     do {                                                  \
@@ -1224,8 +1288,8 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         else XR_CLK_OUT(64, 64);
 #undef XR_CLK_OUT_S
 #undef XR_CLK_OUT
-        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.terminal,
-                           st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
+        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.nrun,
+                           clock_ctl(counters), st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1339,7 +1403,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
-    XR_TRY(flags.reserve((size_t)(3 * K + 4) * sizeof(int)));
+    XR_TRY(flags.reserve((size_t)(4 * K + 4) * sizeof(int)));
     XR_TRY(om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))));
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;
@@ -1354,10 +1418,14 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     }
     j.relay = exact >= 1;
     if (j.relay) XR_TRY(relay_plan());
+    // (the stop test ends the passes one earlier or later from burst to burst: a pass that writes without being the
+    // last costs ~15 us, a call whose last pass did not write pays the whole output pass, ~175 us at C2)
+    j.write_from = pass_writes ? (last_passes - 2 > 3 ? last_passes - 2 : 3) : 0x7fffffff;
     j.dirty = flags.as<int>();
     j.counts = flags.as<int>() + K;
     j.nrun = flags.as<int>() + 2 * K;
     j.terminal = flags.as<int>() + 3 * K;
+    j.written = flags.as<int>() + 3 * K + 4;
     double2 *X = om.as<double2>();
     double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
     const ClockState *st_in = st.as<ClockState>() + cur;
@@ -1375,7 +1443,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
                                work.as<double>());
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
                                S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL, j.dirty,
-                               clock_ctl(counters), (max_passes + 5) * 8, j.terminal);
+                               clock_ctl(counters), (max_passes + 5) * 8, j.terminal, j.written);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {

@@ -200,10 +200,12 @@ struct ClockStage {
         bool mean_j = false;    // the passes use the stream's mean Jacobian: no finite-difference pass
         bool gated = false;     // this call has gone over to the gated solve
         bool rescued = false;   // the serial walk has been tried
-        int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr;
+        int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr, *written = nullptr;
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
         bool relay = false;                     // ... is on for this call
+        int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
     } job;
+    bool pass_writes = true;    // the last hand-off pass is the output pass (XRIT_NO_PASS_OUTPUT=1, read at init: a separate output pass)
     int batch = 7;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int last_passes = -1;
                             // (5-6 in steady state)
