@@ -144,6 +144,17 @@ int xrit_demod_process(xrit_demod *d, const void *samples, size_t n_complex, int
 /* Same with device-resident input and output (no PCIe in the call). */
 int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type,
                               float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* The clock recovery of the LAST process call once more, on the sign-flipped Costas output (xrit_group_*: this
+ * rank's Costas loop locked pi away from the stream the capture's first GPU follows; the Mueller & Mueller detector
+ * slices to {0, 1}, so the loop on -y is not minus the loop on y and the recovery has to run on the right sign).
+ * The clock recovery's carried state goes back to what it was before that call (history and unread tail change sign),
+ * the Costas loop's carried phase moves by pi; d_soft receives the call's symbols again. */
+int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* Called after the process call that warmed the chain up over a time slice's halo (from a cold start): that call's
+ * clock recovery is run once more on the negated Costas output and what it would carry is kept aside, so that a later
+ * xrit_demod_redo_clock_flipped starts from the flipped loop's own state (without it, it starts from this sign's state
+ * with the symbol history negated -- right to 1e-3 sample in timing, which takes 1e4..1e5 symbols to settle). */
+int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
 /* Streaming at full rate: run the front end (ingest, decimator, AGC, matched filter) of a LATER call's input now, on
  * the handle's second stream, so that it overlaps the feedback loops of the call made in between:
  *     prefetch(b);  prefetch(b+1); process_device(b);  prefetch(b+2); process_device(b+1);  ...
@@ -343,12 +354,18 @@ int    xrit_group_rank(const xrit_group *g);
 int    xrit_group_world(const xrit_group *g);
 size_t xrit_group_halo_samples(const xrit_group *g);
 /* Collective: every rank passes ITS slice (n samples, device resident, slices in
- * rank order make up the burst; n >= the halo) and receives its symbols in the
- * stream's polarity with their offset in the burst's symbol sequence: rank r's
- * symbols are out[offset .. offset + n_out) of what one chain would emit for the
- * whole burst (to the clock recovery's floor; a rank that locked pi away from
- * rank 0 has its symbols negated).  The chain of every rank restarts cold per
- * call: consecutive calls are consecutive bursts only in the sense of rank 0. */
+ * rank order make up the burst; n >= the halo, and a whole number of decimation
+ * periods for every rank but the last) and receives its symbols in the stream's
+ * polarity with their offset in the burst's symbol sequence: rank r's symbols are
+ * out[offset .. offset + n_out) of what one chain would emit for the whole burst
+ * (to the clock recovery's floor: a rank whose Costas loop locked pi away from
+ * rank 0's runs its clock recovery once more on the sign-flipped stream, so both
+ * locks end at the same floor).  The chain of every rank restarts cold per call:
+ * consecutive calls are consecutive bursts only in the sense of rank 0.
+ * A failure on one rank (capacity, a stage that did not converge in strict mode,
+ * HIP) is carried to every rank in the all-gather: every rank returns an error
+ * from the same call and nobody is left waiting in an exchange; a rank that
+ * cannot even serve its peers (out of device memory) aborts the communicator. */
 int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t n_complex, int sample_type,
                                     float *d_soft_out, size_t cap, size_t *n_out, uint64_t *offset_out,
                                     int *polarity_out, void *stream);

@@ -908,7 +908,90 @@ def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
     assert rms(s0 - want[:len(s0)]) < 3.2e-4
-    assert rms(s1 - want[len(s0):]) < (3.2e-4 if pol1 == 1 else 3e-3)
+    # round 3: a rank whose Costas loop locked pi away from the stream runs its clock recovery once more on the
+    # sign-flipped Costas output (xrit_demod_redo_clock_flipped) -- both polarities end at the same floor
+    # (round 2: 3e-3 for the flipped one, the M&M detector slices to {0, 1})
+    assert rms(s1 - want[len(s0):]) < 3.2e-4, (pol1, rms(s1 - want[len(s0):]))
+
+
+def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
+    """Both locks of rank 1 are exercised: the start phase of the capture is moved by a quarter turn at a time, so that
+    rank 1 (cold start over its halo) falls on either side of the stream rank 0 follows; the joined output must be the
+    uninterrupted chain's to 3.2e-4 rms with identical decisions in every case."""
+    import threading
+    import torch
+    n, D = 900000, 5
+    dev = torch.device("cuda", 0)
+    seen = set()
+    for ph in (0.7, 2.3, 3.9, 5.4):
+        x = synth.generate(synth.SynthParams(fs_in=6.25e6, phase0=ph, seed=4242), 2 * n)
+        want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, D)).process(x)
+        fabric = xa.LocalFabric(2)
+        xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+        res, err = [None, None], []
+
+        def rank_main(r):
+            try:
+                g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), r, fabric=fabric)
+                cap = n // D + 1024
+                soft = torch.empty(cap, dtype=torch.float32, device=dev)
+                sl = xt[r * n:(r + 1) * n].contiguous()
+                k, off, pol = g.process_slice_device(sl.data_ptr(), n, soft.data_ptr(), cap)
+                res[r] = (soft[:k].cpu().numpy(), off, pol)
+            except Exception as e:          # noqa: BLE001
+                err.append(e)
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not err, err
+        (s0, off0, pol0), (s1, off1, pol1) = res
+        seen.add(pol1)
+        got = np.concatenate([s0, s1])
+        assert len(got) == len(want) and off1 == len(s0)
+        # (the oracle's own lock may be the other one: compare up to the capture's global sign)
+        sgn = 1.0 if np.dot(got[:50000], want[:50000]) > 0 else -1.0
+        big = np.abs(want) > 1e-3
+        assert np.array_equal(np.sign(sgn * got[big]), np.sign(want[big])), ph
+        if sgn > 0:
+            assert rms(s1 - want[len(s0):]) < 3.2e-4, (ph, pol1)
+    assert seen == {1, -1}, seen
+
+
+def test_group_failure_of_one_rank_reaches_every_rank(xa):
+    """A rank whose slice cannot be processed (here: output capacity too small) must not leave its neighbour waiting
+    in the boundary exchange: it goes on exchanging, its status rides in the all-gather, and EVERY rank returns an
+    error from the call."""
+    import threading
+    import torch
+    n, D = 900000, 5
+    x = synth_signal(2 * n, fs_in=6.25e6)
+    dev = torch.device("cuda", 0)
+    xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+    fabric = xa.LocalFabric(2)
+    out = [None, None]
+
+    def rank_main(r):
+        try:
+            g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), r, fabric=fabric)
+            cap = n // D + 1024 if r == 0 else 1000           # rank 1 cannot hold its symbols
+            soft = torch.empty(n // D + 1024, dtype=torch.float32, device=dev)
+            sl = xt[r * n:(r + 1) * n].contiguous()
+            g.process_slice_device(sl.data_ptr(), n, soft.data_ptr(), cap)
+            out[r] = "ok"
+        except Exception as e:          # noqa: BLE001
+            out[r] = str(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert all(not t.is_alive() for t in th), "a rank is still waiting for its failed neighbour"
+    assert out[0] != "ok" and out[1] != "ok", out
+    assert "rank 1" in out[0] and "capacity" in out[1], out
 
 
 def test_group_api_over_rccl_with_one_rank(xa, oracle_mod):

@@ -71,6 +71,8 @@ _SIGNATURES = {
     "xrit_demod_get_stats": (C.c_int, [_vp, C.POINTER(DemodStats)]),
     "xrit_demod_profile": (C.c_int, [_vp, C.c_int]),
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "xrit_demod_prepare_flipped": (C.c_int, [_vp, _vp]),
+    "xrit_demod_redo_clock_flipped": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "xrit_demod_profile_samples": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     "xrit_quantize_i8_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
     "xrit_quantize_i8": (C.c_int, [_vp, _vp, _vp, _sz]),

@@ -1027,7 +1027,7 @@ void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
-    relay.release();
+    relay.release(); alt.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -1049,7 +1049,7 @@ double2 *ClockStage::om_slot(int nb, int BL, double offset)
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
     (void)s;
-    XR_TRY(xbuf.reserve((carry + n + 64 + 16) * sizeof(float2)));
+    XR_TRY(xbuf.reserve((XPAD + carry + n + 64 + 16) * sizeof(float2)));
     *slot = xbase() + carry;
     return XRIT_OK;
 }
@@ -1305,13 +1305,16 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     unconverged = 0;
     large_open = 0;
     max_residual = 0;
+    prev_carry = carry;
+    prev_n = n;
+    redo_ok = false;
     job = Job{};
     Job &j = job;
     j.n = n; j.soft = soft_out; j.sym = sym_out; j.cap = cap;
     j.N = (long long)(carry + n);
     j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
     if (j.N >= (1LL << 31)) { set_error("clock recovery: more than 2^31 samples in one call"); return XRIT_E_INVALID; }
-    XR_TRY(xbuf.reserve((size_t)(j.N + 64 + 16) * sizeof(float2)));
+    if (!xbase_fixed) XR_TRY(xbuf.reserve((size_t)(XPAD + j.N + 64 + 16) * sizeof(float2)));
     float2 *x = xbase();
     if (carry)
         hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, s, tail.as<float2>() + 1024 * cur, x, (int)carry);
@@ -1583,7 +1586,26 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         set_error("clock recovery produced %zu symbols, capacity %zu", last_symbols, job.cap);
         return XRIT_E_CAPACITY;
     }
+    redo_ok = true;
     return XRIT_OK;
+}
+
+__global__ void __launch_bounds__(256) clock_negate_kernel(float2 *__restrict__ x, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { float2 v = x[i]; x[i] = make_float2(-v.x, -v.y); }
+}
+
+// the carried state under the other sign of the stream: the two symbols of history change sign, their slicer
+// decisions (1 where a component is positive) follow; timing (mu, omega) is what it was
+__global__ void clock_flip_state_kernel(ClockState *st)
+{
+    ClockState s = st[0];
+    s.p0 = cf32{-s.p0.x, -s.p0.y};
+    s.p1 = cf32{-s.p1.x, -s.p1.y};
+    s.c0 = cf32{s.p0.x > 0.f ? 1.f : 0.f, s.p0.y > 0.f ? 1.f : 0.f};
+    s.c1 = cf32{s.p1.x > 0.f ? 1.f : 0.f, s.p1.y > 0.f ? 1.f : 0.f};
+    st[0] = s;
 }
 
 int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s,
@@ -1592,6 +1614,61 @@ int ClockStage::run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size
     XR_TRY(begin(n, soft_out, sym_out, cap, s, prof));
     XR_HIP(hipStreamSynchronize(s));
     return finish(n_out, s, prof);
+}
+
+static constexpr size_t CLK_ALT_SLOT = sizeof(ClockState) + 1024 * sizeof(float2);
+
+int ClockStage::redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof)
+{
+    *n_out = 0;
+    if (!redo_ok) { set_error("clock recovery: no finished call to run again"); return XRIT_E_INVALID; }
+    // finish() moved on to the other state / tail slot: back to the one the call started from (untouched since)
+    cur ^= 1;
+    float2 *data = xbuf.as<float2>() + XPAD + (16 - prev_carry % 16) % 16 + prev_carry;     // where the call's input lies
+    const size_t n = prev_n;
+    if (alt_valid) {
+        // the flipped loop's own state (make_alt) in place of this one's
+        XR_HIP(hipMemcpyAsync(st.as<ClockState>() + cur, alt.p, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
+        XR_HIP(hipMemcpyAsync(tail.as<float2>() + 1024 * cur, alt.as<char>() + sizeof(ClockState), 1024 * sizeof(float2),
+                              hipMemcpyDeviceToDevice, s));
+        carry = alt_carry;
+        alt_valid = false;
+    } else {
+        carry = prev_carry;
+        hipLaunchKernelGGL(clock_flip_state_kernel, dim3(1), dim3(1), 0, s, st.as<ClockState>() + cur);
+        if (carry) hipLaunchKernelGGL(clock_negate_kernel, dim3(div_up(carry, 256)), dim3(256), 0, s, tail.as<float2>() + 1024 * cur, carry);
+    }
+    if (n) hipLaunchKernelGGL(clock_negate_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, data, n);
+    XR_HIP(hipGetLastError());
+    xbase_fixed = data - carry;             // (carry <= 1024 = XPAD: never in front of the buffer)
+    const int rc = run(n, soft_out, sym_out, cap, n_out, s, prof);
+    xbase_fixed = nullptr;
+    return rc;
+}
+
+int ClockStage::make_alt(hipStream_t s, Profiler *prof)
+{
+    alt_valid = false;
+    if (!redo_ok) { set_error("clock recovery: no finished call to run again"); return XRIT_E_INVALID; }
+    XR_TRY(alt.reserve(2 * CLK_ALT_SLOT));
+    // this sign's outcome aside ...
+    char *keep = alt.as<char>() + CLK_ALT_SLOT;
+    const size_t carry_keep = carry;
+    XR_HIP(hipMemcpyAsync(keep, st.as<ClockState>() + cur, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
+    XR_HIP(hipMemcpyAsync(keep + sizeof(ClockState), tail.as<float2>() + 1024 * cur, 1024 * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    // ... the call again on its negated input (symbols dropped) ...
+    size_t k = 0;
+    XR_TRY(redo_flipped(nullptr, nullptr, (size_t)1 << 40, &k, s, prof));
+    XR_HIP(hipMemcpyAsync(alt.p, st.as<ClockState>() + cur, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
+    XR_HIP(hipMemcpyAsync(alt.as<char>() + sizeof(ClockState), tail.as<float2>() + 1024 * cur, 1024 * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    alt_carry = carry;
+    // ... and this sign's state back
+    XR_HIP(hipMemcpyAsync(st.as<ClockState>() + cur, keep, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
+    XR_HIP(hipMemcpyAsync(tail.as<float2>() + 1024 * cur, keep + sizeof(ClockState), 1024 * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    carry = carry_keep;
+    alt_valid = true;
+    redo_ok = false;
+    return XRIT_OK;
 }
 
 }  // namespace xrit

@@ -480,6 +480,20 @@ int CostasStage::get_state(float *phase, float *freq, hipStream_t s)
     return XRIT_OK;
 }
 
+__global__ void costas_flip_phase_kernel(float2 *st)
+{
+    float ph = st[0].x;
+    ph = ph > 0.f ? ph - 3.14159265358979323846f : ph + 3.14159265358979323846f;
+    st[0].x = ph;
+}
+
+int CostasStage::flip_phase(hipStream_t s)
+{
+    hipLaunchKernelGGL(costas_flip_phase_kernel, dim3(1), dim3(1), 0, s, state.as<float2>() + cur);
+    XR_HIP(hipGetLastError());
+    return XRIT_OK;
+}
+
 // control block: counters[0..16) = ctl words, per-pass counter slots after it
 
 static inline int *costas_ctl(const DevBuf &b) { return b.as<int>(); }

@@ -413,9 +413,8 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         const size_t worst = (size_t)(((double)length + (double)d->clock.carry) / min_omega) + 2;
         if (worst > cap && length > 0) {
             set_error("output capacity %zu is below the %zu symbols this call may produce (n / (decimation * sps * (1 - omega limit)) + 2)", cap, worst);
-            *n_out = worst;        // the capacity that suffices; nothing has run, the handle is unchanged
-            if (d->pf_count > 0) d->poisoned = true;   // ... unless this call's front end already ran ahead
-            return XRIT_E_CAPACITY;
+            *n_out = worst;        // the capacity that suffices; nothing has been consumed, the handle is unchanged: a front
+            return XRIT_E_CAPACITY;    // end that ran ahead stays queued for the retry with the same (pointer, n, type)
         }
     }
     size_t total_sym = 0, total_len = 0;
@@ -479,6 +478,46 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         set_error("clock hand-off ended with %u boundaries beyond 0.02 sample or with an open symbol slip", large_k);
         return XRIT_E_NOT_CONVERGED;
     }
+    return XRIT_OK;
+}
+
+int xrit_demod_prepare_flipped(xrit_demod *d, void *stream)
+{
+    if (!d) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    int rc = d->clock.make_alt(s, d->prof.enabled ? &d->prof : nullptr);
+    if (rc != XRIT_OK) d->poisoned = true;
+    return rc;
+}
+
+int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft, size_t cap, size_t *n_out, void *stream)
+{
+    if (!d || !n_out || !d_soft) { set_error("null argument"); return XRIT_E_INVALID; }
+    *n_out = 0;
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    float2 *sym = (d->keep_stages || d->keep_symbols) ? d->stage_buf[4].as<float2>() : nullptr;
+    size_t k = 0;
+    // The negated Costas output is the other lock's output to rounding only, which alone moves a float32 M&M by its
+    // 5e-5 .. 1e-4; on top of the tiling's 2.3e-4 the rank sat at 3.2e-4 against the
+    // uninterrupted chain.  Four relay passes (csrc/clock_relay.h, +2 ms per 2^28-sample slice) take the tiling's share
+    // out of the run that is repeated anyway.
+    const int exact_was = d->clock.exact;
+    if (d->clock.exact == 0) d->clock.exact = 4;
+    int rc = d->clock.redo_flipped(d_soft, sym, cap, &k, s, prof);
+    d->clock.exact = exact_was;
+    if (rc == XRIT_OK) rc = d->costas.flip_phase(s);
+    if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+    d->stage_n[4] = k;
+    d->stats.symbols_out = k;
+    d->stats.clock_passes = d->clock.passes;
+    d->stats.clock_relay_passes = d->clock.relay_passes;
+    d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
+    *n_out = k;
     return XRIT_OK;
 }
 

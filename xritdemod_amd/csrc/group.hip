@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
 
 using namespace xrit;
 
@@ -35,8 +36,10 @@ struct Transport {
     // device buffers; the send and the receive of one exchange step are posted together
     virtual int exchange(const void *send, size_t send_bytes, int to, void *recv, size_t recv_bytes, int from,
                          hipStream_t s) = 0;
-    virtual int allgather2(const long long mine[2], long long *all /* [2 * world] */, hipStream_t s) = 0;
+    virtual int allgather2(const long long mine[2], long long *all /* [2 * world] */, hipStream_t s) = 0;   // (a, b) of every rank
     virtual int allreduce_max(double *v, hipStream_t s) = 0;
+    // a rank that cannot go on serving its peers inside a collective call: they must not wait for it for ever
+    virtual void abort() {}
 };
 
 #define XR_NCCL(expr)                                                                   \
@@ -57,6 +60,11 @@ struct RcclTransport : Transport {
     {
         if (comm && owns) (void)ncclCommDestroy(comm);
         scratch.release();
+    }
+    void abort() override
+    {
+        if (comm) (void)ncclCommAbort(comm);      // pending and future operations of every rank on it return an error
+        comm = nullptr;
     }
     int exchange(const void *send, size_t send_bytes, int to, void *recv, size_t recv_bytes, int from,
                  hipStream_t s) override
@@ -100,6 +108,7 @@ struct xrit_local_fabric {
     std::vector<Slot> box;              // box[to]: what rank to-1 offers to rank `to`
     std::vector<long long> gathered;    // 2 * world
     int arrived = 0, generation = 0;
+    bool broken = false;                // a rank gave up inside a collective call: nobody waits any more
     std::vector<double> red;
 };
 
@@ -116,19 +125,24 @@ struct LocalTransport : Transport {
         std::unique_lock<std::mutex> lk(f->m);
         if (to >= 0 && send_bytes) {
             auto &b = f->box[to];
-            f->cv.wait(lk, [&] { return !b.full; });
+            f->cv.wait(lk, [&] { return !b.full || f->broken; });
+            if (f->broken) { set_error("fabric: a rank gave up inside a collective call"); return XRIT_E_INVALID; }
             b.src = send; b.bytes = send_bytes; b.src_dev = device; b.full = true; b.taken = false;
             f->cv.notify_all();
         }
         if (from >= 0 && recv_bytes) {
             auto &b = f->box[rank];
-            f->cv.wait(lk, [&] { return b.full && !b.taken; });
+            f->cv.wait(lk, [&] { return (b.full && !b.taken) || f->broken; });
+            if (f->broken) { set_error("fabric: a rank gave up inside a collective call"); return XRIT_E_INVALID; }
             if (b.bytes != recv_bytes) { set_error("fabric: %zu bytes offered, %zu expected", b.bytes, recv_bytes); return XRIT_E_INVALID; }
             const void *src = b.src;
             const int src_dev = b.src_dev;
             lk.unlock();
-            hipError_t e = src_dev == device ? hipMemcpy(recv, src, recv_bytes, hipMemcpyDeviceToDevice)
-                                             : hipMemcpyPeer(recv, device, src, src_dev, recv_bytes);
+            // on the receiver's stream, and finished before the slot is handed back: a caller-supplied non-blocking
+            // stream is not ordered against the null stream
+            hipError_t e = src_dev == device ? hipMemcpyAsync(recv, src, recv_bytes, hipMemcpyDeviceToDevice, s)
+                                             : hipMemcpyPeerAsync(recv, device, src, src_dev, recv_bytes, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
             lk.lock();
             b.taken = true;
             f->cv.notify_all();
@@ -137,7 +151,8 @@ struct LocalTransport : Transport {
         if (to >= 0 && send_bytes) {
             // the buffer stays ours until the neighbour has copied it
             auto &b = f->box[to];
-            f->cv.wait(lk, [&] { return b.taken; });
+            f->cv.wait(lk, [&] { return b.taken || f->broken; });
+            if (f->broken) { set_error("fabric: a rank gave up inside a collective call"); return XRIT_E_INVALID; }
             b.full = false;
             f->cv.notify_all();
         }
@@ -151,8 +166,9 @@ struct LocalTransport : Transport {
             ++f->generation;
             f->cv.notify_all();
         } else {
-            f->cv.wait(lk, [&] { return f->generation != gen; });
+            f->cv.wait(lk, [&] { return f->generation != gen || f->broken; });
         }
+        if (f->broken) { set_error("fabric: a rank gave up inside a collective call"); return XRIT_E_INVALID; }
         return XRIT_OK;
     }
     int allgather2(const long long mine[2], long long *all, hipStream_t) override
@@ -160,21 +176,25 @@ struct LocalTransport : Transport {
         std::unique_lock<std::mutex> lk(f->m);
         f->gathered[2 * rank] = mine[0];
         f->gathered[2 * rank + 1] = mine[1];
-        rendezvous(lk);
+        XR_TRY(rendezvous(lk));
         for (int i = 0; i < 2 * f->world; ++i) all[i] = f->gathered[i];
-        rendezvous(lk);          // nobody overwrites before everybody has read
-        return XRIT_OK;
+        return rendezvous(lk);          // nobody overwrites before everybody has read
     }
     int allreduce_max(double *v, hipStream_t) override
     {
         std::unique_lock<std::mutex> lk(f->m);
         f->red[rank] = *v;
-        rendezvous(lk);
+        XR_TRY(rendezvous(lk));
         double m = f->red[0];
         for (int i = 1; i < f->world; ++i) m = f->red[i] > m ? f->red[i] : m;
         *v = m;
-        rendezvous(lk);
-        return XRIT_OK;
+        return rendezvous(lk);
+    }
+    void abort() override
+    {
+        std::unique_lock<std::mutex> lk(f->m);
+        f->broken = true;
+        f->cv.notify_all();
     }
 };
 
@@ -185,8 +205,9 @@ struct xrit_group {
     Transport *tr = nullptr;
     int rank = 0, world = 1, device = 0;
     size_t halo = 0;            // input samples taken over from the previous rank
-    DevBuf halo_in, halo_syms, soft_int, tail_out, tail_in, host_in, host_out;
-    std::vector<float> h_halo_syms, h_head, h_prev_tail;
+    DevBuf halo_in, halo_syms, soft_int, tail_out, tail_in, host_in, host_out, zeros, pre_dev;
+    std::vector<float> h_halo_syms, h_head, h_prev_tail, h_pre;
+    unsigned decimation = 1;
 };
 
 namespace {
@@ -232,6 +253,7 @@ int group_finish_create(xrit_group *g, const xrit_demod_config *cfg)
     xrit_demod_config c = *cfg;
     XR_TRY(xrit_demod_create(&c, &g->chain));
     g->device = c.device;
+    g->decimation = c.decimation;
     g->halo = g->world > 1 ? group_halo_samples(c, xrit_demod_sps(g->chain), xrit_demod_decimator_ntaps(g->chain), 24576) : 0;
     return XRIT_OK;
 }
@@ -352,7 +374,7 @@ void xrit_group_destroy(xrit_group *g)
     (void)hipSetDevice(g->device);
     delete g->tr;
     if (g->chain) xrit_demod_destroy(g->chain);
-    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release();
+    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release(); g->zeros.release(); g->pre_dev.release();
     delete g;
 }
 
@@ -369,6 +391,10 @@ int xrit_group_allreduce_max(xrit_group *g, double *value, void *stream)
     return g->tr->allreduce_max(value, stream ? (hipStream_t)stream : (hipStream_t)xrit_demod_stream(g->chain));
 }
 
+// The call is a collective: every rank must reach every exchange and both all-gathers whatever happens to it in
+// between, or its neighbours wait for ever in ncclRecv / ncclAllGather (or in the fabric's condition variable).  So
+// the local work never returns early: a failure is remembered, the rank goes on exchanging (zeros where it has
+// nothing), the status rides in the gathered words, and every rank returns an error after the gather that showed one.
 int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t n, int type, float *d_soft, size_t cap,
                                     size_t *n_out, uint64_t *offset_out, int *polarity_out, void *stream)
 {
@@ -382,95 +408,157 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     const size_t esz = type == XRIT_SAMPLE_FLOATIQ ? 8 : (type == XRIT_SAMPLE_S16IQ ? 4 : 2);
     const int rank = g->rank, world = g->world;
     const size_t H = g->halo;
-    if (world > 1 && n < H) { set_error("slice of %zu samples is shorter than the halo of %zu", n, H); return XRIT_E_INVALID; }
+    const unsigned D = g->decimation;
+    const bool has_next = rank + 1 < world, has_prev = rank > 0;
+    int rc = XRIT_OK;              // this rank's own status
+    std::string why;
+    auto fail = [&](int code) { if (rc == XRIT_OK) { rc = code; why = get_error(); } };
+#define GR_STEP(expr) do { if (rc == XRIT_OK) { int r_ = (expr); if (r_ != XRIT_OK) fail(r_); } } while (0)
+#define GR_HIP(expr) do { if (rc == XRIT_OK) { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e_)); fail(XRIT_E_HIP); } } } while (0)
+    if (world > 1 && n < H) { set_error("slice of %zu samples is shorter than the halo of %zu", n, H); fail(XRIT_E_INVALID); }
+    // (demodulator.cpp:137 drops n mod decimation samples per call: between two ranks that would shift the phase of
+    // the decimator against the uninterrupted stream)
+    if (world > 1 && has_next && D > 1 && n % D) {
+        set_error("slice of %zu samples is not a whole number of decimation periods (%u): the next rank's decimator phase would shift", n, D);
+        fail(XRIT_E_INVALID);
+    }
     // every slice starts from a cold chain: the stream position this rank stopped at is not where this slice begins
     // (a world of one rank is the plain chain: consecutive calls are consecutive pieces of one stream)
-    if (world > 1) XR_TRY(xrit_demod_reset(g->chain, s));
+    if (world > 1) GR_STEP(xrit_demod_reset(g->chain, s));
 
-    // 1. halo: my last H samples to rank + 1, the last H of rank - 1 to me
-    const bool has_next = rank + 1 < world, has_prev = rank > 0;
-    if (has_prev) XR_TRY(g->halo_in.reserve(H * esz + 16));
-    if (world > 1)
-        XR_TRY(g->tr->exchange(has_next ? (const char *)d_samples + (n - H) * esz : nullptr, has_next ? H * esz : 0,
-                               has_next ? rank + 1 : -1, has_prev ? g->halo_in.p : nullptr, has_prev ? H * esz : 0,
-                               has_prev ? rank - 1 : -1, s));
+    // 1. halo: my last H samples to rank + 1, the last H of rank - 1 to me (a rank that failed sends zeros)
+    if (world > 1) {
+        if (has_prev && g->halo_in.reserve(H * esz + 16) != XRIT_OK) fail(XRIT_E_NOMEM);
+        const void *snd = nullptr;
+        if (has_next) {
+            if (rc == XRIT_OK) snd = (const char *)d_samples + (n - H) * esz;
+            else if (g->zeros.reserve(H * esz + 16) == XRIT_OK && hipMemsetAsync(g->zeros.p, 0, H * esz, s) == hipSuccess) snd = g->zeros.p;
+        }
+        // (no buffer at all to send from or to receive into: the peers cannot be served -- the communicator is torn down)
+        if ((has_next && !snd) || (has_prev && !g->halo_in.p)) { g->tr->abort(); set_error("group: out of device memory inside a collective call (%s)", why.c_str()); return XRIT_E_NOMEM; }
+        int xr = g->tr->exchange(snd, has_next ? H * esz : 0, has_next ? rank + 1 : -1, has_prev ? g->halo_in.p : nullptr,
+                                 has_prev ? H * esz : 0, has_prev ? rank - 1 : -1, s);
+        if (xr != XRIT_OK) fail(xr);
+    }
     // 1b. the halo through the chain (cold start); its last symbols are looked at on the host
     const size_t keep = GROUP_TAIL + GROUP_KEEP;
     g->h_halo_syms.clear();
-    if (has_prev) {
+    if (has_prev && rc == XRIT_OK) {
         const size_t hcap = H + 64;
-        XR_TRY(g->halo_syms.reserve(hcap * sizeof(float)));
+        GR_STEP(g->halo_syms.reserve(hcap * sizeof(float)));
         size_t hk = 0;
-        XR_TRY(xrit_demod_process_device(g->chain, g->halo_in.p, H, type, g->halo_syms.as<float>(), hcap, &hk, s));
+        GR_STEP(xrit_demod_process_device(g->chain, g->halo_in.p, H, type, g->halo_syms.as<float>(), hcap, &hk, s));
+        GR_STEP(xrit_demod_prepare_flipped(g->chain, s));       // what the clock recovery would carry on the other sign of the stream
         const size_t take = hk < keep ? hk : keep;
-        g->h_halo_syms.resize(take);
-        if (take)
-            XR_HIP(hipMemcpyAsync(g->h_halo_syms.data(), g->halo_syms.as<float>() + (hk - take), take * sizeof(float),
-                                  hipMemcpyDeviceToHost, s));
+        if (rc == XRIT_OK) g->h_halo_syms.resize(take);
+        if (take) GR_HIP(hipMemcpyAsync(g->h_halo_syms.data(), g->halo_syms.as<float>() + (hk - take), take * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     // 2. the slice
     const size_t icap = cap + 64;
-    XR_TRY(g->soft_int.reserve(icap * sizeof(float)));
+    GR_STEP(g->soft_int.reserve(icap * sizeof(float)));
     size_t k = 0;
-    XR_TRY(xrit_demod_process_device(g->chain, d_samples, n, type, g->soft_int.as<float>(), cap, &k, s));
+    GR_STEP(xrit_demod_process_device(g->chain, d_samples, n, type, g->soft_int.as<float>(), cap, &k, s));
     // 2b. boundary symbols: my last TAIL to rank + 1 (zero padded in front), those of rank - 1 to me
-    XR_TRY(g->tail_out.reserve(GROUP_TAIL * sizeof(float)));
-    XR_TRY(g->tail_in.reserve(GROUP_TAIL * sizeof(float)));
     g->h_prev_tail.clear();
     if (world > 1) {
-        const size_t m = k < (size_t)GROUP_TAIL ? k : (size_t)GROUP_TAIL;
-        XR_HIP(hipMemsetAsync(g->tail_out.p, 0, GROUP_TAIL * sizeof(float), s));
-        if (m)
-            XR_HIP(hipMemcpyAsync(g->tail_out.as<float>() + (GROUP_TAIL - m), g->soft_int.as<float>() + (k - m),
-                                  m * sizeof(float), hipMemcpyDeviceToDevice, s));
-        XR_TRY(g->tr->exchange(has_next ? g->tail_out.p : nullptr, has_next ? GROUP_TAIL * sizeof(float) : 0,
-                               has_next ? rank + 1 : -1, has_prev ? g->tail_in.p : nullptr,
-                               has_prev ? GROUP_TAIL * sizeof(float) : 0, has_prev ? rank - 1 : -1, s));
-        if (has_prev) {
+        if (g->tail_out.reserve(GROUP_TAIL * sizeof(float)) != XRIT_OK || g->tail_in.reserve(GROUP_TAIL * sizeof(float)) != XRIT_OK) {
+            g->tr->abort(); set_error("group: out of device memory inside a collective call"); return XRIT_E_NOMEM;
+        }
+        const size_t m = rc != XRIT_OK ? 0 : (k < (size_t)GROUP_TAIL ? k : (size_t)GROUP_TAIL);
+        (void)hipMemsetAsync(g->tail_out.p, 0, GROUP_TAIL * sizeof(float), s);
+        if (m) GR_HIP(hipMemcpyAsync(g->tail_out.as<float>() + (GROUP_TAIL - m), g->soft_int.as<float>() + (k - m), m * sizeof(float), hipMemcpyDeviceToDevice, s));
+        int xr = g->tr->exchange(has_next ? g->tail_out.p : nullptr, has_next ? GROUP_TAIL * sizeof(float) : 0,
+                                 has_next ? rank + 1 : -1, has_prev ? g->tail_in.p : nullptr,
+                                 has_prev ? GROUP_TAIL * sizeof(float) : 0, has_prev ? rank - 1 : -1, s);
+        if (xr != XRIT_OK) fail(xr);
+        if (has_prev && rc == XRIT_OK) {
             g->h_prev_tail.resize(GROUP_TAIL);
-            XR_HIP(hipMemcpyAsync(g->h_prev_tail.data(), g->tail_in.p, GROUP_TAIL * sizeof(float), hipMemcpyDeviceToHost, s));
+            GR_HIP(hipMemcpyAsync(g->h_prev_tail.data(), g->tail_in.p, GROUP_TAIL * sizeof(float), hipMemcpyDeviceToHost, s));
         }
     }
-    const size_t nhead = k < (size_t)GROUP_KEEP ? k : (size_t)GROUP_KEEP;
-    g->h_head.resize(nhead);
-    if (nhead) XR_HIP(hipMemcpyAsync(g->h_head.data(), g->soft_int.p, nhead * sizeof(float), hipMemcpyDeviceToHost, s));
-    XR_HIP(hipStreamSynchronize(s));
+    auto fetch_head = [&]() {
+        const size_t nhead = k < (size_t)GROUP_KEEP ? k : (size_t)GROUP_KEEP;
+        g->h_head.resize(nhead);
+        if (nhead) GR_HIP(hipMemcpyAsync(g->h_head.data(), g->soft_int.p, nhead * sizeof(float), hipMemcpyDeviceToHost, s));
+        GR_HIP(hipStreamSynchronize(s));
+    };
+    fetch_head();
     int pol_rel = 1, lag = 0;
-    group_align(g->h_prev_tail, g->h_halo_syms, g->h_head, &pol_rel, &lag);
+    if (rc == XRIT_OK) group_align(g->h_prev_tail, g->h_halo_syms, g->h_head, &pol_rel, &lag);
+
+    // 3. every rank's polarity against its predecessor (and status) -> absolute polarity
+    std::vector<long long> all((size_t)2 * world, 0);
+    auto gather = [&](long long a, long long b) -> int {
+        long long mine[2] = {a, b};
+        if (world > 1) return g->tr->allgather2(mine, all.data(), s);
+        all[0] = mine[0]; all[1] = mine[1];
+        return XRIT_OK;
+    };
+    auto peers_ok = [&]() -> bool {     // the gathered second words are status codes
+        for (int r = 0; r < world; ++r)
+            if (all[(size_t)2 * r + 1] != XRIT_OK) {
+                if (rc != XRIT_OK) set_error("%s", why.c_str());
+                else set_error("group: rank %d failed with code %lld; this rank's slice is dropped with it", r, all[(size_t)2 * r + 1]);
+                return false;
+            }
+        return true;
+    };
+    {
+        int gr = gather(pol_rel, rc);
+        if (gr != XRIT_OK) { g->tr->abort(); return gr; }
+        if (!peers_ok()) return rc != XRIT_OK ? rc : XRIT_E_INVALID;
+    }
+    int pol = 1;
+    for (int r = 1; r <= rank; ++r) pol *= (int)all[(size_t)2 * r];
+    // 3b. a rank that locked pi away from the stream: the Mueller & Mueller detector slices to {0, 1}, so the loop on
+    // -y is another loop than minus the loop on y (3e-3 rms in the symbols).  Its clock recovery runs once more, on
+    // the sign-flipped Costas output, from the state it had at the start of the slice: the symbols then come out in
+    // the stream's polarity, to the same floor as any other rank's.
+    if (pol < 0) {
+        GR_STEP(xrit_demod_redo_clock_flipped(g->chain, g->soft_int.as<float>(), cap, &k, s));
+        for (auto &v : g->h_halo_syms) v = -v;
+        fetch_head();
+        int p2 = 1;
+        if (rc == XRIT_OK) group_align(g->h_prev_tail, g->h_halo_syms, g->h_head, &p2, &lag);
+    }
     // lag > 0: rank - 1 already emitted my first `lag` symbols; lag < 0: the -lag symbols before my slice were
     // only emitted here, over the halo
     size_t count = k;
     if (lag > 0) count = k > (size_t)lag ? k - (size_t)lag : 0;
     if (lag < 0) count = k + (size_t)(-lag);
-    if (count > cap) { set_error("group: %zu symbols, capacity %zu", count, cap); return XRIT_E_CAPACITY; }
-    // 3. absolute polarity and offset
-    long long mine[2] = {pol_rel, (long long)count};
-    std::vector<long long> all((size_t)2 * world, 0);
-    if (world > 1) XR_TRY(g->tr->allgather2(mine, all.data(), s));
-    else { all[0] = mine[0]; all[1] = mine[1]; }
-    int pol = 1;
+    if (rc == XRIT_OK && count > cap) { set_error("group: %zu symbols, capacity %zu", count, cap); fail(XRIT_E_CAPACITY); }
+    // 4. counts (and status) -> output offset
+    {
+        int gr = gather((long long)count, rc);
+        if (gr != XRIT_OK) { g->tr->abort(); return gr; }
+        if (!peers_ok()) return rc != XRIT_OK ? rc : XRIT_E_INVALID;
+    }
     unsigned long long offset = 0;
-    for (int r = 1; r <= rank; ++r) pol *= (int)all[(size_t)2 * r];
-    for (int r = 0; r < rank; ++r) offset += (unsigned long long)all[(size_t)2 * r + 1];
-    // the aligned symbols, in the stream's polarity
+    for (int r = 0; r < rank; ++r) offset += (unsigned long long)all[(size_t)2 * r];
+    // the aligned symbols, in the stream's polarity (a rank that ran again already has them so)
+    const float emit = 1.0f;
     size_t pre = 0;
     if (lag < 0) {
         pre = (size_t)(-lag);
         const size_t nh = g->h_halo_syms.size();
-        std::vector<float> tmp(pre);
-        for (size_t i = 0; i < pre; ++i) tmp[i] = (float)pol * g->h_halo_syms[nh - pre + i];
-        XR_HIP(hipMemcpyAsync(d_soft, tmp.data(), pre * sizeof(float), hipMemcpyHostToDevice, s));
-        XR_HIP(hipStreamSynchronize(s));      // tmp goes out of scope
+        XR_TRY(g->pre_dev.reserve(64 * sizeof(float)));
+        g->h_pre.resize(pre);
+        // (halo symbols are in this rank's own polarity, already negated above where it ran again)
+        for (size_t i = 0; i < pre; ++i) g->h_pre[i] = (pol < 0 ? 1.0f : (float)pol) * g->h_halo_syms[nh - pre + i];
+        XR_HIP(hipMemcpyAsync(d_soft, g->h_pre.data(), pre * sizeof(float), hipMemcpyHostToDevice, s));
     }
     const size_t skip = lag > 0 ? (size_t)lag : 0;
     const size_t body = k > skip ? k - skip : 0;
     if (body)
         hipLaunchKernelGGL(group_emit_kernel, dim3(div_up(body, 256)), dim3(256), 0, s, g->soft_int.as<float>() + skip,
-                           d_soft + pre, body, (float)pol);
+                           d_soft + pre, body, emit);
     XR_HIP(hipGetLastError());
+    if (pre) XR_HIP(hipStreamSynchronize(s));       // h_pre is read by the copy until then
     *n_out = count;
     if (offset_out) *offset_out = offset;
     if (polarity_out) *polarity_out = pol;
+#undef GR_STEP
+#undef GR_HIP
     return XRIT_OK;
 }
 

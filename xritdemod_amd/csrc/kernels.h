@@ -141,6 +141,7 @@ struct CostasStage {
     int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
                             // (2 on a locked signal); every surplus pass is ~4 no-op launches of ~5 us
     int get_state(float *phase, float *freq, hipStream_t s);
+    int flip_phase(hipStream_t s);      // the carried phase moves by pi: the other of the loop's two locks
 };
 
 // ---- ClockRecovery (demodulator.cpp:449; Work at :156) --------------------
@@ -158,7 +159,11 @@ struct ClockStage {
     DevBuf xbuf;            // [pad | carry | new] input samples of the call
     // The new samples (the Costas loop's output rows of 128 bytes) start on a 128-byte boundary: the carried tail
     // sits right-aligned in front of it.  Unaligned, every output row straddled two lines (partial-line writes).
-    float2 *xbase() const { return xbuf.as<float2>() + (16 - carry % 16) % 16; }
+    // (XPAD samples of room in front: a call that is run again from another carried state -- redo_flipped -- puts that
+    // state's unread tail in front of the input where it lies)
+    static constexpr size_t XPAD = 1024;
+    float2 *xbase_fixed = nullptr;
+    float2 *xbase() const { return xbase_fixed ? xbase_fixed : xbuf.as<float2>() + XPAD + (16 - carry % 16) % 16; }
     DevBuf st;              // carried ClockState + carry count
     DevBuf S, E, J, om, work, counters, sym, dlin, flags, wsolve, jmean;
     bool jmean_valid = false;         // jmean holds the mean chain Jacobian of an earlier, locked call with ...
@@ -186,6 +191,20 @@ struct ClockStage {
     double om_offset = 0;
     // soft (real parts) and/or complex symbols; either may be null
     int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
+    // The last call once more on its sign-flipped input (one capture across GPUs: this rank's Costas loop turned out
+    // to sit pi away from the stream's, csrc/group.hip): the carried state goes back to what it was before the
+    // call, its history and unread tail change sign, the call's input is negated in place, the recovery runs again.
+    int redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
+    size_t prev_carry = 0, prev_n = 0;      // of the last call
+    bool redo_ok = false;                   // ... which ended normally (its input is still in xbuf)
+    // What the recovery would carry had it run on the sign-flipped stream so far (make_alt(): the last call -- the
+    // halo of a time slice, from a cold start -- is run again on its negated input and the outcome kept aside); a
+    // later redo_flipped() starts from it instead of from the other sign's state with its history negated, whose
+    // timing sits 1e-3 sample off the flipped loop's and takes 1e4..1e5 symbols to come home on the lattice.
+    DevBuf alt;                             // ClockState + 1024 samples of unread tail, twice (the second: scratch)
+    size_t alt_carry = 0;
+    bool alt_valid = false;
+    int make_alt(hipStream_t s, Profiler *prof);
     // the same in two halves (see CostasStage): begin() only enqueues, finish() runs after a stream synchronise
     int begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hipStream_t s, Profiler *prof);
     bool closed() const;

@@ -453,10 +453,16 @@ template <typename P>
 __global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(P p, long long n, const AffMap *aggs,
                                                                                int *ctl, NewtonStat *slots)
 {
-    if (ctl[0] || ctl[NEWTON_CTL_TAKEOVER]) return;
     __shared__ AffMap buf[NEWTON_WAVES_BLOCK];
     __shared__ NewtonStat wst[NEWTON_WAVES_PER_BLOCK];
-    __shared__ int is_last;
+    __shared__ int is_last, skip;
+    // One decision per workgroup: another workgroup of this launch may raise the take-over flag at any time, and waves
+    // of one workgroup that disagree about it would leave the block scan below with missing inputs.  (A workgroup that
+    // saw the flag too late still takes part in the count of finished workgroups; the host goes over to the gated
+    // solve either way.)
+    if (threadIdx.x == 0) skip = ctl[0] || ctl[NEWTON_CTL_TAKEOVER];
+    __syncthreads();
+    if (skip) return;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int w0 = blockIdx.x * NEWTON_WAVES_PER_BLOCK;         // first wave of this workgroup
     const int w = w0 + wib;
