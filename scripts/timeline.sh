@@ -6,7 +6,7 @@ shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/tl_$TAG
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$TAG -o t -- python $R/bench.py --steps 3 --warmup 2 --no-cpu --no-profile "$@" > $R/gpurun_out/tl_$TAG.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$TAG -o t -- python $R/bench.py --steps 3 --warmup 2 --no-cpu --no-profile --no-exact "$@" > $R/gpurun_out/tl_$TAG.log 2>&1
 F=$(find $R/gpurun_out/tl_$TAG -name 't_kernel_trace.csv' | head -1)
 python - "$F" > $R/gpurun_out/timeline_$TAG.txt <<'PY'
 import csv, sys, re

@@ -787,10 +787,22 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
     if (produced < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
 }
 
+// a hand-off pass left the symbols (ClockPassOut): the first chain that ran out of input, from that pass's counts
+__global__ void __launch_bounds__(256) clock_terminal_kernel(const int *__restrict__ nrun, const int *__restrict__ ctl,
+                                                             int *__restrict__ terminal, int K, int NS)
+{
+    if (!ctl[CLK_CTL_SYMBOLS]) return;        // the output pass has found it
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const bool short_ = k < K && nrun[k] < NS;
+    const unsigned long long m = __ballot(short_);
+    if (m && (threadIdx.x & 63) == 0) atomicMin(terminal, k + __builtin_ctzll(m));
+}
+
 // result of the call + the state and the unread tail carried to the next call
 __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *__restrict__ E,
                                                               const int *__restrict__ counts_out,
                                                               const int *__restrict__ nrun,
+                                                              const int *__restrict__ terminal,
                                                               const int *__restrict__ ctl,
                                                               const ClockState *__restrict__ carried_in,
                                                               ClockState *__restrict__ carried_out,
@@ -799,21 +811,10 @@ __global__ void __launch_bounds__(1024) clock_finalize_kernel(const ClockState *
                                                               float2 *__restrict__ tail_out, long long N, int K, int NS)
 {
     __shared__ long long s_ii;
-    __shared__ int s_term;
     // symbols per chain: what the output pass counted, or -- when a hand-off pass left the symbols -- what that pass did
     const int *counts = ctl[CLK_CTL_SYMBOLS] ? nrun : counts_out;
-    if (threadIdx.x == 0) s_term = 0x7fffffff;
-    __syncthreads();
-    // the first chain that ran out of input ends the call
-    int first = 0x7fffffff;
-    for (int k = threadIdx.x; k < K; k += 1024) {      // (no early exit: the loads stay independent of one another)
-        const int c = counts[k];
-        first = (c < NS && k < first) ? k : first;
-    }
-    if (first != 0x7fffffff) atomicMin(&s_term, first);
-    __syncthreads();
     if (threadIdx.x == 0) {
-        int k = s_term;
+        int k = *terminal;
         ClockState s;
         if (k < 0 || k >= K) {
             // no chain reached the end of the input: the chain budget was too small
@@ -1288,7 +1289,9 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         else XR_CLK_OUT(64, 64);
 #undef XR_CLK_OUT_S
 #undef XR_CLK_OUT
-        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.nrun,
+        hipLaunchKernelGGL(clock_terminal_kernel, dim3(div_up((size_t)j.K, 256)), dim3(256), 0, s, j.nrun, clock_ctl(counters),
+                           j.terminal, j.K, NS);
+        hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.nrun, j.terminal,
                            clock_ctl(counters), st_in, st_out, clock_res(counters), x, tail_out, j.N, j.K, NS);
     }
     XR_HIP(hipGetLastError());
