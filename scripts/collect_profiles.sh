@@ -12,8 +12,8 @@ python bench.py --no-prefetch --no-cpu --no-exact > $OUT/bench_c2_noprefetch.jso
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o c2 -- python $R/bench.py --steps 3 --warmup 2 --no-cpu --no-profile --no-exact > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_np -o c2 -- python $R/bench.py --steps 3 --warmup 2 --no-cpu --no-profile --no-exact --no-prefetch > $OUT/stats_np.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c2 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu --no-profile --no-exact --no-prefetch > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c2 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu --no-profile --no-exact --no-prefetch > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c2 -- python $R/bench.py --steps 1 --warmup 3 --no-cpu --no-profile --no-exact --no-prefetch > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c2 -- python $R/bench.py --steps 1 --warmup 3 --no-cpu --no-profile --no-exact --no-prefetch > $OUT/pmc_write.log 2>&1
 cd $R
 scripts/timeline.sh $TAG --no-prefetch > /dev/null 2>&1
 python scripts/timeline_print.py gpurun_out/tl_$TAG/t_kernel_trace.csv > $OUT/timeline.txt 2>&1

@@ -82,7 +82,7 @@ if os.path.exists(fpath) and os.path.exists(wpath):
     tot_f, tot_w = last_burst(f), last_burst(w)
     with open(os.path.join(dst, f"{tag}_c2_pmc_hbm.csv"), "w") as fo:
         fo.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (separate passes), "
-                 "bench.py --steps 1 --warmup 1 --no-prefetch, C2 burst (256 Mi samples): two bursts per run\n")
+                 "bench.py --steps 1 --warmup 3 --no-prefetch, C2 burst (256 Mi samples): four bursts per run\n")
         fo.write("# FETCH_SIZE/WRITE_SIZE are in KiB per dispatch, averaged over the dispatches of the run that did work (the "
                  "passes a batch enqueues beyond the last needed one return at once and are left out).\n")
         fo.write("# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the bytes of a coalesced "
@@ -91,7 +91,7 @@ if os.path.exists(fpath) and os.path.exists(wpath):
         fo.write("kernel,dispatches,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB_raw,hbm_bytes_corrected_per_dispatch\n")
         for k, n, fv, wv, _, _ in rows:
             fo.write(f"{k},{n},{fv:.1f},{wv:.1f},{(2 * fv + wv) * 1024:.0f}\n")
-    names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0", "clock_pass": "clock_pass_kernel<1, 32, 20>",
+    names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0", "clock_pass": "clock_pass_kernel<1, 32, 20, false>", "clock_pass_writing": "clock_pass_kernel<1, 32, 20, true>",
              "clock_pass_jac": "clock_pass_kernel<3, 32, 20>", "costas_pass": "costas_pass_kernel<false>",
              "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0, 3",
              "clock_output": "clock_output_kernel<32, 20, false>"}

@@ -491,7 +491,11 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
             } else {
                 for (int i = 0; i < SS; ++i) {
                     cf32 p = clock_step_ring<WP>(rowp, off, t.table, s, par);
-                    if (OUT) clock_put(orow[i], p);
+                    if (OUT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q == i) clock_put(orow[q], p);
+                    }
                 }
             }
             s.ii = (long long)origin + off;
@@ -502,7 +506,13 @@ __device__ __forceinline__ void clock_substep(const ClockTile &t, const float2 *
             if (alive && (s.ii >= ni || s.ii < 0)) alive = false;
             if (alive) {
                 cf32 p = clock_step_w(reinterpret_cast<const cf32 *>(x) + s.ii, t.table, s, par);
-                if (OUT) clock_put(orow[i], p);
+                if (OUT) {
+                    // (constant indices: orow[i] with a run-time i put the caller's four symbols in scratch memory --
+                    // 48 bytes per lane that the fast path then went through as well)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q == i) clock_put(orow[q], p);
+                }
                 ++produced;
             }
         }
@@ -596,6 +606,8 @@ struct ClockPassOut {
     unsigned long long cap;
     int *valid;          // ctl word: the symbols in soft / sym belong to the end states in E
     int *written;        // per chain: its symbols have been written in this call (a chain that has not runs, dirty or not)
+    float4 *stage;       // soft symbols in the order the waves produce them: [wave of 64 chains][sub-step][lane] -> a wave
+                         // instruction writes 1 KiB of whole lines (clock_unstage_kernel puts them where they belong)
 };
 constexpr int CLK_CTL_SYMBOLS = 13;
 
@@ -663,8 +675,11 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
                                     produced, ps);
             const int nv = produced - before;
             const unsigned long long o = obase + (unsigned long long)j * SS;
-            if (nv == 4 && (NS & 3) == 0 && SS == 4 && o + 3 < po.cap) {
-                if (po.soft) *reinterpret_cast<float4 *>(po.soft + o) = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);
+            // (SS == 4 here, see ClockStage::enqueue_passes.)  Written straight to k * NS + i, a lane's 16 bytes of a
+            // sub-step were a partial line of their own: 64 lines per wave instruction, each touched again 4 us
+            // later -- 226 MB written and 167 MB more fetched for 50 MB of symbols, the pass 70 us longer.
+            if (po.soft && run) po.stage[((size_t)wv * nsub + j) * 64 + lane] = make_float4(ps[0].x, ps[1].x, ps[2].x, ps[3].x);      // (a chain that does not run keeps what an earlier pass staged)
+            if (nv == 4 && (NS & 3) == 0 && o + 3 < po.cap) {
                 if (po.sym) {
                     *reinterpret_cast<float4 *>(po.sym + o) = make_float4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
                     *reinterpret_cast<float4 *>(po.sym + o + 2) = make_float4(ps[2].x, ps[2].y, ps[3].x, ps[3].y);
@@ -673,7 +688,6 @@ __global__ void __launch_bounds__(NV > 1 ? 64 * NV : 512) clock_pass_kernel(cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < nv && o + i < po.cap) {
-                        if (po.soft) po.soft[o + i] = ps[i].x;
                         if (po.sym) po.sym[o + i] = make_float2(ps[i].x, ps[i].y);
                     }
                 }
@@ -785,6 +799,32 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
     E[k] = s;
     counts[k] = produced;
     if (produced < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
+}
+
+// a hand-off pass left the soft symbols in wave order (ClockPassOut::stage): a workgroup takes the 64 chains of one
+// wave -- 64 * NS symbols that are ONE contiguous stretch of the output -- through LDS; both sides whole lines
+__global__ void __launch_bounds__(256) clock_unstage_kernel(const float4 *__restrict__ stage, float *__restrict__ soft,
+                                                            const int *__restrict__ nrun, const int *__restrict__ ctl,
+                                                            unsigned long long cap, int K, int NS)
+{
+    if (!ctl[CLK_CTL_SYMBOLS]) return;        // the output pass wrote the symbols itself
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);          // [64][NS + 1]
+    int *cnt = reinterpret_cast<int *>(tile + 64 * (NS + 1));
+    const int wv = blockIdx.x, nsub = NS / 4;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = wv * 64 + (int)threadIdx.x < K ? nrun[wv * 64 + threadIdx.x] : 0;
+    for (int e = threadIdx.x; e < nsub * 64; e += 256) {
+        const float4 v = stage[(size_t)wv * nsub * 64 + e];
+        const int j = e >> 6, c = e & 63;
+        float *row = tile + c * (NS + 1) + 4 * j;
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    __syncthreads();
+    const unsigned long long base = (unsigned long long)wv * 64 * NS;
+    for (int e = threadIdx.x; e < 64 * NS; e += 256) {
+        const int c = e / NS, i = e - c * NS;
+        if (i < cnt[c] && base + e < cap) soft[base + e] = tile[c * (NS + 1) + i];
+    }
 }
 
 // a hand-off pass left the symbols (ClockPassOut): the first chain that ran out of input, from that pass's counts
@@ -1028,7 +1068,7 @@ void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
-    relay.release(); alt.release();
+    relay.release(); alt.release(); stage.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -1236,8 +1276,9 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
             const bool narrow = (j.STEP >> 16) + 1 <= 20;      // columns a sub-step adds to a ring
             // from the pass the stop test is expected to fire after (what the previous call needed, never before the
             // fourth: ClockPolicy::decide stops no earlier) the passes leave the symbols themselves
-            const bool writes = !jac && !j.relay && p >= j.write_from && (j.SS == 4 || j.SS == 2 || j.SS == 1);
-            const ClockPassOut po{j.soft, j.sym, (unsigned long long)j.cap, clock_ctl(counters) + CLK_CTL_SYMBOLS, j.written};
+            const bool writes = !jac && !j.relay && p >= j.write_from && j.SS == 4 && (NS & 3) == 0;
+            const ClockPassOut po{j.soft, j.sym, (unsigned long long)j.cap, clock_ctl(counters) + CLK_CTL_SYMBOLS, j.written,
+                                  stage.as<float4>()};
             if (jac) XR_CLK_PASS_NV(3, false);
             else if (writes) XR_CLK_PASS_NV(1, true);
             else XR_CLK_PASS_NV(1, false);
@@ -1289,6 +1330,12 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         else XR_CLK_OUT(64, 64);
 #undef XR_CLK_OUT_S
 #undef XR_CLK_OUT
+        if (j.soft && j.SS == 4 && (NS & 3) == 0 && pass_writes) {
+            const size_t lds = (size_t)64 * (NS + 1) * sizeof(float) + 64 * sizeof(int);
+            clock_allow_lds(clock_unstage_kernel, lds);
+            hipLaunchKernelGGL(clock_unstage_kernel, dim3(nw), dim3(256), lds, s, stage.as<float4>(), j.soft, j.nrun,
+                               clock_ctl(counters), (unsigned long long)j.cap, j.K, NS);
+        }
         hipLaunchKernelGGL(clock_terminal_kernel, dim3(div_up((size_t)j.K, 256)), dim3(256), 0, s, j.nrun, clock_ctl(counters),
                            j.terminal, j.K, NS);
         hipLaunchKernelGGL(clock_finalize_kernel, dim3(1), dim3(1024), 0, s, E.as<ClockState>(), j.counts, j.nrun, j.terminal,
@@ -1410,6 +1457,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(J.reserve((size_t)K * sizeof(float4)));
     XR_TRY(flags.reserve((size_t)(4 * K + 4) * sizeof(int)));
+    if (pass_writes) XR_TRY(stage.reserve(((size_t)div_up((size_t)K, 64) * 64 * NS + 64) * sizeof(float)));
     XR_TRY(om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))));
     const int nbK = scan_blocks(K), nbB = scan_blocks(nb);
     const int nbmax = nbK > nbB ? nbK : nbB;

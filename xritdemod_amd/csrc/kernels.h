@@ -236,6 +236,7 @@ struct ClockStage {
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
     DevBuf relay;               // segment records + per-pass counters
+    DevBuf stage;               // soft symbols of a writing hand-off pass, in wave order (ClockPassOut::stage)
     int relay_batch = 96;       // relay passes enqueued before the host looks
     int relay_passes = 0;       // relay passes the last call ran (the closing, change-free one included)
     bool relay_closed = false;  // ... and whether they reproduced the serial trajectory
