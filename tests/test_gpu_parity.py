@@ -102,6 +102,30 @@ def test_fir_straight_line_kernels_are_the_generic_ones_bit_for_bit(xa, oracle_m
     assert len(fast) == sum(n_out) and np.array_equal(fast.view(np.uint32), generic.view(np.uint32))
 
 
+def test_mfma_decimator_experiment_is_bit_identical(xa, oracle_mod, monkeypatch):
+    """XRIT_MFMA_DEC=1 (read when the filter is created): the C2 decimator as a block-Toeplitz product on
+    v_mfma_f32_16x16x4_f32 -- an experiment that is NOT the default (slower: profiles/r3_mfma_decimator.txt) but must stay
+    what it was measured as: the same words as the packed-FMA kernel, across calls and ragged lengths."""
+    o = oracle_mod
+    taps = o.lowpass_taps(1, 6.25e6, 625e3, 100e3)
+    rng = np.random.default_rng(99)
+    n_out = [50003, 5, 0, 4097, 768 * 20]
+    x = (rng.standard_normal(sum(n_out) * 5) + 1j * rng.standard_normal(sum(n_out) * 5)).astype(np.complex64)
+    x[3000:3500] = 0
+
+    def run():
+        f, pos, out = xa.FirFilter(5, taps), 0, []
+        for n in n_out:
+            out.append(f.Work(x[pos:pos + n * 5], n))
+            pos += n * 5
+        return np.concatenate(out)
+
+    valu = run()
+    monkeypatch.setenv("XRIT_MFMA_DEC", "1")
+    mfma = run()
+    assert np.array_equal(valu.view(np.uint32), mfma.view(np.uint32))
+
+
 def test_agc_stage(xa, oracle_mod):
     o = oracle_mod
     rng = np.random.default_rng(11)

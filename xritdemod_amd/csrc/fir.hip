@@ -125,12 +125,17 @@ __device__ __forceinline__ void fir_leave_history(const void *__restrict__ in, c
 // TS > 0 (decimation 1, TS taps -- the chain's 63-tap matched filter): the window walk is straight-line code with
 // all taps in scalar registers.  The generic loop fetches RC rows of taps per eight samples through the scalar
 // cache and waits for them and for its LDS reads three times per iteration: 36 % of the vector rate.
-template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1>
+// MF (matrix-pipe experiment below): the window tile is skewed by 20 samples per 80, so that the 16 groups a wave's
+// ds_read_b64 touches (80 samples = 160 dwords apart: banks 0 / 32 only, 8-way conflicts) sit 200 dwords apart
+// (8 mod 64: two lanes per bank, the minimum for 128 dwords)
+template <bool MF> __device__ __forceinline__ int fir_mf_pos(int q) { return MF ? q + 20 * (q / 80) : q; }
+
+template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1, bool MF = false>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
                  int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af,
-                 float2 *__restrict__ hist_new)
+                 float2 *__restrict__ hist_new, const float *__restrict__ mfb = nullptr)
 {
     // (AGC in the window fill: `in` is the serially produced AGC output if the guard has tripped, else see below)
     if (hist_new != nullptr && blockIdx.x == gridDim.x - 1 && (APL == 0 || af.state_out[1] != 0.0f))
@@ -149,7 +154,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         // interior block: no history, no end of input -> eight loads in flight per lane before the first store
         // (the guarded loop below waits for every single load: ~16 serial memory latencies per block)
         int idx = tid;
-        if (TYPE == XRIT_SAMPLE_FLOATIQ && !PAD && (tile_start & 1) == 0 &&
+        if (TYPE == XRIT_SAMPLE_FLOATIQ && !PAD && !MF && (tile_start & 1) == 0 &&
             (reinterpret_cast<size_t>(in) & 15) == 0) {
             // cf32 input, even start: two samples per 16-byte load / LDS store
             const float4 *in4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(in) + tile_start);
@@ -176,7 +181,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
             v[u] = SampleLoad<TYPE>::at(in, (size_t)(tile_start + idx + u * nthr));                           \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
             const int q = idx + u * nthr;                                                                     \
-            tile[PAD ? q + q / D : q] = v[u];                                                                 \
+            tile[PAD ? q + q / D : fir_mf_pos<MF>(q)] = v[u];                                                 \
         }                                                                                                     \
     }
         XR_TILE_BATCH(8)
@@ -194,7 +199,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
             } else if (j < n_in) {
                 v = SampleLoad<TYPE>::at(in, (size_t)j);
             }
-            int pos = PAD ? idx + idx / D : idx;
+            int pos = PAD ? idx + idx / D : fir_mf_pos<MF>(idx);
             tile[pos] = v;
         }
     }
@@ -212,7 +217,68 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     const int lane_base = PAD ? tid * RC * (D + 1) : tid * RC * D;
     const float2 *w = tile + lane_base;
     // PAD: window index i sits at i + i/D; walk it D samples at a time
-    if (TS > 0) {
+    if (MF) {
+        // EXPERIMENT (round 2's review, item 7): the same sums on the matrix pipe.  A decimating FIR is a block-Toeplitz
+        // product: for 16 groups of 16 consecutive outputs (rows G, columns j; output 16 G + j of the workgroup),
+        //     Y[G][j] = sum_s X[G][s] * H[s][j],   X[G][s] = tile[16 DS G + s],   H[s][j] = g[s - DS j]  (0 outside the filter),
+        // s = 0 .. 15 DS + TS - 1.  v_mfma_f32_16x16x4_f32 accumulates four s per instruction as a k-ordered fmaf chain
+        // (MI355X guide: bitwise a v_fmac loop), i.e. in the window order of the straight-line path; the taps that are
+        // zero for a column add exact zeros.  Same rate as v_pk_fma_f32 (64 FLOP / clk / SIMD), but 15 DS + TS = 226
+        // columns of H for TS = 151 useful ones (1.5 x the multiply-adds), on a pipe nothing else in the chain uses,
+        // with one ds_read_b64 per lane and two MFMAs instead of the VALU path's 76 ds_read2_b64 + 453 FMAs per lane.
+        // Three waves of the workgroup take 256 outputs each (RC = 3, 256 threads: 768 outputs), the fourth waits.
+        // RESULT (round 3, profiles/r3_mfma_decimator.txt): bit-identical to the VALU path (0 differing words over
+        // ragged multi-call runs, test_mfma_decimator_experiment_is_bit_identical) and SLOWER -- 0.82 ms against 0.51 alone
+        // at C2, 1.16 against 0.93 under the loops.  Ablation on 12 Mi outputs: VALU kernel 133 us; this one 203 =
+        // 119 (window fill + epilogue alone) + ~90 (the 114 MFMAs per wave alone: 129 with the stores).  The VALU kernel is
+        // already within 25 % of a pure stream (5.2 TB/s on its bytes) with its arithmetic hidden under other
+        // workgroups' fills; f32 MFMA has the SAME rate as v_pk_fma_f32, the Toeplitz padding makes it 1.5 x the
+        // multiply-adds and a quarter of the waves idle, so the matrix pipe would have to run at > 80 % while the same
+        // waves also wait for their fills: it does not.  Kept behind XRIT_MFMA_DEC=1 as the measured experiment; off.
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        constexpr int KS = (15 * DS + TS + 3) / 4;              // MFMA steps
+        const int wave = tid >> 6, lane = tid & 63;
+        f4 dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 3) {
+            const int gg = lane & 15, kk = lane >> 4;
+            // B: H[4 q + kk][j] for this lane's (kk, j), precomputed on the host (FirStage::init), one coalesced load per step
+            float bt[KS];
+#pragma unroll
+            for (int q = 0; q < KS; ++q) bt[q] = mfb[q * 64 + lane];
+            // A: X[G][4 q + kk] = tile[pos(80 G + 4 q + kk)]: the skew adds 20 samples at s = 80 and s = 160, the same for
+            // every lane (4 q + kk crosses a multiple of 80 only between steps)
+            const float2 *xa = tile + (16 * DS + 20) * (16 * wave + gg) + kk;
+            constexpr int NB = 8;                               // steps per batch: the next batch's reads are in flight
+            float2 xs[2][NB];                                   // under this batch's MFMAs
+#pragma unroll
+            for (int u = 0; u < NB; ++u) xs[0][u] = xa[4 * u + 20 * ((4 * u) / 80)];
+#pragma unroll
+            for (int b = 0; b < (KS + NB - 1) / NB; ++b) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int q = (b + 1) * NB + u;
+                    if (q < KS) xs[(b + 1) & 1][u] = xa[4 * q + 20 * ((4 * q) / 80)];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int q = b * NB + u;
+                    if (q < KS) {
+                        dre = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[b & 1][u].x, bt[q], dre, 0, 0, 0);
+                        dim = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[b & 1][u].y, bt[q], dim, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // every window is dead
+        if (wave < 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[256 * wave + 16 * (4 * (lane >> 4) + r) + (lane & 15)] = make_float2(dre[r], dim[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < RC; ++c) acc[c] = tile[tid * RC + c];
+    } else if (TS > 0) {
         // row 0 of g is the reversed filter, g[i] = h[TS-1-i] (zero behind it); output c takes sample i with tap
         // g[i - c].  Taps sit in scalar registers as aligned pairs and v_pk_fma_f32 broadcasts either half of a
         // pair through op_sel -- written out, because left to itself the compiler builds a (tap, tap) pair per use
@@ -462,6 +528,7 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     // diagnostic switches are read once, here: never on the launch path (a host that calls setenv races with getenv)
     no_static_dec = getenv("XRIT_NO_STATIC_DEC") != nullptr;
     no_static_mf = getenv("XRIT_NO_STATIC_MF") != nullptr;
+    mfma_dec = getenv("XRIT_MFMA_DEC") != nullptr;
     T = ntaps;
     D = decim < 1 ? 1 : decim;
     // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
@@ -500,6 +567,18 @@ int FirStage::init(const float *taps, int ntaps, int decim)
         }
     XR_TRY(g.reserve(rows.size() * sizeof(float)));
     XR_HIP(hipMemcpy(g.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (mfma_dec && T == 151 && D == 5) {
+        // the Toeplitz operand of the matrix-pipe experiment: step q, lane l -> H[4 q + (l >> 4)][l & 15] = g[s - 5 j]
+        const int KS = (15 * 5 + 151 + 3) / 4;
+        std::vector<float> hb((size_t)KS * 64, 0.0f);
+        for (int q = 0; q < KS; ++q)
+            for (int l = 0; l < 64; ++l) {
+                const int sp = 4 * q + (l >> 4) - 5 * (l & 15);
+                if (sp >= 0 && sp < T) hb[(size_t)q * 64 + l] = rows[(size_t)sp];
+            }
+        XR_TRY(mfb.reserve(hb.size() * sizeof(float)));
+        XR_HIP(hipMemcpy(mfb.p, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     // block size: keep the LDS window under 64 KiB
     threads = 256;
     for (;;) {
@@ -548,6 +627,7 @@ bool FirStage::stat_supported(int statL) const
 void FirStage::release()
 {
     g.release();
+    mfb.release();
     hist[0].release();
     hist[1].release();
 }
@@ -564,7 +644,12 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
                        out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
                        f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
-    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
+    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && f.mfma_dec && f.threads == 256)
+        hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5, (RC == 3 && !PAD)>), dim3(blocks),
+                           dim3(f.threads), f.lds_bytes + (f.tile_len / 80 + 1) * 20 * 8, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
+                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr,
+                           f.mfb.as<float>());
+    else if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
                            f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);

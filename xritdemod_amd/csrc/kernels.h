@@ -11,11 +11,13 @@ namespace xrit {
 struct FirStage {
     int T = 0, D = 1, RC = 3, W = 0, Wpad = 0, threads = 256, tile_len = 0, cur = 0;
     bool pad = false;
+    bool mfma_dec = false;      // XRIT_MFMA_DEC=1: the C2 decimator on the matrix pipe (experiment, fir.hip)
     bool no_static_dec = false, no_static_mf = false;   // XRIT_NO_STATIC_DEC / XRIT_NO_STATIC_MF, read once in init (A/B runs)
     bool poly = false;   // polyphase kernel (lanes = phases) for decimation 16 / 32 / 64
     static constexpr int POLY_PR = 16, POLY_NQ = 32;     // outputs per lane group, taps per phase (T <= 32 * D)
     size_t lds_bytes = 0;
     DevBuf g;        // RC x Wpad window taps (polyphase: D x POLY_NQ phase taps)
+    DevBuf mfb;      // matrix-pipe experiment: the Toeplitz tap operand, one float per (step, lane)
     DevBuf hist[2];  // T-1 samples of history (ping-pong)
     int init(const float *taps, int ntaps, int decim);
     int reset(hipStream_t s);     // zero history, as after construction (no reallocation)
