@@ -354,14 +354,17 @@ int    xrit_group_rank(const xrit_group *g);
 int    xrit_group_world(const xrit_group *g);
 size_t xrit_group_halo_samples(const xrit_group *g);
 /* Collective: every rank passes ITS slice (n samples, device resident, slices in
- * rank order make up the burst; n >= the halo, and a whole number of decimation
- * periods for every rank but the last) and receives its symbols in the stream's
+ * rank order make up the burst; n >= the halo and a whole number of decimation
+ * periods) and receives its symbols in the stream's
  * polarity with their offset in the burst's symbol sequence: rank r's symbols are
  * out[offset .. offset + n_out) of what one chain would emit for the whole burst
  * (to the clock recovery's floor: a rank whose Costas loop locked pi away from
  * rank 0's runs its clock recovery once more on the sign-flipped stream, so both
- * locks end at the same floor).  The chain of every rank restarts cold per call:
- * consecutive calls are consecutive bursts only in the sense of rank 0.
+ * locks end at the same floor).  Consecutive calls are consecutive bursts of ONE
+ * capture: the last rank keeps the end of its slice and hands it to rank 0 at the
+ * start of the next call (the exchanges become a ring), so rank 0 warms up over a
+ * halo like every other rank; xrit_group_restart() begins a new capture (as does
+ * a failed call).  Every slice must be a whole number of decimation periods.
  * A failure on one rank (capacity, a stage that did not converge in strict mode,
  * HIP) is carried to every rank in the all-gather: every rank returns an error
  * from the same call and nobody is left waiting in an exchange; a rank that
@@ -373,6 +376,7 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
 int xrit_group_process_slice_host(xrit_group *g, const void *samples, size_t n_complex, int sample_type, float *soft_out,
                                   size_t cap, size_t *n_out, uint64_t *offset_out, int *polarity_out);
 /* max over the ranks (timing: the slowest rank's seconds) */
+int xrit_group_restart(xrit_group *g);   /* the next slice call is a capture's first (every rank calls it) */
 int xrit_group_allreduce_max(xrit_group *g, double *value, void *stream);
 
 /* ------------------------------------------------------------------------

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "xrit_demod_get_stats": (C.c_int, [_vp, C.POINTER(DemodStats)]),
     "xrit_demod_profile": (C.c_int, [_vp, C.c_int]),
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "xrit_group_restart": (C.c_int, [_vp]),
     "xrit_demod_prepare_flipped": (C.c_int, [_vp, _vp]),
     "xrit_demod_redo_clock_flipped": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "xrit_demod_profile_samples": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
@@ -489,6 +490,10 @@ class Group(_Handle):
                                                      C.c_void_p(d_soft_ptr), cap, C.byref(n_out), C.byref(off),
                                                      C.byref(pol), C.c_void_p(stream) if stream else None))
         return n_out.value, off.value, pol.value
+
+    def restart(self):
+        """The next slice call is a capture's first (rank 0 starts cold, nothing is taken over from the last rank)."""
+        _check(lib().xrit_group_restart(self._h))
 
     def allreduce_max(self, value, stream=None):
         v = C.c_double(value)

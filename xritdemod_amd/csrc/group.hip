@@ -208,6 +208,12 @@ struct xrit_group {
     DevBuf halo_in, halo_syms, soft_int, tail_out, tail_in, host_in, host_out, zeros, pre_dev;
     std::vector<float> h_halo_syms, h_head, h_prev_tail, h_pre;
     unsigned decimation = 1;
+    // streaming: consecutive calls are consecutive bursts of ONE capture.  The last rank keeps the end of its slice
+    // (halo samples, boundary symbols in the stream's polarity) and hands it to rank 0 at the start of the next call --
+    // the exchanges become a ring -- so that rank 0 warms up over a halo like every other rank instead of starting cold
+    // in the middle of the stream.
+    unsigned long long calls = 0;       // slice calls of this capture that succeeded
+    DevBuf keep_halo, keep_tail;
 };
 
 namespace {
@@ -374,7 +380,7 @@ void xrit_group_destroy(xrit_group *g)
     (void)hipSetDevice(g->device);
     delete g->tr;
     if (g->chain) xrit_demod_destroy(g->chain);
-    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release(); g->zeros.release(); g->pre_dev.release();
+    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release(); g->zeros.release(); g->pre_dev.release(); g->keep_halo.release(); g->keep_tail.release();
     delete g;
 }
 
@@ -382,6 +388,13 @@ xrit_demod *xrit_group_chain(xrit_group *g) { return g ? g->chain : nullptr; }
 int xrit_group_rank(const xrit_group *g) { return g ? g->rank : -1; }
 int xrit_group_world(const xrit_group *g) { return g ? g->world : 0; }
 size_t xrit_group_halo_samples(const xrit_group *g) { return g ? g->halo : 0; }
+
+int xrit_group_restart(xrit_group *g)
+{
+    if (!g) { set_error("null argument"); return XRIT_E_INVALID; }
+    g->calls = 0;        // the next slice call begins a new capture (collective by convention: every rank calls it)
+    return XRIT_OK;
+}
 
 int xrit_group_allreduce_max(xrit_group *g, double *value, void *stream)
 {
@@ -409,7 +422,10 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     const int rank = g->rank, world = g->world;
     const size_t H = g->halo;
     const unsigned D = g->decimation;
-    const bool has_next = rank + 1 < world, has_prev = rank > 0;
+    const bool ring = world > 1 && g->calls > 0;                      // (every rank counts the same calls)
+    const bool has_next = rank + 1 < world || ring, has_prev = rank > 0 || ring;
+    const int to = rank + 1 < world ? rank + 1 : 0, from = rank > 0 ? rank - 1 : world - 1;
+    const bool wrap_send = ring && rank + 1 == world;                 // the last rank sends what it kept of the call before
     int rc = XRIT_OK;              // this rank's own status
     std::string why;
     auto fail = [&](int code) { if (rc == XRIT_OK) { rc = code; why = get_error(); } };
@@ -418,8 +434,8 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     if (world > 1 && n < H) { set_error("slice of %zu samples is shorter than the halo of %zu", n, H); fail(XRIT_E_INVALID); }
     // (demodulator.cpp:137 drops n mod decimation samples per call: between two ranks that would shift the phase of
     // the decimator against the uninterrupted stream)
-    if (world > 1 && has_next && D > 1 && n % D) {
-        set_error("slice of %zu samples is not a whole number of decimation periods (%u): the next rank's decimator phase would shift", n, D);
+    if (world > 1 && D > 1 && n % D) {
+        set_error("slice of %zu samples is not a whole number of decimation periods (%u): the next slice's decimator phase would shift", n, D);
         fail(XRIT_E_INVALID);
     }
     // every slice starts from a cold chain: the stream position this rank stopped at is not where this slice begins
@@ -431,13 +447,14 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
         if (has_prev && g->halo_in.reserve(H * esz + 16) != XRIT_OK) fail(XRIT_E_NOMEM);
         const void *snd = nullptr;
         if (has_next) {
-            if (rc == XRIT_OK) snd = (const char *)d_samples + (n - H) * esz;
+            if (wrap_send) snd = g->keep_halo.p;
+            else if (rc == XRIT_OK) snd = (const char *)d_samples + (n - H) * esz;
             else if (g->zeros.reserve(H * esz + 16) == XRIT_OK && hipMemsetAsync(g->zeros.p, 0, H * esz, s) == hipSuccess) snd = g->zeros.p;
         }
         // (no buffer at all to send from or to receive into: the peers cannot be served -- the communicator is torn down)
         if ((has_next && !snd) || (has_prev && !g->halo_in.p)) { g->tr->abort(); set_error("group: out of device memory inside a collective call (%s)", why.c_str()); return XRIT_E_NOMEM; }
-        int xr = g->tr->exchange(snd, has_next ? H * esz : 0, has_next ? rank + 1 : -1, has_prev ? g->halo_in.p : nullptr,
-                                 has_prev ? H * esz : 0, has_prev ? rank - 1 : -1, s);
+        int xr = g->tr->exchange(snd, has_next ? H * esz : 0, has_next ? to : -1, has_prev ? g->halo_in.p : nullptr,
+                                 has_prev ? H * esz : 0, has_prev ? from : -1, s);
         if (xr != XRIT_OK) fail(xr);
     }
     // 1b. the halo through the chain (cold start); its last symbols are looked at on the host
@@ -467,9 +484,11 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
         const size_t m = rc != XRIT_OK ? 0 : (k < (size_t)GROUP_TAIL ? k : (size_t)GROUP_TAIL);
         (void)hipMemsetAsync(g->tail_out.p, 0, GROUP_TAIL * sizeof(float), s);
         if (m) GR_HIP(hipMemcpyAsync(g->tail_out.as<float>() + (GROUP_TAIL - m), g->soft_int.as<float>() + (k - m), m * sizeof(float), hipMemcpyDeviceToDevice, s));
-        int xr = g->tr->exchange(has_next ? g->tail_out.p : nullptr, has_next ? GROUP_TAIL * sizeof(float) : 0,
-                                 has_next ? rank + 1 : -1, has_prev ? g->tail_in.p : nullptr,
-                                 has_prev ? GROUP_TAIL * sizeof(float) : 0, has_prev ? rank - 1 : -1, s);
+        // (boundary symbols travel in the polarity their rank computed them in, except the last rank's kept ones, which
+        // are in the stream's: rank 0 then reads its ABSOLUTE polarity off them)
+        int xr = g->tr->exchange(has_next ? (wrap_send ? g->keep_tail.p : g->tail_out.p) : nullptr, has_next ? GROUP_TAIL * sizeof(float) : 0,
+                                 has_next ? to : -1, has_prev ? g->tail_in.p : nullptr,
+                                 has_prev ? GROUP_TAIL * sizeof(float) : 0, has_prev ? from : -1, s);
         if (xr != XRIT_OK) fail(xr);
         if (has_prev && rc == XRIT_OK) {
             g->h_prev_tail.resize(GROUP_TAIL);
@@ -506,10 +525,10 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     {
         int gr = gather(pol_rel, rc);
         if (gr != XRIT_OK) { g->tr->abort(); return gr; }
-        if (!peers_ok()) return rc != XRIT_OK ? rc : XRIT_E_INVALID;
+        if (!peers_ok()) { g->calls = 0; return rc != XRIT_OK ? rc : XRIT_E_INVALID; }
     }
     int pol = 1;
-    for (int r = 1; r <= rank; ++r) pol *= (int)all[(size_t)2 * r];
+    for (int r = 0; r <= rank; ++r) pol *= (int)all[(size_t)2 * r];      // (rank 0: +1 on a capture's first call)
     // 3b. a rank that locked pi away from the stream: the Mueller & Mueller detector slices to {0, 1}, so the loop on
     // -y is another loop than minus the loop on y (3e-3 rms in the symbols).  Its clock recovery runs once more, on
     // the sign-flipped Costas output, from the state it had at the start of the slice: the symbols then come out in
@@ -531,7 +550,7 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     {
         int gr = gather((long long)count, rc);
         if (gr != XRIT_OK) { g->tr->abort(); return gr; }
-        if (!peers_ok()) return rc != XRIT_OK ? rc : XRIT_E_INVALID;
+        if (!peers_ok()) { g->calls = 0; return rc != XRIT_OK ? rc : XRIT_E_INVALID; }
     }
     unsigned long long offset = 0;
     for (int r = 0; r < rank; ++r) offset += (unsigned long long)all[(size_t)2 * r];
@@ -554,6 +573,16 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
                            d_soft + pre, body, emit);
     XR_HIP(hipGetLastError());
     if (pre) XR_HIP(hipStreamSynchronize(s));       // h_pre is read by the copy until then
+    // the last rank keeps what rank 0 needs to go on from here in the next call
+    if (world > 1 && rank + 1 == world) {
+        XR_TRY(g->keep_halo.reserve(H * esz + 16));
+        XR_TRY(g->keep_tail.reserve(GROUP_TAIL * sizeof(float)));
+        XR_HIP(hipMemcpyAsync(g->keep_halo.p, (const char *)d_samples + (n - H) * esz, H * esz, hipMemcpyDeviceToDevice, s));
+        const size_t m = count < (size_t)GROUP_TAIL ? count : (size_t)GROUP_TAIL;
+        XR_HIP(hipMemsetAsync(g->keep_tail.p, 0, GROUP_TAIL * sizeof(float), s));
+        if (m) XR_HIP(hipMemcpyAsync(g->keep_tail.as<float>() + (GROUP_TAIL - m), d_soft + (count - m), m * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    g->calls += 1;
     *n_out = count;
     if (offset_out) *offset_out = offset;
     if (polarity_out) *polarity_out = pol;
