@@ -345,6 +345,46 @@ def test_exact_walker_from_global_memory(xa, oracle_mod, lrit_1m, monkeypatch):
         assert len(so) == len(sg) and np.array_equal(so.view(np.uint32), sg.view(np.uint32))
 
 
+def test_exact_closure_edge_cases(xa):
+    """Against the serial wave, word for word: samples-per-symbol too large for the walker's LDS ring (21 and 68: the
+    one-wave walker on global memory; the tiled evaluation on its own uses up its pass budget there and, at 68, miscounts
+    by a symbol -- the relay runs from its start states all the same), empty / tiny / ragged calls of one stream, kept
+    stages (complex symbols), HRIT with a decimator and s16 ingest."""
+    def pair(mode, fs, D):
+        return (xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)),
+                xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=1)))
+
+    def same(a, b):
+        return len(a) == len(b) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+    for fs in (6.25e6, 20e6):
+        x = synth.generate(synth.SynthParams(fs_in=fs), 2000000)
+        s, e = pair("lrit", fs, 1)
+        for a, b in ((0, 700001), (700001, 2000000)):
+            assert same(s.process(x[a:b]), e.process(x[a:b])), (fs, a)
+            assert e.stats().clock_relay_closed == 1
+    x = synth_signal(1200000, fs_in=6.25e6)
+    s, e = pair("lrit", 6.25e6, 5)
+    cuts = [0, 0, 7, 40, 45, 300, 5000, 5005, 70000, 70000, 400000, 400020, 1200000]
+    tot = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ys, ye = s.process(x[a:b]), e.process(x[a:b])
+        assert same(ys, ye), (a, b)
+        tot += len(ye)
+    assert tot > 56000
+    s, e = pair("lrit", 6.25e6, 5)
+    s.keep_stages(True)
+    e.keep_stages(True)
+    ys, ye = s.process(x), e.process(x)
+    ce = e.stage("clock")
+    assert same(ys, ye) and np.array_equal(s.stage("clock").view(np.uint32), ce.view(np.uint32)) and np.array_equal(ce.real, ye)
+    xh = synth.generate(synth.SynthParams(fs_in=12.5e6, symbol_rate=927000.0, alpha=0.3), 1500000)
+    xi = np.clip(np.round(xh.view(np.float32) * 32768), -32768, 32767).astype(np.int16)
+    s, e = pair("hrit", 12.5e6, 5)
+    for a, b in ((0, 600000), (600000, 600010), (600010, 1500000)):
+        assert same(s.process(xi[2 * a:2 * b], 1), e.process(xi[2 * a:2 * b], 1)), (a, b)
+
+
 def test_partial_relay_trades_passes_for_parity(xa):
     """cfg.clock_exact = n > 1 stops after n relay passes: every pass lets every segment know one more segment of its
     own past, so the distance to the serial trajectory falls with n and is zero once a pass changes nothing."""

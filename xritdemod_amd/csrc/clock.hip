@@ -1118,9 +1118,9 @@ __global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelayS
                                                                     ClockState *__restrict__ carried_out,
                                                                     ClockResult *__restrict__ res,
                                                                     const float2 *__restrict__ x,
-                                                                    float2 *__restrict__ tail_out, long long N, int *ctl)
+                                                                    float2 *__restrict__ tail_out, long long N, int *ctl, int force)
 {
-    if (!ctl[0]) return;        // the tiled hand-off did not close in its batch: ClockStage::finish starts over
+    if (!ctl[0] && !force) return;      // the tiled hand-off did not close in its batch: ClockStage::finish starts over
     __shared__ int s_term, s_buf;
     __shared__ long long s_ii;
     if (threadIdx.x == 0) {
@@ -1213,7 +1213,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
         if (a.q_mu < 1) a.q_mu = 1;
     }
     a.soft = j.soft; a.sym = j.sym; a.cap = (unsigned long long)j.cap; a.par = par;
-    a.changed = changed; a.ctl = clock_ctl(counters);
+    a.changed = changed; a.ctl = j.relay_force ? nullptr : clock_ctl(counters);
     if (restart) {
         j.relay_enq = 0;
         const int words = 4 * (limit + 2) > j.G ? 4 * (limit + 2) : j.G;
@@ -1233,7 +1233,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
         }
         hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(1024), 0, s, a.ends[0], a.ends[1], changed,
                            j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
-                           clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters));
+                           clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), j.relay_force ? 1 : 0);
     }
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1536,6 +1536,9 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
             XR_HIP(hipStreamSynchronize(s));
         }
+        // (a hand-off that used up its pass budget without closing -- ctl[0] still 0 -- is relayed all the same: the
+        // walkers need start states, not a closed hand-off)
+        job.relay_force = hctl[0] == 0;
         if (job.relay && job.K > 1) XR_TRY(enqueue_relay(relay_batch, true, s, prof));
         else XR_TRY(enqueue_output(s, prof, true));
         XR_HIP(hipStreamSynchronize(s));
@@ -1543,7 +1546,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     relay_passes = 0;
     relay_closed = false;
     relay_auto = false;
-    if (exact == 0 && job.K > 1 && hctl[0] != 0) {
+    if (exact == 0 && job.K > 1) {
         // The hand-off passes normally stall at the recurrence's own floor, an rms residual of ~1e-4 sample (Es/N0 12 dB).
         // At low Es/N0 they stall at 5e-4 .. 1e-3 instead -- every wrong decision kicks mu by 2e-3 -- and which
         // near-zero symbols then fall on the other side differs from the serial loop (a third
@@ -1552,8 +1555,11 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         float q;
         memcpy(&q, &hctl[4], sizeof q);
         const int open_ = hctl[6];
-        if (open_ > 0 && q > auto_rms * auto_rms * (float)open_) {
+        // (... and a hand-off that never closed at all -- the pass budget ran out on an acquisition -- has every reason
+        // to be walked: the relay needs start states, not a closed hand-off)
+        if (hctl[0] == 0 || (open_ > 0 && q > auto_rms * auto_rms * (float)open_)) {
             job.relay = relay_auto = true;
+            job.relay_force = hctl[0] == 0;
             XR_TRY(relay_plan());
             XR_TRY(enqueue_relay(relay_batch, true, s, prof));
             XR_HIP(hipStreamSynchronize(s));

@@ -62,7 +62,7 @@ struct RelayArgs {
     int q_om, q_mu;               // lattice steps of omega and of mu + omega, in units of 2^-24 sample
     unsigned *changed;            // [4 * pass] segments whose start changed in that pass, [+1] steps, [+2] symbols walked,
                                   // [+3] slowest walker (steps << 12 | segment) or a watchdog mark
-    const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed
+    const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed (null: do not ask)
 };
 
 __device__ __forceinline__ bool relay_same_state(const ClockState &a, const ClockState &b)
@@ -126,7 +126,8 @@ constexpr int RELAY_ROUNDS = 4;      // guess rounds per step at most
 template <bool SYM, bool RING>
 __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs a, int pass, int span)
 {
-    if (!a.ctl[0]) return;                                       // the tiled hand-off has not closed: nothing to refine yet
+    if (a.ctl && !a.ctl[0]) return;                              // the tiled hand-off has not closed: nothing to refine yet
+                                                                 // (null: it never will -- pass budget used up -- go anyway)
     if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;      // closed in an earlier pass
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
     __shared__ cf32 xr[RING ? RELAY_RX : 1];

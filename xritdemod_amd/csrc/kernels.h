@@ -224,6 +224,7 @@ struct ClockStage {
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr, *written = nullptr;
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
         bool relay = false;                     // ... is on for this call
+        bool relay_force = false;               // ... although the tiled hand-off never closed (pass budget used up)
         int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
     } job;
     bool pass_writes = true;    // the last hand-off pass is the output pass (XRIT_NO_PASS_OUTPUT=1, read at init: a separate output pass)
