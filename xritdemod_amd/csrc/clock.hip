@@ -1529,7 +1529,10 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     const int *hctl = reinterpret_cast<const int *>(h_res);
     const bool in_batch = closed();
     if (!in_batch) {
-        while (hctl[0] == 0 && job.enqueued < max_passes) {
+        // (past 48 passes a hand-off that is still open is an acquisition that closes a chain or two per pass: unless
+        // the exact closure is switched off the relay takes over -- it walks from whatever start states there are)
+        const int give_up = exact >= 0 && max_passes > 48 ? 48 : max_passes;
+        while (hctl[0] == 0 && job.enqueued < give_up) {
             // a boundary outside the trust region (acquisition, a slip): from here on the gated three-launch solve
             if (hctl[NEWTON_CTL_TAKEOVER]) job.gated = true;
             XR_TRY(enqueue_passes(4, s, prof));
