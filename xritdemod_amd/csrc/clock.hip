@@ -187,6 +187,7 @@ struct ClockPolicy {
     float trust_t, trust_w, tol_t, tol_w;
     int min_passes;
     const float4 *jmean;  // not null: every chain takes the stream's mean Jacobian (ClockStage::begin)
+    float floor_sq;       // mean squared residual (samples^2) at which a hand-off counts as being at the recurrence's floor
 
     struct Elem { ClockState e, s; float4 j; int nrun; };
     __device__ float4 jac_of(long long k) const { return jmean ? jmean[0] : J[k]; }
@@ -278,7 +279,7 @@ struct ClockPolicy {
         int memo = ctl[7];
         if (ctl[1] >= 3 && large != 0) memo |= 0x100;
         const bool acquiring = (memo & 0x100) != 0;
-        const bool above_floor = open_ != 0u && (acquiring || q > 9e-8f * (float)open_);
+        const bool above_floor = open_ != 0u && (acquiring || q > floor_sq * (float)open_);
         const bool freezing = above_floor && open_prev != 0x7fffffff && (long long)open_prev - (long long)open_ >= 1 &&
                               200ll * ((long long)open_prev - (long long)open_) >= (long long)open_prev;
         // With a few thousand boundaries or fewer the summed residual is a noisy statistic (a handful of boundaries
@@ -1244,7 +1245,11 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
     const Job &j = job;
     ClockPolicy pol{S.as<ClockState>(), E.as<ClockState>(), J.as<float4>(), j.dirty, j.nrun, nullptr,
-                    0.75f, 0.01f, tol_t, tol_w, min_passes, j.mean_j ? jmean.as<float4>() : nullptr};
+                    0.75f, 0.01f, tol_t, tol_w, min_passes, j.mean_j ? jmean.as<float4>() : nullptr,
+                    // (3e-4 sample rms at the 2.7 .. 4.25 samples per symbol the rule was tuned at; the floor is a
+                    // fraction of a SYMBOL: at 21 or 68 samples per symbol it sits that much higher in samples, and
+                    // calls there went on freezing a few boundaries per pass for 185 passes)
+                    9e-8f * (sps > 4.2534f ? (sps / 4.2534f) * (sps / 4.2534f) : 1.0f)};
     const unsigned nw = div_up((size_t)j.K, 64);              // waves of 64 chains
     const float2 *x = xbase();
     // wave-aligned solve (newton.h): the pass leaves its waves' aggregates, one more launch applies them;
