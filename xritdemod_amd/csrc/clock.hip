@@ -1041,6 +1041,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     carry = 0;
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
+    relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
     pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
@@ -1179,6 +1180,7 @@ int ClockStage::relay_plan()
     j.cps = cps;
     j.G = (j.K + cps - 1) / cps;
     XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)relay_limit() + 8) * 4 * sizeof(unsigned)));
+    if (!relay_no_rec) XR_TRY(relay_rec.reserve((size_t)j.G * cps * NS * sizeof(unsigned)));
     relay_segments = j.G;
     relay_seg_chains = cps;
     return XRIT_OK;
@@ -1215,6 +1217,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     }
     a.soft = j.soft; a.sym = j.sym; a.cap = (unsigned long long)j.cap; a.par = par;
     a.changed = changed; a.ctl = j.relay_force ? nullptr : clock_ctl(counters);
+    a.rec = relay_no_rec ? nullptr : relay_rec.as<unsigned>();
     if (restart) {
         j.relay_enq = 0;
         const int words = 4 * (limit + 2) > j.G ? 4 * (limit + 2) : j.G;
@@ -1590,6 +1593,18 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
                         hc[4 * p], job.G, hc[4 * p + 1], hc[4 * p + 2], hc[4 * p + 1] ? (double)hc[4 * p + 2] / hc[4 * p + 1] : 0.0,
                         hc[4 * p + 3] >> 12, hc[4 * p + 3] & 0xfff);
         }
+#ifdef XRIT_RELAY_TIMING
+        if (trace_env) {
+            unsigned long long hd[16] = {0}, z[16] = {0};
+            XR_HIP(hipMemcpyFromSymbol(hd, HIP_SYMBOL(relay_dbg), sizeof hd));
+            XR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z));
+            for (int o = 0; o < 16; o += 8) {
+                const double st = hd[o + 6] ? (double)hd[o + 6] : 1.0;
+                fprintf(stderr, "[xrit] relay walker cycles per step, passes %s: wait %.0f, setup %.0f, rounds %.0f, verify %.0f, commit %.0f, loop head %.0f (%llu steps)\n",
+                        o ? ">= 8" : "< 8", hd[o] / st, hd[o + 1] / st, hd[o + 2] / st, hd[o + 3] / st, hd[o + 4] / st, hd[o + 5] / st, hd[o + 6]);
+            }
+        }
+#endif
         const int want = relay_passes + relay_passes / 4 + 8;
         relay_batch = want < 32 ? 32 : (want > 4096 ? 4096 : want);
     }

@@ -28,6 +28,10 @@
 //    next block starts from the literal result.  Lane 0 always starts from the walker's own state.
 //  * The samples are streamed into an LDS ring by a second wave of the workgroup that runs ahead of the walker
 //    (the walker itself reads LDS only and issues stores nobody waits for).
+//  * A segment that is walked again (its start moved by a few lattice units) meets the same arms and read indices
+//    as the walk before in all but ~1 % of its symbols: every walk leaves (index, arm) per symbol, the prefetching
+//    wave streams the record of the walk before into a second LDS ring, and the lanes take THAT as their first
+//    guess -- one round settles most blocks instead of two or three.
 #pragma once
 
 #include "kernels.h"
@@ -63,6 +67,8 @@ struct RelayArgs {
     unsigned *changed;            // [4 * pass] segments whose start changed in that pass, [+1] steps, [+2] symbols walked,
                                   // [+3] slowest walker (steps << 12 | segment) or a watchdog mark
     const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed (null: do not ask)
+    unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
+                                  // (null: no records -- every block starts from the nominal rate)
 };
 
 __device__ __forceinline__ bool relay_same_state(const ClockState &a, const ClockState &b)
@@ -83,16 +89,22 @@ __device__ __forceinline__ float relay_lane(float v, int src)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ int relay_scan(int v, int lane)
+// lane i <- i - 1, lane 0 <- first (the DPP move leaves lanes without a source lane what they held)
+__device__ __forceinline__ float relay_shr1_from(float v, float first)
 {
-    v += relay_dpp<0x111>(v);       // row_shr:1 .. 8 inside every row of 16
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+// inclusive prefix sum over the 64 lanes: inside every row of 16, then row 0's total into row 1 and row 2's into
+// row 3 (row_bcast:15, rows 1 and 3), then the total of rows 0..1 into rows 2..3 (row_bcast:31)
+__device__ __forceinline__ int relay_scan(int v, int)
+{
+    v += relay_dpp<0x111>(v);       // row_shr:1 .. 8
     v += relay_dpp<0x112>(v);
     v += relay_dpp<0x114>(v);
     v += relay_dpp<0x118>(v);
-    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
-    const int row = lane >> 4;
-    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
 }
 
 // The hand-shake words between the two waves live in LDS and order LDS traffic only.  A wave's DS operations are
@@ -117,9 +129,23 @@ __device__ __forceinline__ void relay_st(int *p, int v)
     asm volatile("ds_write_b32 %0, %1" : : "v"(relay_lds_addr(p)), "v"(v) : "memory");
 }
 
+#ifdef XRIT_RELAY_TIMING
+// (instrumented build, make EXTRA=-DXRIT_RELAY_TIMING: shader-clock cycles the walkers spend per phase of a step, summed
+// over all walkers and passes of a call; printed with XRIT_TRACE)
+__device__ unsigned long long relay_dbg[16];
+#define RELAY_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define RELAY_TICK(i) do { } while (0)
+#endif
+
 constexpr int RELAY_RX = 4096;       // sample ring (RING): about ten steps of lead for the prefetching wave
 constexpr int RELAY_XCH = 1024;      // samples per refill (16 per lane)
 constexpr int RELAY_ROUNDS = 4;      // guess rounds per step at most
+constexpr int RELAY_XMIR = 8;        // the ring's first samples again behind its end: a window never wraps
+constexpr int RELAY_GR = 2048;       // ring of first guesses (symbols), refilled RELAY_GCH at a time
+constexpr int RELAY_GCH = 512;
+constexpr unsigned RELAY_NOGUESS = 0xffffffffu;
+constexpr int RELAY_REF_MARGIN = 1 << 20;     // a segment's reference index sits this far in front of its nominal start
 
 // RING: two waves per workgroup, samples through the LDS ring (span = samples a block of 64 symbols can cover
 // <= RELAY_RX - RELAY_XCH - 72); else one wave that reads its windows from global memory (any symbol rate).
@@ -130,8 +156,9 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                                                                  // (null: it never will -- pass budget used up -- go anyway)
     if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;      // closed in an earlier pass
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    __shared__ cf32 xr[RING ? RELAY_RX : 1];
-    __shared__ int sh_xhi, sh_pos_ii, sh_done;
+    __shared__ cf32 xr[RING ? RELAY_RX + RELAY_XMIR : 1];
+    __shared__ unsigned gr[RING ? RELAY_GR : 1];
+    __shared__ int sh_xhi, sh_pos_ii, sh_done, sh_ghi, sh_pos_n;
     clock_table_to_lds(table, a.table);
     const int s = blockIdx.x, lane = threadIdx.x & 63;
     // (wave-uniform by construction; said so, so that the two roles are two scalar branches and not two exec masks)
@@ -161,7 +188,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;
     const RelaySeg prev = a.start[s];
     const int x_lo = (int)(T.ii > 4 ? T.ii - 4 : 0);
-    if (threadIdx.x == 0) { sh_xhi = x_lo; sh_pos_ii = (int)T.ii; sh_done = 0; }
+    if (threadIdx.x == 0) { sh_xhi = x_lo; sh_pos_ii = (int)T.ii; sh_done = 0; sh_ghi = 0; sh_pos_n = 0; }
     __syncthreads();      // (the only barrier: both waves pass it before either can leave)
     if (dead) {
         if (pass > 0 && (prev.flags & RELAY_DEAD)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
@@ -176,28 +203,56 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     }
     if (pass > 0 && (prev.flags & RELAY_WALKED) && relay_same_state(prev.s, T)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
     const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
+    // the record of the walk before (this call's: the flags are cleared when a call's relay starts): prev.n_done symbols,
+    // read indices relative to a reference that does not depend on the pass
+    const bool use_rec = RING && a.rec != nullptr &&
+                         __builtin_amdgcn_readfirstlane((int)((prev.flags & RELAY_WALKED) != 0 && prev.n_done > 0)) != 0;
+    const int n_rec = __builtin_amdgcn_readfirstlane(prev.n_done);
+    const int ref = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii)) -
+                    RELAY_REF_MARGIN;
+    unsigned *recs = a.rec ? a.rec + obase : nullptr;
 
     if (RING && role == 1) {
         // ---- the prefetcher: keeps [position, position + RX - XCH) of the samples in the ring; a slot is overwritten
-        // only when the walker's published position is past it
+        // only when the walker's published position is past it.  Same for the first guesses, by symbol number.
         const long long nlast = a.N > 0 ? a.N - 1 : 0;
-        int x_hi = x_lo;
+        int x_hi = x_lo, g_hi = 0;
         unsigned rounds = 0;
         while (!relay_ld(&sh_done)) {
             if (++rounds > (1u << 24)) { if (lane == 0) a.changed[4 * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
             const int pii = relay_ld(&sh_pos_ii);
             const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= nlast + RELAY_XCH;
-            if (!fx) { __builtin_amdgcn_s_sleep(4); continue; }
-            cf32 vx[RELAY_XCH / 64];
+            bool fg = false;
+            if (use_rec) fg = g_hi < Lseg && g_hi + RELAY_GCH - RELAY_GR <= relay_ld(&sh_pos_n);
+            if (!fx && !fg) { __builtin_amdgcn_s_sleep(4); continue; }
+            if (fx) {
+                cf32 vx[RELAY_XCH / 64];
 #pragma unroll
-            for (int q = 0; q < RELAY_XCH / 64; ++q) {
-                const long long i = (long long)x_hi + lane + 64 * q;
-                vx[q] = xs[i < nlast ? i : nlast];
+                for (int q = 0; q < RELAY_XCH / 64; ++q) {
+                    const long long i = (long long)x_hi + lane + 64 * q;
+                    vx[q] = xs[i < nlast ? i : nlast];
+                }
+#pragma unroll
+                for (int q = 0; q < RELAY_XCH / 64; ++q) {
+                    const int slot = (x_hi + lane + 64 * q) & (RELAY_RX - 1);
+                    xr[slot] = vx[q];
+                    if (slot < RELAY_XMIR) xr[RELAY_RX + slot] = vx[q];
+                }
+                x_hi += RELAY_XCH;
+                if (lane == 0) relay_st(&sh_xhi, x_hi);
             }
+            if (fg) {
+                unsigned vg[RELAY_GCH / 64];
 #pragma unroll
-            for (int q = 0; q < RELAY_XCH / 64; ++q) xr[(x_hi + lane + 64 * q) & (RELAY_RX - 1)] = vx[q];
-            x_hi += RELAY_XCH;
-            if (lane == 0) relay_st(&sh_xhi, x_hi);
+                for (int q = 0; q < RELAY_GCH / 64; ++q) {
+                    const int m = g_hi + lane + 64 * q;
+                    vg[q] = m < n_rec ? recs[m] : RELAY_NOGUESS;
+                }
+#pragma unroll
+                for (int q = 0; q < RELAY_GCH / 64; ++q) gr[(g_hi + lane + 64 * q) & (RELAY_GR - 1)] = vg[q];
+                g_hi += RELAY_GCH;
+                if (lane == 0) relay_st(&sh_ghi, g_hi);
+            }
         }
         return;
     }
@@ -205,51 +260,83 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     // ---- the walker
     if (lane == 0) atomicAdd(&a.changed[4 * pass], 1u);
     const ClockState T0 = T;
-    const float kw = 16777216.0f / (float)a.q_om, km = 16777216.0f / (float)a.q_mu;
+    // (the integer model is a guess generator, not the arithmetic: the gains folded into one factor each, the lattice
+    // steps -- powers of two, float32 spacings -- as shifts)
+    const float gkw = a.par.gain_omega * (16777216.0f / (float)a.q_om), gkm = a.par.gain_mu * (16777216.0f / (float)a.q_mu);
+    const int sh_om = 31 - __builtin_clz((unsigned)a.q_om), sh_mu = 31 - __builtin_clz((unsigned)a.q_mu);
+    // symbols of this segment the output holds
+    const long long room = (long long)a.cap - obase;
+    const int n_out = room <= 0 ? 0 : (room < (long long)Lseg ? (int)room : Lseg);
+    float *softs = a.soft ? a.soft + obase : nullptr;
+    float2 *syms = (SYM && a.sym) ? a.sym + obase : nullptr;
+    const int ni_w = (int)(a.ni < 0x7fffffffLL ? a.ni : 0x7fffffffLL);     // (read indices are 32-bit here: x_lo, need_x)
     int n = 0;
     unsigned steps = 0, rounds_total = 0;
     bool exhausted = false;
+    int x_hi = x_lo, g_hi = 0;           // what the rings are known to hold (asked again only when that is not enough)
+#ifdef XRIT_RELAY_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     while (n < Lseg) {
-        ++steps;
-        if (steps > 64u * (unsigned)Lseg + 1000u) { if (lane == 0) a.changed[4 * pass + 3] = 0xa0000000u | (unsigned)s; exhausted = true; break; }
+        RELAY_TICK(5);
+        ++steps;          // (every step commits at least one symbol or ends the walk: no more than Lseg steps)
         // (a walker that stands beyond the input has nothing to wait for: the prefetcher stops at the end of the input)
-        if (T.ii < 0 || T.ii >= a.ni) { exhausted = true; break; }
-        const int need_x = (int)T.ii + span + 8;
-        if (RING) {
-            // wait until the ring holds this step's samples (it does, unless memory is slower than ten steps)
-            int x_hi = relay_ld(&sh_xhi), spins = 0;
+        const int ii0 = (int)T.ii;
+        if ((unsigned)ii0 >= (unsigned)ni_w) { exhausted = true; break; }
+        const int need_x = ii0 + span + 8;
+        const int need_g = n + 64 < Lseg ? n + 64 : Lseg;
+        if (RING && (x_hi < need_x || (use_rec && g_hi < need_g))) {
+            // wait until the rings hold this step's samples and guesses (they do, unless memory is slower than ten steps)
+            int spins = 0;
+#pragma nounroll
             while (x_hi < need_x) {
-                __builtin_amdgcn_s_sleep(2);
                 x_hi = relay_ld(&sh_xhi);
+                if (x_hi >= need_x) break;
+                __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 22)) { if (lane == 0) a.changed[4 * pass + 3] = 0x80000000u | (unsigned)s; exhausted = true; break; }
+            }
+#pragma nounroll
+            while (use_rec && !exhausted && g_hi < need_g) {
+                g_hi = relay_ld(&sh_ghi);
+                if (g_hi >= need_g) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[4 * pass + 3] = 0x90000000u | (unsigned)s; exhausted = true; break; }
             }
             if (exhausted) break;
         }
-        // the walker's state on the lattice; the first guess puts symbol n + lane at the nominal rate
-        const int ii0 = (int)T.ii;
+        RELAY_TICK(0);
+        // the walker's state on the lattice; the first guess puts symbol n + lane where the walk before had it, or,
+        // without one, at the nominal rate
         const int mu0u = (int)(T.mu * 16777216.0f), W0 = (int)(T.omega * 16777216.0f);
         const int wint = W0 >> 24, wfrac = W0 & 0xffffff;
-        int cii, uarm = -1;
+        const int fr0 = mu0u + lane * wfrac, bii = ii0 + lane * wint;     // symbol n + lane at the walker's rate
+        int cii, carm;
         float cmu, com = T.omega;
-        {
-            const int fr = mu0u + lane * wfrac;
-            cii = ii0 + lane * wint + (fr >> 24);
-            cmu = (float)(fr & 0xffffff) * (1.0f / 16777216.0f);
-        }
+        cii = bii + (fr0 >> 24);
+        cmu = (float)(fr0 & 0xffffff) * (1.0f / 16777216.0f);
         if (lane == 0) cmu = T.mu;
+        carm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
+        if (use_rec) {
+            const unsigned g = gr[(n + lane) & (RELAY_GR - 1)];
+            if (g != RELAY_NOGUESS && lane != 0) {
+                cii = ref + (int)(g >> 8);
+                carm = min((int)(g & 0xffu), XR_MM_NSTEPS);
+            }
+        }
+        RELAY_TICK(1);
         cf32 p0{0.f, 0.f};
         float mm = 0.f;
         ClockState hs{};               // the history symbol n + lane sees: (p0, p1) of the two symbols in front of it
         bool stale = false, inrange = true;
         for (int round = 0; round < RELAY_ROUNDS; ++round) {
             ++rounds_total;
-            const int arm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
             // (re)interpolate where the read index or the arm moved
             inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
             cf32 w[XR_MM_NTAPS];
             if (RING) {
+                const cf32 *wp = xr + (cii & (RELAY_RX - 1));
 #pragma unroll
-                for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xr[(cii + q) & (RELAY_RX - 1)];
+                for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = wp[q];
             } else {
                 long long wi = cii;
                 wi = wi < 0 ? 0 : (wi >= a.ni ? a.ni - 1 : wi);
@@ -257,40 +344,38 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = xs[wi + q];
                 inrange = true;
             }
-            p0 = clock_interp(w, table, cmu);
-            uarm = arm;
-            cf32 h0 = cf32{relay_shr1(p0.x), relay_shr1(p0.y)};
-            cf32 h1 = cf32{relay_shr1(h0.x), relay_shr1(h0.y)};
-            if (lane == 0) { h0 = T.p0; h1 = T.p1; }
-            if (lane == 1) { h1 = T.p0; }
-            hs.p0 = h0; hs.p1 = h1;
-            hs.c0 = cf32{h0.x > 0.f ? 1.f : 0.f, h0.y > 0.f ? 1.f : 0.f};
-            hs.c1 = cf32{h1.x > 0.f ? 1.f : 0.f, h1.y > 0.f ? 1.f : 0.f};
-            if (lane == 0) { hs.c0 = T.c0; hs.c1 = T.c1; }
-            if (lane == 1) { hs.c1 = T.c0; }
+            p0 = clock_interp_arm(w, table, carm);
+            // the two symbols in front: the neighbours' interpolated values, the walker's own history in front of lane 0
+            const cf32 sl{p0.x > 0.f ? 1.f : 0.f, p0.y > 0.f ? 1.f : 0.f};
+            hs.p0 = cf32{relay_shr1_from(p0.x, T.p0.x), relay_shr1_from(p0.y, T.p0.y)};
+            hs.p1 = cf32{relay_shr1_from(hs.p0.x, T.p1.x), relay_shr1_from(hs.p0.y, T.p1.y)};
+            hs.c0 = cf32{relay_shr1_from(sl.x, T.c0.x), relay_shr1_from(sl.y, T.c0.y)};
+            hs.c1 = cf32{relay_shr1_from(hs.c0.x, T.c1.x), relay_shr1_from(hs.c0.y, T.c1.y)};
             mm = clock_timing_error(p0, hs);
             // omega and mu on the lattice: additions of rounded increments, i.e. two prefix sums
-            const int dW = (int)rintf(a.par.gain_omega * mm * kw) * a.q_om;
-            const int dM = (int)rintf(a.par.gain_mu * mm * km) * a.q_mu;
+            const int dW = (int)rintf(mm * gkw) << sh_om;
+            const int dM = (int)rintf(mm * gkm) << sh_mu;
             const int C = relay_scan(dW, lane);                  // omega after symbol n + lane, minus W0
             const int E = C + dM;
             const int D = relay_scan(E, lane) - E;               // position in front of symbol n + lane, minus the nominal one
-            const int fr = mu0u + lane * wfrac + D;
-            int nii = ii0 + lane * wint + (fr >> 24);
+            const int fr = fr0 + D;
+            int nii = bii + (fr >> 24);
             float nmu = (float)(fr & 0xffffff) * (1.0f / 16777216.0f);
             float nom = (float)(W0 + C - dW) * (1.0f / 16777216.0f);
             if (lane == 0) { nii = ii0; nmu = T.mu; nom = T.omega; }
-            stale = nii != cii || (int)rintf(nmu * (float)XR_MM_NSTEPS) != uarm;
-            cii = nii; cmu = nmu; com = nom;
+            const int narm = (int)rintf(nmu * (float)XR_MM_NSTEPS);
+            stale = nii != cii || narm != carm;
+            cii = nii; carm = narm; cmu = nmu; com = nom;
             if (!__any(stale)) break;
         }
+        RELAY_TICK(2);
         // the literal step from every lane's state, compared with the neighbour's state bit for bit
         ClockState st = hs;
         st.ii = cii; st.mu = cmu; st.omega = com;
         clock_advance(mm, p0, st, a.par);
         const int nxt_ii = relay_dpp<0x130>(cii);
         const float nxt_mu = relay_shl1(cmu), nxt_om = relay_shl1(com);
-        const bool exists = cii >= 0 && (long long)cii < a.ni;
+        const bool exists = (unsigned)cii < (unsigned)ni_w;
         const bool good = !stale && inrange;                      // this lane's interpolation belongs to its state
         const bool ok = good && exists && lane < 63 && (int)st.ii == nxt_ii && st.mu == nxt_mu && st.omega == nxt_om;
         const unsigned long long okm = __ballot(ok), exm = __ballot(exists), gdm = __ballot(good);
@@ -302,11 +387,16 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         nv = nv < lim ? nv : lim;
         nv = nv < g ? nv : g;
         if (e < nv) { nv = e; exhausted = true; }
+        RELAY_TICK(3);
         if (lane < nv) {
-            const unsigned long long o = (unsigned long long)(obase + n + lane);
-            if (o < a.cap) {
-                if (a.soft) a.soft[o] = p0.x;
-                if (SYM && a.sym) a.sym[o] = make_float2(p0.x, p0.y);
+            const int o = n + lane;
+            if (o < n_out) {
+                if (softs) softs[o] = p0.x;
+                if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
+            }
+            if (RING && recs) {
+                const unsigned rel = (unsigned)(cii - ref);
+                recs[o] = rel < (1u << 24) ? (rel << 8) | (unsigned)carm : RELAY_NOGUESS;
             }
         }
         if (nv > 0) {
@@ -321,10 +411,18 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             nt.c1 = cf32{relay_lane(st.c1.x, src), relay_lane(st.c1.y, src)};
             T = nt;
             n += nv;
-            if (RING && lane == 0) relay_st(&sh_pos_ii, (int)T.ii);
+            if (RING && lane == 0) { relay_st(&sh_pos_ii, (int)T.ii); relay_st(&sh_pos_n, n); }
         }
+        RELAY_TICK(4);
         if (exhausted || nv == 0) { exhausted = true; break; }      // (nv == 0 without exhaustion cannot happen: lane 0 is good)
     }
+#ifdef XRIT_RELAY_TIMING
+    if (lane == 0) {
+        const int o = pass >= 8 ? 8 : 0;
+        for (int q = 0; q < 6; ++q) atomicAdd(&relay_dbg[o + q], tacc[q]);
+        atomicAdd(&relay_dbg[o + 6], (unsigned long long)steps);
+    }
+#endif
     if (lane == 0) {
         if (RING) relay_st(&sh_done, 1);
         atomicMax(&a.changed[4 * pass + 3], (steps << 12) | (unsigned)(s & 0xfff));
@@ -332,6 +430,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         atomicAdd(&a.changed[4 * pass + 2], rounds_total);
         RelaySeg st0{};
         st0.s = T0;
+        st0.n_done = n;                 // symbols the record holds
         st0.flags = RELAY_WALKED;
         a.start[s] = st0;
         RelaySeg e{};

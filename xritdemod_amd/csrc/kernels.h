@@ -239,6 +239,8 @@ struct ClockStage {
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
     DevBuf relay;               // segment records + per-pass counters
+    DevBuf relay_rec;           // per symbol: read index and interpolator arm of the last exact walk (the next walk's first guess)
+    bool relay_no_rec = false;  // XRIT_RELAY_NO_REC: walkers always guess from the nominal rate (A/B runs)
     DevBuf stage;               // soft symbols of a writing hand-off pass, in wave order (ClockPassOut::stage)
     int relay_batch = 96;       // relay passes enqueued before the host looks
     int relay_passes = 0;       // relay passes the last call ran (the closing, change-free one included)

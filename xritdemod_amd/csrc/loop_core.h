@@ -211,15 +211,21 @@ struct ClockState {
 // The step in two halves, so that a kernel which gets a symbol's history from somewhere else (clock_relay.h:
 // the two previous symbols sit in neighbouring lanes) runs the very same float operations.
 // First half: the interpolated sample at (window, mu).
+// (the interpolator arm given: clock_relay.h keeps it next to the read index)
+template <typename TableT>
+XR_HD cf32 clock_interp_arm(const cf32 *w, const TableT *table, int imu)
+{
+    const TableT *row = table + imu * XR_MM_NTAPS;
+    float ar = 0.0f, ai = 0.0f;
+    XR_MM_INTERPOLATE(row, w, ar, ai);
+    return cf32{ar, ai};
+}
 template <typename TableT>
 XR_HD cf32 clock_interp(const cf32 *w, const TableT *table, float mu_now, int *arm_out = nullptr)
 {
     int imu = (int)rintf(mu_now * (float)XR_MM_NSTEPS);
     if (arm_out) *arm_out = imu;
-    const TableT *row = table + imu * XR_MM_NTAPS;
-    float ar = 0.0f, ai = 0.0f;
-    XR_MM_INTERPOLATE(row, w, ar, ai);
-    return cf32{ar, ai};
+    return clock_interp_arm(w, table, imu);
 }
 
 // Second half, again in two: the Mueller & Mueller timing error of the symbol p0 given the history in s ...
