@@ -24,13 +24,14 @@ def main():
     ap.add_argument("--mode", default="lrit")
     ap.add_argument("--decimation", type=int, default=5)
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--esn0", type=float, default=None, help="Es/N0 of the synthetic stream (dB; default: the generator's 12)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = 1 << args.log2
     D = args.decimation
     fs_in = (1.25e6 if args.mode == "lrit" else 2.5e6) * D
     sym_rate, alpha = (293883.0, 0.5) if args.mode == "lrit" else (927000.0, 0.3)
-    sp = _capi.synth_params(fs_in=fs_in, symbol_rate=sym_rate, alpha=alpha)
+    sp = _capi.synth_params(fs_in=fs_in, symbol_rate=sym_rate, alpha=alpha, **({"esn0_db": args.esn0} if args.esn0 is not None else {}))
     stream = torch.cuda.current_stream(dev)
     bursts = torch.empty((args.bursts, n, 2), dtype=torch.float32, device=dev)
     for b in range(args.bursts):

@@ -188,6 +188,8 @@ struct ClockPolicy {
     int min_passes;
     const float4 *jmean;  // not null: every chain takes the stream's mean Jacobian (ClockStage::begin)
     float floor_sq;       // mean squared residual (samples^2) at which a hand-off counts as being at the recurrence's floor
+    int relay_after;      // > 0: the exact closure follows (cfg.clock_exact >= 1) -- the walkers need start states near the
+                          // trajectory, not a hand-off at its floor: closed after this many passes once no residual is large
 
     struct Elem { ClockState e, s; float4 j; int nrun; };
     __device__ float4 jac_of(long long k) const { return jmean ? jmean[0] : J[k]; }
@@ -264,6 +266,7 @@ struct ClockPolicy {
         const int open_prev = ctl[1] == 1 ? 0x7fffffff : ctl[6];
         ctl[6] = (int)open_;
         if (changed == 0) { ctl[0] = 1; ctl[2] = 0; return; }
+        if (relay_after > 0 && ctl[1] >= relay_after && large == 0 && !(__uint_as_float(mr) > 0.02f)) { ctl[0] = 1; return; }
         // "stalled" is the chaos floor only if the boundaries have also stopped freezing: at C2 112 653 of 113 266
         // stay open from pass to pass (they move by 1e-5 for ever), whereas a call of a few dozen chains closes
         // EXACTLY given the passes (20 -> 19 -> ... -> 0 open, then 3e-7 from the serial loop) and its summed
@@ -1042,6 +1045,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
+    if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
     pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
@@ -1128,9 +1132,15 @@ __global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelayS
     if (threadIdx.x == 0) {
         int ran = enq, closed = 0;
         for (int p = 0; p < enq; ++p)
-            if (changed[4 * p] == 0u) { ran = p + 1; closed = 1; break; }
+            if (changed[RELAY_STAT * p] == 0u) { ran = p + 1; closed = 1; break; }
         ctl[10] = ran;
         ctl[11] = closed;
+        {
+            // how far the starts still moved in the last pass: mean square (samples^2, float bits)
+            const unsigned *c = changed + RELAY_STAT * (ran - 1);
+            const unsigned long long sq = (unsigned long long)c[4] | ((unsigned long long)c[5] << 32);
+            ctl[12] = __float_as_int(c[6] ? (float)((double)sq / 1099511627776.0 / (double)c[6]) : 0.0f);
+        }
         s_buf = (ran - 1) & 1;
         s_term = 0x7fffffff;
     }
@@ -1179,7 +1189,8 @@ int ClockStage::relay_plan()
     if (cps < 1) cps = 1;
     j.cps = cps;
     j.G = (j.K + cps - 1) / cps;
-    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)relay_limit() + 8) * 4 * sizeof(unsigned)));
+    // (counters for G + 1 passes whatever the budget: the default configuration raises its own, ClockStage::finish)
+    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned)));
     if (!relay_no_rec) XR_TRY(relay_rec.reserve((size_t)j.G * cps * NS * sizeof(unsigned)));
     relay_segments = j.G;
     relay_seg_chains = cps;
@@ -1190,7 +1201,7 @@ int ClockStage::relay_limit() const
 {
     // a pass moves the exact front by at least one segment: G + 1 passes always close
     const int hard = job.G + 1;
-    return exact > 1 ? (exact < hard ? exact : hard) : hard;
+    return job.relay_budget > 0 ? (job.relay_budget < hard ? job.relay_budget : hard) : hard;
 }
 
 // `restart`: first batch of a call (or the tiled evaluation was redone): nothing has been walked.  Every batch ends
@@ -1220,9 +1231,9 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     a.rec = relay_no_rec ? nullptr : relay_rec.as<unsigned>();
     if (restart) {
         j.relay_enq = 0;
-        const int words = 4 * (limit + 2) > j.G ? 4 * (limit + 2) : j.G;
+        const int words = RELAY_STAT * (j.G + 3);
         hipLaunchKernelGGL(clock_relay_init_kernel, dim3(div_up((size_t)words, 256)), dim3(256), 0, s, segs, j.G, changed,
-                           limit + 2, clock_ctl(counters));
+                           j.G + 3, clock_ctl(counters));
     }
     // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
     const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
@@ -1252,7 +1263,12 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
                     // (3e-4 sample rms at the 2.7 .. 4.25 samples per symbol the rule was tuned at; the floor is a
                     // fraction of a SYMBOL: at 21 or 68 samples per symbol it sits that much higher in samples, and
                     // calls there went on freezing a few boundaries per pass for 185 passes)
-                    9e-8f * (sps > 4.2534f ? (sps / 4.2534f) * (sps / 4.2534f) : 1.0f)};
+                    9e-8f * (sps > 4.2534f ? (sps / 4.2534f) * (sps / 4.2534f) : 1.0f),
+                    // (measured at C2: the walks meet the serial trajectory after as many relay passes from the starts two
+                    // hand-off passes leave -- rms residual 8e-4 sample -- as from those of five, 1.2e-4)
+                    // (segments of a few hundred symbols -- cfg.clock_exact_window -- do not get that far in a pass: they start from
+                    // a hand-off at its floor as before)
+                    j.relay && (long long)j.cps * NS >= 2048 ? 2 : 0};
     const unsigned nw = div_up((size_t)j.K, 64);              // waves of 64 chains
     const float2 *x = xbase();
     // wave-aligned solve (newton.h): the pass leaves its waves' aggregates, one more launch applies them;
@@ -1478,7 +1494,10 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         j.gated = force_gated;
         j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !no_meanj;
     }
-    j.relay = exact >= 1;
+    // cfg.clock_exact: 1 -- relayed to closure; n > 1 -- n relay passes; 0 -- hand-off passes, relayed from finish() when
+    // they stall high (or, XRIT_AUTO_PASSES: that many relay passes on every call, kernels.h); < 0 -- hand-off passes only
+    j.relay = exact >= 1 || (exact == 0 && auto_passes > 0 && (long long)K * NS >= auto_min);
+    j.relay_budget = exact > 1 ? exact : (exact == 1 ? 0 : auto_passes);
     if (j.relay) XR_TRY(relay_plan());
     // (measured at C2: a pass that writes costs ~40 us more than one that does not -- 16-byte stores, 64 lines per wave
     // instruction --, a call whose last pass did not write pays the output pass, 175 us.  Writing from one pass earlier
@@ -1557,7 +1576,8 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     relay_passes = 0;
     relay_closed = false;
     relay_auto = false;
-    if (exact == 0 && job.K > 1) {
+    if (exact == 0 && job.K > 1 && !job.relay) {
+        // (a call too short for the relay to be planned at its start)
         // The hand-off passes normally stall at the recurrence's own floor, an rms residual of ~1e-4 sample (Es/N0 12 dB).
         // At low Es/N0 they stall at 5e-4 .. 1e-3 instead -- every wrong decision kicks mu by 2e-3 -- and which
         // near-zero symbols then fall on the other side differs from the serial loop (a third
@@ -1571,12 +1591,24 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         if (hctl[0] == 0 || (open_ > 0 && q > auto_rms * auto_rms * (float)open_)) {
             job.relay = relay_auto = true;
             job.relay_force = hctl[0] == 0;
+            job.relay_budget = 0;
             XR_TRY(relay_plan());
             XR_TRY(enqueue_relay(relay_batch, true, s, prof));
             XR_HIP(hipStreamSynchronize(s));
         }
     }
     if (job.relay && job.K > 1) {
+        if (exact == 0 && !relay_auto && hctl[11] == 0) {
+            // (XRIT_AUTO_PASSES) after the budgeted passes the starts of a clean signal move by a few 1e-4 sample rms from
+            // pass to pass.  Where they still move by more -- low Es/N0: every decision that differs kicks mu by 2e-3 --,
+            // or the hand-off passes never closed, the call is walked to closure: the serial trajectory whatever the noise.
+            float shift_sq;
+            memcpy(&shift_sq, &hctl[12], sizeof shift_sq);
+            if (job.relay_force || !(shift_sq <= auto_shift * auto_shift)) {
+                relay_auto = true;
+                job.relay_budget = 0;
+            }
+        }
         // the relay goes on until a pass changes nothing (or the pass budget of a partial closure is used up)
         while (hctl[11] == 0 && job.relay_enq < relay_limit()) {
             XR_TRY(enqueue_relay(relay_batch < 32 ? 32 : relay_batch, false, s, prof));
@@ -1585,13 +1617,19 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         relay_passes = hctl[10];
         relay_closed = hctl[11] != 0;
         if (trace_env) {
-            std::vector<unsigned> hc((size_t)relay_passes * 4);
+            std::vector<unsigned> hc((size_t)relay_passes * RELAY_STAT);
             const unsigned *changed = reinterpret_cast<const unsigned *>(relay.as<RelaySeg>() + 3 * (size_t)job.G);
             XR_HIP(hipMemcpy(hc.data(), changed, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-            for (int p = 0; p < relay_passes; ++p)
-                fprintf(stderr, "[xrit] relay pass %d: segments walked %u of %d, steps %u, rounds %u (%.2f per step); slowest: %u steps (segment %u)\n", p,
-                        hc[4 * p], job.G, hc[4 * p + 1], hc[4 * p + 2], hc[4 * p + 1] ? (double)hc[4 * p + 2] / hc[4 * p + 1] : 0.0,
-                        hc[4 * p + 3] >> 12, hc[4 * p + 3] & 0xfff);
+            for (int p = 0; p < relay_passes; ++p) {
+                const unsigned *c = &hc[(size_t)RELAY_STAT * p];
+                float mv;
+                memcpy(&mv, &c[3], sizeof mv);
+                const unsigned long long sq = (unsigned long long)c[4] | ((unsigned long long)c[5] << 32);
+                fprintf(stderr, "[xrit] relay pass %d: segments walked %u of %d, steps %u, rounds %u (%.2f per step); starts moved by %.3e sample rms, %.3e at most%s\n", p,
+                        c[0], job.G, c[1], c[2], c[1] ? (double)c[2] / c[1] : 0.0,
+                        c[6] ? sqrt((double)sq / 1099511627776.0 / (double)c[6]) : 0.0,
+                        c[3] >= 0x80000000u ? 0.0 : (double)mv, c[3] >= 0x80000000u ? " (watchdog mark)" : "");
+            }
         }
 #ifdef XRIT_RELAY_TIMING
         if (trace_env) {

@@ -38,6 +38,7 @@
 
 namespace xrit {
 
+constexpr int RELAY_STAT = 8;        // counters per relay pass (RelayArgs::changed)
 constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exactly from start[].s
 constexpr int RELAY_EXHAUSTED = 2;   // ends[]: the input ran out inside this segment (n_done symbols exist)
 constexpr int RELAY_DEAD = 4;        // the input ran out before this segment
@@ -64,8 +65,9 @@ struct RelayArgs {
     unsigned long long cap;
     ClockPar par;
     int q_om, q_mu;               // lattice steps of omega and of mu + omega, in units of 2^-24 sample
-    unsigned *changed;            // [4 * pass] segments whose start changed in that pass, [+1] steps, [+2] symbols walked,
-                                  // [+3] slowest walker (steps << 12 | segment) or a watchdog mark
+    unsigned *changed;            // [RELAY_STAT * pass] segments whose start changed in that pass, [+1] steps, [+2] guess rounds,
+                                  // [+3] largest move of a start against the walk before (float bits) or a watchdog mark,
+                                  // [+4, +5] sum of the squared moves (64 bits, 2^-40 sample^2), [+6] moves summed
     const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed (null: do not ask)
     unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
                                   // (null: no records -- every block starts from the nominal rate)
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
 {
     if (a.ctl && !a.ctl[0]) return;                              // the tiled hand-off has not closed: nothing to refine yet
                                                                  // (null: it never will -- pass budget used up -- go anyway)
-    if (pass > 0 && a.changed[4 * (pass - 1)] == 0) return;      // closed in an earlier pass
+    if (pass > 0 && a.changed[RELAY_STAT * (pass - 1)] == 0) return;      // closed in an earlier pass
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
     __shared__ cf32 xr[RING ? RELAY_RX + RELAY_XMIR : 1];
     __shared__ unsigned gr[RING ? RELAY_GR : 1];
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             e.flags = RELAY_DEAD;
             eout[s] = e;
             a.start[s] = e;
-            atomicAdd(&a.changed[4 * pass], 1u);
+            atomicAdd(&a.changed[RELAY_STAT * pass], 1u);
         }
         return;
     }
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         int x_hi = x_lo, g_hi = 0;
         unsigned rounds = 0;
         while (!relay_ld(&sh_done)) {
-            if (++rounds > (1u << 24)) { if (lane == 0) a.changed[4 * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
+            if (++rounds > (1u << 24)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
             const int pii = relay_ld(&sh_pos_ii);
             const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= nlast + RELAY_XCH;
             bool fg = false;
@@ -258,7 +260,20 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     }
 
     // ---- the walker
-    if (lane == 0) atomicAdd(&a.changed[4 * pass], 1u);
+    if (lane == 0) {
+        atomicAdd(&a.changed[RELAY_STAT * pass], 1u);
+        // how far this start is from the one the segment was last walked from (samples): what the automatic closure
+        // looks at (ClockStage::finish).  Non-negative floats order like their bits; watchdog marks stay on top.
+        if (pass > 0 && (prev.flags & RELAY_WALKED)) {
+            const float mv = fabsf(clock_tdiff(prev.s, T));
+            atomicMax(&a.changed[RELAY_STAT * pass + 3], __float_as_uint(mv));
+            // (sum of squares in units of 2^-40 sample^2, moves beyond a sample count as one)
+            const float m1 = fminf(mv, 1.0f);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&a.changed[RELAY_STAT * pass + 4]),
+                      (unsigned long long)(m1 * m1 * 1099511627776.0f));
+            atomicAdd(&a.changed[RELAY_STAT * pass + 6], 1u);
+        }
+    }
     const ClockState T0 = T;
     // (the integer model is a guess generator, not the arithmetic: the gains folded into one factor each, the lattice
     // steps -- powers of two, float32 spacings -- as shifts)
@@ -293,14 +308,14 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 x_hi = relay_ld(&sh_xhi);
                 if (x_hi >= need_x) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { if (lane == 0) a.changed[4 * pass + 3] = 0x80000000u | (unsigned)s; exhausted = true; break; }
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x80000000u | (unsigned)s; exhausted = true; break; }
             }
 #pragma nounroll
             while (use_rec && !exhausted && g_hi < need_g) {
                 g_hi = relay_ld(&sh_ghi);
                 if (g_hi >= need_g) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { if (lane == 0) a.changed[4 * pass + 3] = 0x90000000u | (unsigned)s; exhausted = true; break; }
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x90000000u | (unsigned)s; exhausted = true; break; }
             }
             if (exhausted) break;
         }
@@ -425,9 +440,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
 #endif
     if (lane == 0) {
         if (RING) relay_st(&sh_done, 1);
-        atomicMax(&a.changed[4 * pass + 3], (steps << 12) | (unsigned)(s & 0xfff));
-        atomicAdd(&a.changed[4 * pass + 1], steps);
-        atomicAdd(&a.changed[4 * pass + 2], rounds_total);
+        atomicAdd(&a.changed[RELAY_STAT * pass + 1], steps);
+        atomicAdd(&a.changed[RELAY_STAT * pass + 2], rounds_total);
         RelaySeg st0{};
         st0.s = T0;
         st0.n_done = n;                 // symbols the record holds
@@ -446,7 +460,7 @@ __global__ void __launch_bounds__(256) clock_relay_init_kernel(RelaySeg *start, 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < G) start[i].flags = 0;
-    if (i < 4 * npass) changed[i] = 0u;
+    if (i < RELAY_STAT * npass) changed[i] = 0u;
     if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; }
 }
 

@@ -503,13 +503,9 @@ int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft, size_t cap, size
     float2 *sym = (d->keep_stages || d->keep_symbols) ? d->stage_buf[4].as<float2>() : nullptr;
     size_t k = 0;
     // The negated Costas output is the other lock's output to rounding only, which alone moves a float32 M&M by its
-    // 5e-5 .. 1e-4; on top of the tiling's 2.3e-4 the rank sat at 3.2e-4 against the
-    // uninterrupted chain.  Four relay passes (csrc/clock_relay.h, +2 ms per 2^28-sample slice) take the tiling's share
-    // out of the run that is repeated anyway.
-    const int exact_was = d->clock.exact;
-    if (d->clock.exact == 0) d->clock.exact = 4;
+    // 5e-5 .. 1e-4.  The run is repeated in the handle's own configuration (cfg.clock_exact: by
+    // default two hand-off passes and three relay passes, csrc/clock_relay.h).
     int rc = d->clock.redo_flipped(d_soft, sym, cap, &k, s, prof);
-    d->clock.exact = exact_was;
     if (rc == XRIT_OK) rc = d->costas.flip_phase(s);
     if (rc != XRIT_OK) { d->poisoned = true; return rc; }
     d->stage_n[4] = k;

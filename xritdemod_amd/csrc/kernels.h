@@ -225,6 +225,7 @@ struct ClockStage {
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
         bool relay = false;                     // ... is on for this call
         bool relay_force = false;               // ... although the tiled hand-off never closed (pass budget used up)
+        int relay_budget = 0;                   // relay passes at most (0: until closed)
         int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
     } job;
     bool pass_writes = true;    // the last hand-off pass is the output pass (XRIT_NO_PASS_OUTPUT=1, read at init: a separate output pass)
@@ -233,9 +234,15 @@ struct ClockStage {
                             // (5-6 in steady state)
     // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
     // serial trajectory is reproduced bit for bit
-    int exact = 0;              // 0: when the hand-off stalls above auto_rms; 1: always, until closed; n > 1: always, at most n
-                                // relay passes (partial closure); < 0: never
+    int exact = 0;              // 0: when the hand-off stalls above auto_rms; 1: always, until closed; n > 1: always, n relay
+                                // passes (partial closure; 3: the "balanced" configuration of bench.py); < 0: never
     float auto_rms = 3e-4f;     // rms hand-off residual (samples) beyond which a call is closed exactly on its own
+    // (experiment, XRIT_AUTO_PASSES=n: cfg.clock_exact = 0 runs n relay passes on every call of auto_min symbols or more and
+    // walks on to closure when the starts still moved by more than auto_shift rms in the last of them -- measured at C2
+    // after three passes: 3.8e-4 sample at Es/N0 12 dB, 1.1e-3 at 6 dB, 4.3e-3 at 3 dB)
+    int auto_passes = 0;
+    float auto_shift = 6e-4f;
+    long long auto_min = 16384;
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
     DevBuf relay;               // segment records + per-pass counters
