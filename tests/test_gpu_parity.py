@@ -287,6 +287,27 @@ def test_soft_symbol_target_of_1e_4(xa, oracle_mod, case):
 
 
 @pytest.mark.parametrize("case", list(CASES))
+def test_three_relay_passes_are_within_reach_of_the_floor(xa, oracle_mod, case):
+    """cfg.clock_exact = 3, bench.py's `balanced_mode`: two hand-off passes, then three relay passes -- no closure, 0.6 ms
+    more than the default per 2^28-sample burst.  The symbols are then within 20 % of the floor the serial trajectory
+    itself has against the oracle (C2 bench burst: 8.1e-5 against 8.06e-5; the default: 2.2e-4), hard decisions equal."""
+    mode, fs, D, kw, n = CASES[case]
+    x = synth_signal(4 * n if case == "C2" else 2 * n, **kw)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=3))
+    got = dem.process(x)
+    st = dem.stats()
+    assert 1 <= st.clock_relay_passes <= 3
+    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
+    fast = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=-1)).process(x)
+    assert len(got) == len(want) == len(ser) == len(fast)
+    r, floor, rf = rms(got - want), rms(ser - want), rms(fast - want)
+    big = np.abs(want) > 1e-3
+    assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
+    assert r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
+
+
+@pytest.mark.parametrize("case", list(CASES))
 def test_exact_closure_is_the_serial_trajectory_bit_for_bit(xa, case):
     """cfg.clock_exact = 1: the relay of exactly walked segments ends with a pass that changes nothing, and the symbols
     are then those of ONE serial trajectory (cfg.clock_serial, a single wave at 0.3 us per symbol), word for word --
