@@ -1185,7 +1185,11 @@ int ClockStage::relay_plan()
     int cps = relay_window > 0 ? relay_window : (j.K + 3 * cu_count - 1) / (3 * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
-    if (relay_window <= 0 && cps * NS < 2048) cps = (2048 + NS - 1) / NS;
+    // With a budget of relay passes (cfg.clock_exact = n > 1) what the passes buy is their horizon, n x the segment length
+    // -- a segment is exact once everything within the merge length in front of it is: segments no shorter than the big
+    // bursts' (16 k symbols), whatever the size of the call, so that n means the same parity everywhere.
+    const int min_syms = j.relay_budget > 0 ? 16384 : 2048;
+    if (relay_window <= 0 && cps * NS < min_syms) cps = (min_syms + NS - 1) / NS;
     if (cps < 1) cps = 1;
     j.cps = cps;
     j.G = (j.K + cps - 1) / cps;
