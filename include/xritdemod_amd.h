@@ -111,15 +111,20 @@ typedef struct xrit_demod_config {
     int32_t  clock_exact;       /* exact closure of the clock recovery's time tiling (csrc/clock_relay.h): the call is cut
                                  * into segments that are walked with the literal recurrence, 64 symbols per step, and
                                  * relayed until a pass changes nothing -- the symbols are then bit for bit those of
-                                 * the serial trajectory (clock_serial = 1), in ~14 ms per 256 Mi-sample burst instead
-                                 * of 3.9 s.
+                                 * the serial trajectory (clock_serial = 1), in ~10 ms per 256 Mi-sample burst instead
+                                 * of 3.9 s.  Calls in which the relay is planned from the start (1, n > 1) run two
+                                 * hand-off passes in front of it instead of five.
                                  *   0 (default): only for a call whose hand-off passes stall above an rms residual of
                                  *      3e-4 sample (low Es/N0: the tiled result then differs from the serial loop in hard
                                  *      decisions); other calls end at the recurrence's ~1e-4-sample floor (DESIGN.md
                                  *      section 6: 2.2e-4 rms in the soft symbols);
                                  *   1: every call, until closed;  n > 1: every call, at most n relay passes -- each pass
-                                 *      extends what every segment knows of its past by one segment
-                                 *      (stats.clock_relay_closed says whether n sufficed);  < 0: never */
+                                 *      extends what every segment knows of its past by one segment (no shorter than
+                                 *      16 384 symbols here, so that n buys the same parity whatever the size of the call;
+                                 *      stats.clock_relay_closed says whether n sufficed).  n = 3 is bench.py's "balanced"
+                                 *      configuration: +0.7 ms per 256 Mi-sample burst, soft symbols within 5 % of the
+                                 *      serial trajectory's distance from the CPU chain (6e-5 rms from the serial
+                                 *      trajectory itself; the default: 2.6e-4);  < 0: never */
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
     int32_t  reserved[3];
 } xrit_demod_config;
