@@ -498,6 +498,13 @@ def main():
                                                                  ser[:min(len(ge), len(ser))].view(np.uint32)).sum())
                     out["parity_vs_oracle"][key] = ex
                 out["parity_vs_oracle"]["target_rms"] = 1e-4
+                out["parity_vs_oracle"]["target_met"] = {
+                    "default (value)": bool(out["parity_vs_oracle"]["rms"] <= 1e-4),
+                    **{k: bool(out["parity_vs_oracle"][k]["rms"] <= 1e-4) for k in soft0_alt if k in out["parity_vs_oracle"]},
+                    "serial_gpu (the floor)": bool(fl["rms"] <= 1e-4),
+                    "note": "the throughput at which the target is met is balanced_mode.value (cfg.clock_exact = 3); the "
+                            "default trades 1.4e-4 rms of soft-symbol parity (3 % of an int8 LSB of what the decoder "
+                            "receives) for 0.8 ms per step"}
                 out["parity_vs_oracle"]["floor_note"] = ("serial_gpu_rms is the measured floor of a hand-off-free float32 "
                                                          "M&M on this chain's Costas output; the time-tiled evaluation "
                                                          "adds the rest")
