@@ -565,9 +565,12 @@ def test_capacity_and_argument_errors(xa):
             xa.Demodulator(bad)
 
 
-def test_prefetched_front_ends_give_the_same_symbols(xa):
+@pytest.mark.parametrize("exact", [0, 3, 1])
+def test_prefetched_front_ends_give_the_same_symbols(xa, exact):
     """xrit_demod_prefetch_device: the front end of later bursts runs ahead on the second stream (two may wait);
-    the symbols are bit for bit those of plain consecutive calls, also when plain and prefetched calls mix."""
+    the symbols are bit for bit those of plain consecutive calls, also when plain and prefetched calls mix.  With the
+    exact closure on (cfg.clock_exact >= 1) a registered front end waits for the relay kernels of the call before its own
+    and starts in front of them -- or, where there are none, when its own call takes it."""
     import torch
     dev = torch.device("cuda", 0)
     n, D, nb = 1500000, 5, 5
@@ -577,7 +580,7 @@ def test_prefetched_front_ends_give_the_same_symbols(xa):
     soft = torch.empty(cap, dtype=torch.float32, device=dev)
 
     def run(plan):
-        dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D))
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D, clock_exact=exact))
         out = []
         for op, b in plan:
             if op == "pf":
@@ -591,10 +594,18 @@ def test_prefetched_front_ends_give_the_same_symbols(xa):
     ahead = run([("pf", 0), ("pf", 1), ("go", 0), ("pf", 2), ("go", 1), ("go", 2), ("go", 3), ("pf", 4), ("go", 4)])
     for a, b in zip(plain, ahead):
         assert np.array_equal(a, b)
-    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D))
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D, clock_exact=exact))
     dem.prefetch_device(xt[0].data_ptr(), n)
     with pytest.raises(xa.XritError):                     # inputs are taken in the order they were prefetched
         dem.process_device(xt[1].data_ptr(), n, soft.data_ptr(), cap)
+    # a handle that is reset or destroyed with a registered input it never started
+    dem2 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D, clock_exact=exact))
+    dem2.prefetch_device(xt[0].data_ptr(), n)
+    dem2.reset()
+    k = dem2.process_device(xt[0].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy(), plain[0])
+    dem2.prefetch_device(xt[1].data_ptr(), n)
+    del dem2
 
 
 def test_run_to_run_determinism(xa):

@@ -1536,7 +1536,10 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
     }
     // (exact closure: the first relay pass walks every segment and writes every symbol; there is no output pass)
-    if (j.relay && K > 1) return enqueue_relay(relay_batch, true, s, prof);
+    if (j.relay && K > 1) {
+        if (before_relay) XR_TRY(before_relay());
+        return enqueue_relay(relay_batch, true, s, prof);
+    }
     return enqueue_output(s, prof);
 }
 

@@ -140,12 +140,15 @@ __device__ unsigned long long relay_dbg[16];
 #define RELAY_TICK(i) do { } while (0)
 #endif
 
-constexpr int RELAY_RX = 4096;       // sample ring (RING): about ten steps of lead for the prefetching wave
-constexpr int RELAY_XCH = 1024;      // samples per refill (16 per lane)
+constexpr int RELAY_RX = 2048;       // sample ring (RING): about five steps of lead for the prefetching wave.  (Twice the size is as fast for the
+                                     // walk, but three workgroups then hold 135 KB of a CU's LDS and the front end of the next burst, started in
+                                     // front of the relay -- xrit_demod_prefetch_device --, cannot move in next to them: 2.65 against 2.33 ms per
+                                     // burst in the three-pass configuration; half the size again costs the walk 6 %.)
+constexpr int RELAY_XCH = 512;       // samples per refill (8 per lane)
 constexpr int RELAY_ROUNDS = 4;      // guess rounds per step at most
 constexpr int RELAY_XMIR = 8;        // the ring's first samples again behind its end: a window never wraps
-constexpr int RELAY_GR = 2048;       // ring of first guesses (symbols), refilled RELAY_GCH at a time
-constexpr int RELAY_GCH = 512;
+constexpr int RELAY_GR = 1024;       // ring of first guesses (symbols), refilled RELAY_GCH at a time
+constexpr int RELAY_GCH = 256;
 constexpr unsigned RELAY_NOGUESS = 0xffffffffu;
 constexpr int RELAY_REF_MARGIN = 1 << 20;     // a segment's reference index sits this far in front of its nominal start
 
@@ -223,7 +226,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         while (!relay_ld(&sh_done)) {
             if (++rounds > (1u << 24)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
             const int pii = relay_ld(&sh_pos_ii);
-            const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= nlast + RELAY_XCH;
+            // (... and not beyond what a walker standing on the last sample can ask for: its block's span)
+            const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= nlast + span + 16;
             bool fg = false;
             if (use_rec) fg = g_hi < Lseg && g_hi + RELAY_GCH - RELAY_GR <= relay_ld(&sh_pos_n);
             if (!fx && !fg) { __builtin_amdgcn_s_sleep(4); continue; }

@@ -57,14 +57,19 @@ struct xrit_demod {
     int next_set = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
+    hipEvent_t ev_relay = nullptr;                                  // the relay kernels of the current call come next
     int last_fe_set = -1;       // set of the front end that ran last (its event orders the next one behind it)
     struct Prefetched {
         const void *samples = nullptr; size_t n = 0; int type = 0; int set = 0;
         size_t length = 0; const float2 *rrc = nullptr; bool stat_ready = false; const float *agc_flag = nullptr;
+        bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
+                                // starts the front end of the next burst in front of the relay kernels of the current one,
+                                // which leave most of the chip idle, instead of under the loops that fill it
     } pf[2];                    // front ends that ran ahead, oldest first: the one of the next process call, and
     int pf_count = 0;           // at most the one after it
     RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
+    bool no_defer = false;      // XRIT_NO_DEFER: registered front ends start at once also with the exact closure on (A/B runs)
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
     bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
     bool agc_fallback_seen = false;   // this call: the AGC's guard sent a slice down the serial path
@@ -198,10 +203,17 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
     d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
     int rc = XRIT_OK;
     do {
-        if (hipStreamCreate(&d->stream) != hipSuccess || hipStreamCreate(&d->stream2) != hipSuccess ||
+        // (the second stream at the lowest priority: a hardware queue of its own -- streams of one priority share a few
+        // queues round-robin, and a front end that lands in the queue of the caller's stream does not overlap anything --
+        // and the loops of the current burst go first where the two compete)
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreate(&d->stream) != hipSuccess ||
+            hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, getenv("XRIT_FE_NORMAL_PRIORITY") ? 0 : prio_least) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+            hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_relay, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
@@ -214,6 +226,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;
         d->clock.exact = cfg->clock_exact;
+        d->no_defer = getenv("XRIT_NO_DEFER") != nullptr;
         d->clock.relay_window = cfg->clock_exact_window > 0 ? cfg->clock_exact_window : 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
@@ -232,6 +245,7 @@ void xrit_demod_destroy(xrit_demod *d)
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+    if (d->ev_relay) (void)hipEventDestroy(d->ev_relay);
     for (int i = 0; i < 2; ++i) if (d->ev_fe[i]) (void)hipEventDestroy(d->ev_fe[i]);
     for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->bufC[i].release(); d->bufR[i].release(); d->stat[i].release(); }
     d->rtl.release();
@@ -353,6 +367,28 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     return XRIT_OK;
 }
 
+// the front end of a registered input on stream2 (xrit_demod_prefetch_device); `after`: not before this event
+static int launch_prefetched(xrit_demod *d, xrit_demod::Prefetched &f, hipEvent_t after)
+{
+    // stream2 may read the input once whatever the caller queued on its stream at registration is done, and may touch
+    // the stages once the previous front end (on either stream) is done
+    XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_ready, 0));
+    if (after) XR_HIP(hipStreamWaitEvent(d->stream2, after, 0));
+    if (d->last_fe_set >= 0) XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_fe[d->last_fe_set], 0));
+    const int set = d->next_set;
+    d->next_set ^= 1;
+    SliceIO io;
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    int rc = front_end(d, f.samples, f.n, f.type, set, d->stream2, prof, &io);
+    if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+    XR_HIP(hipEventRecord(d->ev_fe[set], d->stream2));
+    d->last_fe_set = set;
+    f.set = set;
+    f.length = io.length; f.rrc = io.rrc; f.stat_ready = io.stat_ready; f.agc_flag = io.agc_flag;
+    f.launched = true;
+    return XRIT_OK;
+}
+
 static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, size_t *nsym, hipStream_t s, Profiler *prof)
 {
     const size_t length = io.length;
@@ -373,7 +409,18 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
     const double inv_sps = 1.0 / (double)d->sps;
     const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
     XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
-    XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
+    // (a registered front end of the next burst goes in front of this call's relay kernels)
+    d->clock.before_relay = [d, s]() -> int {
+        if (d->pf_count > 0 && !d->pf[0].launched) {
+            if (d->clock.trace_env) fprintf(stderr, "[xrit] the registered front end starts in front of the relay kernels\n");
+            XR_HIP(hipEventRecord(d->ev_relay, s));
+            return launch_prefetched(d, d->pf[0], d->ev_relay);
+        }
+        return XRIT_OK;
+    };
+    const int rc_begin = d->clock.begin(length, d_soft, sym, cap, s, prof);
+    d->clock.before_relay = nullptr;
+    XR_TRY(rc_begin);
     if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
     XR_HIP(hipStreamSynchronize(s));
     if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
@@ -423,12 +470,14 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     int rc = XRIT_OK;
     if (d->pf_count > 0) {
         // the front end of this call ran ahead (xrit_demod_prefetch_device): the loops wait for it, nothing else
-        const xrit_demod::Prefetched f = d->pf[0];
-        if (f.samples != d_samples || f.n != n || f.type != type) {
+        if (d->pf[0].samples != d_samples || d->pf[0].n != n || d->pf[0].type != type) {
             set_error("process calls must take the prefetched inputs in the order they were prefetched");
             d->poisoned = true;
             return XRIT_E_INVALID;
         }
+        // (registered only: the call before had no relay phase to put it in front of)
+        if (!d->pf[0].launched) XR_TRY(launch_prefetched(d, d->pf[0], nullptr));
+        const xrit_demod::Prefetched f = d->pf[0];
         d->pf[0] = d->pf[1];
         --d->pf_count;
         io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
@@ -530,19 +579,20 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     // stream2 may read the input once whatever the caller queued on its stream is done, and may touch the stages once
     // the previous front end (on either stream) is done
     XR_HIP(hipEventRecord(d->ev_ready, s));
-    XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_ready, 0));
-    if (d->last_fe_set >= 0) XR_HIP(hipStreamWaitEvent(d->stream2, d->ev_fe[d->last_fe_set], 0));
-    const int set = d->next_set;
-    d->next_set ^= 1;
-    SliceIO io;
-    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
-    int rc = front_end(d, d_samples, n, type, set, d->stream2, prof, &io);
-    if (rc != XRIT_OK) { d->poisoned = true; return rc; }
-    XR_HIP(hipEventRecord(d->ev_fe[set], d->stream2));
-    d->last_fe_set = set;
-    xrit_demod::Prefetched &f = d->pf[d->pf_count++];
-    f.samples = d_samples; f.n = n; f.type = type; f.set = set;
-    f.length = io.length; f.rrc = io.rrc; f.stat_ready = io.stat_ready; f.agc_flag = io.agc_flag;
+    xrit_demod::Prefetched &f = d->pf[d->pf_count];
+    f = xrit_demod::Prefetched{};
+    f.samples = d_samples; f.n = n; f.type = type; f.launched = false;
+    // With the exact closure on (cfg.clock_exact >= 1) the next process call ends in relay kernels that occupy three
+    // waves per CU: the front end waits for those (ClockStage::before_relay) instead of competing with the Costas and
+    // hand-off passes.  (Registered inputs start in order: the process call that takes one starts it if it still waits,
+    // and starts the one behind it in front of its own relay kernels.)
+    const bool defer = d->clock.exact >= 1 && !d->no_defer;
+    if (!defer) {
+        // (front ends run in the order of their inputs: one that is still waiting goes first)
+        if (d->pf_count > 0 && !d->pf[0].launched) XR_TRY(launch_prefetched(d, d->pf[0], nullptr));
+        XR_TRY(launch_prefetched(d, f, nullptr));
+    }
+    ++d->pf_count;
     return XRIT_OK;
 }
 

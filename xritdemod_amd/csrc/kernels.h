@@ -1,6 +1,8 @@
 // kernels.h -- stage objects of the chain (device state + launch plans).
 #pragma once
 
+#include <functional>
+
 #include "common.h"
 #include "loop_core.h"
 #include "taps.h"
@@ -245,6 +247,8 @@ struct ClockStage {
     long long auto_min = 16384;
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
+    std::function<int()> before_relay;   // called by begin() in front of the relay kernels of a call that plans them (the chain
+                                         // starts the front end of the next burst there: xrit_demod_prefetch_device)
     DevBuf relay;               // segment records + per-pass counters
     DevBuf relay_rec;           // per symbol: read index and interpolator arm of the last exact walk (the next walk's first guess)
     bool relay_no_rec = false;  // XRIT_RELAY_NO_REC: walkers always guess from the nominal rate (A/B runs)
