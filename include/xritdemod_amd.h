@@ -108,23 +108,27 @@ typedef struct xrit_demod_config {
                                  * against the CPU chain is what any float32 M&M fed by this chain's Costas output
                                  * shows (the recurrence lives on a 2^-21-sample lattice and keeps a one-ulp
                                  * difference for ~1e5 symbols).  A diagnostic, not a production mode. */
-    int32_t  clock_exact;       /* exact closure of the clock recovery's time tiling (csrc/clock_relay.h): the call is cut
-                                 * into segments that are walked with the literal recurrence, 64 symbols per step, and
-                                 * relayed until a pass changes nothing -- the symbols are then bit for bit those of
-                                 * the serial trajectory (clock_serial = 1), in ~10 ms per 256 Mi-sample burst instead
-                                 * of 3.9 s.  Calls in which the relay is planned from the start (1, n > 1) run two
-                                 * hand-off passes in front of it instead of five.
-                                 *   0 (default): only for a call whose hand-off passes stall above an rms residual of
-                                 *      3e-4 sample (low Es/N0: the tiled result then differs from the serial loop in hard
-                                 *      decisions); other calls end at the recurrence's ~1e-4-sample floor (DESIGN.md
-                                 *      section 6: 2.2e-4 rms in the soft symbols);
-                                 *   1: every call, until closed;  n > 1: every call, at most n relay passes -- each pass
-                                 *      extends what every segment knows of its past by one segment (no shorter than
-                                 *      16 384 symbols here, so that n buys the same parity whatever the size of the call;
-                                 *      stats.clock_relay_closed says whether n sufficed).  n = 3 is bench.py's "balanced"
-                                 *      configuration: +0.7 ms per 256 Mi-sample burst, soft symbols within 5 % of the
-                                 *      serial trajectory's distance from the CPU chain (6e-5 rms from the serial
-                                 *      trajectory itself; the default: 2.6e-4);  < 0: never */
+    int32_t  clock_exact;       /* the relay of the clock recovery (csrc/clock_relay.h): the call is cut into segments that
+                                 * are walked with the literal recurrence, 64 symbols per step, from the end states the
+                                 * segments in front of them reached a pass earlier.  Every pass extends what a segment
+                                 * knows of its past by one segment (no shorter than 16 384 symbols unless the relay
+                                 * runs to closure); a pass that changes nothing has reproduced the serial trajectory
+                                 * (clock_serial = 1) bit for bit.
+                                 *   0 (default): two hand-off passes, then three relay passes -- soft symbols within
+                                 *      5 % of the serial trajectory's own distance from the CPU chain (6e-5 rms from the
+                                 *      serial trajectory itself), 2.3 ms per 256 Mi-sample burst; walked on to closure on
+                                 *      its own when the segment starts still move by more than 6e-4 sample rms in the
+                                 *      third pass (low Es/N0: hard decisions would differ from the serial loop's) or the
+                                 *      hand-off passes never closed (stats.clock_relay_closed).  Calls of fewer than
+                                 *      4096 symbols: hand-off passes, which close such calls exactly or, stalled above
+                                 *      3e-4 sample rms, hand over to the relay;
+                                 *   1: every call to closure (~9 ms per 256 Mi-sample burst; the serial wave: 3.9 s);
+                                 *   n > 1: two hand-off passes and n relay passes, nothing else;
+                                 *   -2: hand-off passes only, five of them on a clean signal -- the fast configuration
+                                 *      (2.1 ms per burst, soft symbols 2.2e-4 .. 2.6e-4 rms from the serial trajectory:
+                                 *      DESIGN.md section 6); a call whose passes stall above 3e-4 sample rms (low Es/N0)
+                                 *      or never close is still relayed to closure (rounds 2-3's default);
+                                 *   -1: hand-off passes only, never relayed. */
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
     int32_t  reserved[3];
 } xrit_demod_config;

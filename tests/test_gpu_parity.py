@@ -426,19 +426,32 @@ def test_partial_relay_trades_passes_for_parity(xa):
 
 
 def test_stalled_hand_off_is_closed_exactly_on_its_own(xa):
-    """Default configuration (clock_exact = 0): a call whose hand-off passes stall above 3e-4 sample rms -- low Es/N0 --
-    is relayed to closure without being asked (stats.clock_relay_closed), i.e. its symbols are the serial trajectory's;
-    a call at 12 dB is not (no relay passes, the tiled result)."""
+    """Default configuration (clock_exact = 0): two hand-off passes and three relay passes; a call whose segment starts
+    still move by more than 6e-4 sample rms in the third pass -- low Es/N0 -- is walked on to closure without being asked
+    (stats.clock_relay_closed), i.e. its symbols are the serial trajectory's; a call at 12 dB stays with the three.
+    The fast configuration (clock_exact = -2, the default of rounds 2-3): hand-off passes only, relayed to closure when
+    they stall above 3e-4 sample rms -- the 3 dB call -- and not otherwise."""
     fs, D, n = 6.25e6, 5, 1500000
-    for esn0, expect in ((3.0, True), (12.0, False)):
+    for esn0, low in ((3.0, True), (12.0, False)):
         x = synth.generate(synth.SynthParams(fs_in=fs, esn0_db=esn0, seed=77), n)
+        ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_serial=1)).process(x)
         dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
         got = dem.process(x)
         st = dem.stats()
-        assert (st.clock_relay_passes > 0) == expect, (esn0, st.clock_relay_passes, st.clock_max_residual)
-        if expect:
-            ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_serial=1)).process(x)
+        assert st.clock_relay_passes >= 1 and (low or st.clock_passes <= 12), (esn0, st.clock_relay_passes, st.clock_passes)
+        if low:
             assert st.clock_relay_closed == 1 and np.array_equal(got.view(np.uint32), ser.view(np.uint32))
+        else:
+            assert st.clock_relay_passes <= 3 and rms(got - ser) <= 1.2e-4
+        fast = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_exact=-2))
+        gf = fast.process(x)
+        sf = fast.stats()
+        assert (sf.clock_relay_passes > 0) == low, (esn0, sf.clock_relay_passes, sf.clock_max_residual)
+        if low:
+            assert sf.clock_relay_closed == 1 and np.array_equal(gf.view(np.uint32), ser.view(np.uint32))
+        never = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_exact=-1))
+        never.process(x)
+        assert never.stats().clock_relay_passes == 0
 
 
 def test_serial_device_floor_and_what_tiling_adds(xa, oracle_mod):
@@ -1487,15 +1500,19 @@ def test_low_snr_regression_seeds(xa, oracle_mod, seed, esn0, carrier, ppm, toff
     _, ser = _run_case(xa, oracle_mod, *case, clock_serial=1)
     big = np.abs(w) > 1e-3
     assert np.array_equal(np.sign(w[big]), np.sign(ser[big])) and rms(w - ser) <= 5e-4
-    # round 3: a call whose hand-off passes stall above 3e-4 sample rms is closed exactly without being asked -- the
-    # default configuration then IS the serial device run, word for word (the second seed: residuals stall at 1e-3;
-    # round 2: a flipped decision, rms 1.0e-3).  The first seed's hand-off settles at 8e-5 like a clean signal's and
-    # stays the tiled result (2.5e-4 from the serial run, no decision differs).
-    assert relayed == (seed == 151577245)
-    if relayed:
-        assert np.array_equal(g.view(np.uint32), ser.view(np.uint32))
+    # The default configuration relays every call of this size; two segments close in at most three passes: it IS the
+    # serial device run, word for word.
+    assert relayed and np.array_equal(g.view(np.uint32), ser.view(np.uint32))
+    # The fast configuration (clock_exact = -2, the default of rounds 2-3): a call whose hand-off passes stall above 3e-4
+    # sample rms is closed exactly without being asked (the second seed: residuals stall at 1e-3; round 2: a flipped
+    # decision, rms 1.0e-3).  The first seed's hand-off settles at 8e-5 like a clean signal's and stays the tiled
+    # result (2.5e-4 from the serial run, no decision differs).
+    _, gf = _run_case(xa, oracle_mod, *case, clock_exact=-2)
+    assert (_run_case.relay_passes > 0) == (seed == 151577245)
+    if _run_case.relay_passes > 0:
+        assert np.array_equal(gf.view(np.uint32), ser.view(np.uint32))
     else:
-        assert np.array_equal(np.sign(w[big]), np.sign(g[big])) and rms(g - ser) <= 3.2e-4
+        assert np.array_equal(np.sign(w[big]), np.sign(gf[big])) and rms(gf - ser) <= 3.2e-4
     _, til = _run_case(xa, oracle_mod, *case, clock_exact=-1)
     assert int(np.sum(np.sign(w[big]) != np.sign(til[big]))) <= 3 and rms(w - til) <= 1.5e-3
 

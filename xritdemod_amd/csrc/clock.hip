@@ -1498,8 +1498,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         j.gated = force_gated;
         j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !no_meanj;
     }
-    // cfg.clock_exact: 1 -- relayed to closure; n > 1 -- n relay passes; 0 -- hand-off passes, relayed from finish() when
-    // they stall high (or, XRIT_AUTO_PASSES: that many relay passes on every call, kernels.h); < 0 -- hand-off passes only
+    // cfg.clock_exact: 1 -- relayed to closure; n > 1 -- n relay passes; 0 -- auto_passes of them, and on to closure from
+    // finish() when the walks have not settled by then (calls of fewer than auto_min symbols: hand-off passes, relayed from
+    // finish() when they stall high); < 0 -- hand-off passes only
     j.relay = exact >= 1 || (exact == 0 && auto_passes > 0 && (long long)K * NS >= auto_min);
     j.relay_budget = exact > 1 ? exact : (exact == 1 ? 0 : auto_passes);
     if (j.relay) XR_TRY(relay_plan());
@@ -1565,7 +1566,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     if (!in_batch) {
         // (past 48 passes a hand-off that is still open is an acquisition that closes a chain or two per pass: unless
         // the exact closure is switched off the relay takes over -- it walks from whatever start states there are)
-        const int give_up = exact >= 0 && max_passes > 48 ? 48 : max_passes;
+        const int give_up = exact != -1 && max_passes > 48 ? 48 : max_passes;
         while (hctl[0] == 0 && job.enqueued < give_up) {
             // a boundary outside the trust region (acquisition, a slip): from here on the gated three-launch solve
             if (hctl[NEWTON_CTL_TAKEOVER]) job.gated = true;
@@ -1583,8 +1584,8 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     relay_passes = 0;
     relay_closed = false;
     relay_auto = false;
-    if (exact == 0 && job.K > 1 && !job.relay) {
-        // (a call too short for the relay to be planned at its start)
+    if ((exact == 0 || exact <= -2) && job.K > 1 && !job.relay) {
+        // (cfg.clock_exact = 0: a call too short for the relay to be planned at its start; -2: the fast configuration)
         // The hand-off passes normally stall at the recurrence's own floor, an rms residual of ~1e-4 sample (Es/N0 12 dB).
         // At low Es/N0 they stall at 5e-4 .. 1e-3 instead -- every wrong decision kicks mu by 2e-3 -- and which
         // near-zero symbols then fall on the other side differs from the serial loop (a third
@@ -1606,7 +1607,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     }
     if (job.relay && job.K > 1) {
         if (exact == 0 && !relay_auto && hctl[11] == 0) {
-            // (XRIT_AUTO_PASSES) after the budgeted passes the starts of a clean signal move by a few 1e-4 sample rms from
+            // The default: after its three passes the segment starts of a clean signal move by a few 1e-4 sample rms from
             // pass to pass.  Where they still move by more -- low Es/N0: every decision that differs kicks mu by 2e-3 --,
             // or the hand-off passes never closed, the call is walked to closure: the serial trajectory whatever the noise.
             float shift_sq;

@@ -582,11 +582,11 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     xrit_demod::Prefetched &f = d->pf[d->pf_count];
     f = xrit_demod::Prefetched{};
     f.samples = d_samples; f.n = n; f.type = type; f.launched = false;
-    // With the exact closure on (cfg.clock_exact >= 1) the next process call ends in relay kernels that occupy three
+    // Unless the relay is off (cfg.clock_exact < 0) the next process call ends in relay kernels that occupy three
     // waves per CU: the front end waits for those (ClockStage::before_relay) instead of competing with the Costas and
     // hand-off passes.  (Registered inputs start in order: the process call that takes one starts it if it still waits,
     // and starts the one behind it in front of its own relay kernels.)
-    const bool defer = d->clock.exact >= 1 && !d->no_defer;
+    const bool defer = d->clock.relay_by_default() && !d->no_defer;
     if (!defer) {
         // (front ends run in the order of their inputs: one that is still waiting goes first)
         if (d->pf_count > 0 && !d->pf[0].launched) XR_TRY(launch_prefetched(d, d->pf[0], nullptr));

@@ -236,15 +236,20 @@ struct ClockStage {
                             // (5-6 in steady state)
     // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
     // serial trajectory is reproduced bit for bit
-    int exact = 0;              // 0: when the hand-off stalls above auto_rms; 1: always, until closed; n > 1: always, n relay
-                                // passes (partial closure; 3: the "balanced" configuration of bench.py); < 0: never
-    float auto_rms = 3e-4f;     // rms hand-off residual (samples) beyond which a call is closed exactly on its own
-    // (experiment, XRIT_AUTO_PASSES=n: cfg.clock_exact = 0 runs n relay passes on every call of auto_min symbols or more and
-    // walks on to closure when the starts still moved by more than auto_shift rms in the last of them -- measured at C2
-    // after three passes: 3.8e-4 sample at Es/N0 12 dB, 1.1e-3 at 6 dB, 4.3e-3 at 3 dB)
-    int auto_passes = 0;
+    int exact = 0;              // 0 (default): two hand-off passes, auto_passes relay passes, and on to closure when the segment
+                                // starts still move by more than auto_shift by then (low Es/N0) or the hand-off never closed;
+                                // 1: always until closed; n > 1: n relay passes, nothing else; -2: hand-off passes only (the
+                                // fast configuration: five of them, 2.6e-4 rms from the serial trajectory), relayed to closure
+                                // when they stall above auto_rms or never close (round 2's default); -1: never relayed
+    float auto_rms = 3e-4f;     // (calls too short for the relay to be planned -- fewer than auto_min symbols -- and
+                                // cfg.clock_exact = 0: closed exactly when the hand-off stalls above this rms residual, samples)
+    // the default's three relay passes: measured at C2 after the third, the starts move by 3.8e-4 sample rms at Es/N0
+    // 12 dB, 1.1e-3 at 6 dB, 4.3e-3 at 3 dB (XRIT_AUTO_PASSES=n: another count; 0: the hand-off passes' result as in
+    // round 2 unless they stall)
+    int auto_passes = 3;
     float auto_shift = 6e-4f;
-    long long auto_min = 16384;
+    long long auto_min = 4096;
+    bool relay_by_default() const { return exact >= 1 || (exact == 0 && auto_passes > 0); }
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
     std::function<int()> before_relay;   // called by begin() in front of the relay kernels of a call that plans them (the chain
