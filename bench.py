@@ -287,6 +287,9 @@ def main():
         "agc_apply": 2 * c8, "fir_rrc": 2 * c8,      # the AGC reduce sweep lives in fir_decim's epilogue
         "costas_pass": c8, "costas_final": 2 * c8,      # the guesses read per-chain statistics only (fused upstream)
         "clock_pass_jac": c8, "clock_pass": c8, "clock_output": c8 + 4.0 / (D * sps),
+        # (one launch bracket = the call's relay passes, three by default: each reads the stream and leaves a soft symbol and
+        # a record word per symbol)
+        "clock_relay": 3 * (c8 + 8.0 / (D * sps)),
     }
     roofline = None
     kernels = {}

@@ -83,14 +83,14 @@ def main():
     out["serial_device"] = {"vs_oracle": cmp(ser, want), "ms_per_call": round(ms, 2)}
     out["tiled"] = {}
     for ns_ in [int(v) for v in args.chains.split(",")]:
-        g, ms, st = run(clock_chain_syms=ns_)
+        g, ms, st = run(clock_chain_syms=ns_, clock_exact=-2)       # (hand-off passes only: the fast configuration)
         out["tiled"][str(ns_)] = {"vs_oracle": cmp(g, want), "vs_serial_device": cmp(g, ser), "ms_per_call": round(ms, 3),
                                   "clock_passes": st.clock_passes, "Msamples_per_s": round(n / ms / 1e3, 1)}
     if args.passes:
         out["forced_passes"] = {}
         for p_ in [int(v) for v in args.passes.split(",")]:
             # max_passes caps both loops (the Costas loop needs 2 here), clock_min_passes keeps the stop rule from ending earlier
-            g, ms, st = run(max_passes=max(p_, 3), clock_min_passes=p_) if p_ >= 3 else run(max_passes=p_)
+            g, ms, st = run(max_passes=max(p_, 3), clock_min_passes=p_, clock_exact=-2) if p_ >= 3 else run(max_passes=p_, clock_exact=-2)
             # (the cap also applies to the cold-started first burst, which may then lock with the other BPSK polarity)
             if len(g) == len(ser) and float(np.dot(g, ser)) < 0:
                 g = -g

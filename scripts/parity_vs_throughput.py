@@ -85,7 +85,9 @@ def main():
 
     row("serial wave (cfg.clock_serial)", ser, ms_ser, run(clock_serial=1)[2])
     o, m, st = run(clock_exact=-1)
-    row("tiled evaluation only (cfg.clock_exact = -1; the default at this Es/N0)", o, m, st)
+    row("tiled evaluation only (cfg.clock_exact = -1 / -2: the fast configuration)", o, m, st)
+    o, m, st = run()
+    row("default configuration (cfg.clock_exact = 0)", o, m, st)
     for passes in (2, 3, 4, 6, 8, 12, 16, 24):
         o, m, st = run(clock_exact=passes)
         row("exact closure stopped after n relay passes", o, m, st, relay_pass_budget=passes)

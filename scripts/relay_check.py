@@ -31,7 +31,7 @@ def main():
         p = synth.SynthParams(fs_in=6.25e6)
         x = synth.generate(p, n)
         ser, tser, _ = run(dict(clock_serial=1), x, calls=2)
-        fast, tf, _ = run({}, x, calls=2)
+        fast, tf, _ = run(dict(clock_exact=-2), x, calls=2)
         for w in (0, 8, 64):
             ex, tex, st = run(dict(clock_exact=1, clock_exact_window=w), x, calls=2)
             for c in range(2):
