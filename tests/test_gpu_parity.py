@@ -4,16 +4,20 @@ Tolerances (float32 path, stated per check):
   * FIR / AGC / RRC / Costas outputs: max |err| <= 2e-5, rms <= 2e-6 relative to signals of amplitude ~0.5
     (different summation order, scan instead of serial gain recurrence, hand-off tolerance 1e-5 rad).
   * recovered symbols: count identical, hard-decision sign identical wherever |oracle| > 1e-3 (Es/N0 >= 6 dB; below,
-    see test_randomised_chains), rms <= 3.2e-4 -- pinned ~1.3x above what is measured (2.0e-4 .. 2.5e-4 on every
-    configuration and burst size), so that a regression shows.  BASELINE.json asks for 1e-4: that target is kept as
-    an expected failure (test_soft_symbol_target_of_1e_4).  Why it is missed, measured: the
-    M&M recurrence lives on a lattice -- mu and omega move in steps of 2^-21 sample (float32 near 4.25), the
-    interpolator arm is rint(mu*128) -- and does not forget a one-step difference for ~1e5 symbols.  The SAME device
-    chain with the clock recovery run as one serial trajectory (cfg.clock_serial, bit-identical to the CPU
-    recurrence on identical input: test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit) is already 1.05e-4 away
-    from the oracle on the bench burst, because its Costas output differs from the oracle's by 1e-6; the time-tiled
-    evaluation adds the rest.  On calls of a few thousand chains or fewer the passes go on until the hand-offs
-    close exactly and the result IS the serial one (test_clock_closes_with_more_passes).
+    see test_randomised_chains), rms <= 3.2e-4 on every call -- the bound of the hand-off passes alone (cfg.clock_exact
+    = -2 / -1, and what calls of fewer than 4096 symbols get: 2.0e-4 .. 2.5e-4 on every configuration and burst size,
+    pinned ~1.3x above what is measured so that a regression shows).  BASELINE.json asks for 1e-4.  Why the hand-off
+    passes miss it, measured: the M&M recurrence lives on a lattice -- mu and omega move in steps of
+    2^-21 sample (float32 near 4.25), the interpolator arm is rint(mu*128) -- and does not forget a one-step difference
+    for ~1e5 symbols.  The SAME device chain with the clock recovery run as one serial trajectory (cfg.clock_serial,
+    bit-identical to the CPU recurrence on identical input: test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit) is
+    already 0.5e-4 .. 1.3e-4 away from the oracle, because its Costas output differs from the oracle's by 1e-6; that is
+    the floor.  The DEFAULT configuration (round 3: two hand-off passes, then three relay passes of csrc/clock_relay.h)
+    is held to it: <= 1e-4, or within 20 % of the serial floor of the same samples where that is above 1e-4
+    (test_three_relay_passes_are_within_reach_of_the_floor, which also runs the default; C2 bench burst: 8.1e-5 against
+    a floor of 8.06e-5); cfg.clock_exact = 1 IS the serial trajectory, word for word (test_soft_symbol_target_of_1e_4,
+    test_exact_closure_is_the_serial_trajectory_bit_for_bit).  On calls of a few thousand chains or fewer the hand-off
+    passes go on until they close exactly and the result is the serial one too (test_clock_closes_with_more_passes).
   * int8 soft symbols (what the decoder receives): within 1 LSB.
 """
 import ctypes as C
@@ -288,9 +292,10 @@ def test_soft_symbol_target_of_1e_4(xa, oracle_mod, case):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_three_relay_passes_are_within_reach_of_the_floor(xa, oracle_mod, case):
-    """cfg.clock_exact = 3, bench.py's `balanced_mode`: two hand-off passes, then three relay passes -- no closure, 0.6 ms
-    more than the default per 2^28-sample burst.  The symbols are then within 20 % of the floor the serial trajectory
-    itself has against the oracle (C2 bench burst: 8.1e-5 against 8.06e-5; the default: 2.2e-4), hard decisions equal."""
+    """cfg.clock_exact = 3 = what the default configuration runs on a clean signal: two hand-off passes, then three relay
+    passes -- no closure, 0.3 ms more per 2^28-sample burst than five hand-off passes.  The symbols are then within 20 %
+    of the floor the serial trajectory itself has against the oracle (C2 bench burst: 8.1e-5 against 8.06e-5; the
+    hand-off passes alone: 2.2e-4), hard decisions equal."""
     mode, fs, D, kw, n = CASES[case]
     x = synth_signal(4 * n if case == "C2" else 2 * n, **kw)
     want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
@@ -298,6 +303,10 @@ def test_three_relay_passes_are_within_reach_of_the_floor(xa, oracle_mod, case):
     got = dem.process(x)
     st = dem.stats()
     assert 1 <= st.clock_relay_passes <= 3
+    # (the default configuration is these three passes, plus the watch on how far the segment starts still move)
+    dflt = xa.Demodulator(xa.Demodulator.config(mode, fs, D))
+    gd = dflt.process(x)
+    assert dflt.stats().clock_relay_passes == st.clock_relay_passes and np.array_equal(gd.view(np.uint32), got.view(np.uint32))
     ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
     fast = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=-1)).process(x)
     assert len(got) == len(want) == len(ser) == len(fast)

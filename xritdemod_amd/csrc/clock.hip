@@ -1117,7 +1117,7 @@ template <typename KernelT> static void clock_allow_lds(KernelT kernel, size_t b
 // ---- exact closure: host side ---------------------------------------------------------------------------------
 // After a batch of relay passes: how many ran, whether they closed, and -- from the end states of the last pass
 // that did something -- the call's result as clock_finalize_kernel leaves it (symbol count, carried state, tail).
-__global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelaySeg *__restrict__ e0,
+__global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySeg *__restrict__ e0,
                                                                     const RelaySeg *__restrict__ e1,
                                                                     const unsigned *__restrict__ changed, int enq, int G,
                                                                     int Lseg, const ClockState *__restrict__ carried_in,
@@ -1146,7 +1146,7 @@ __global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelayS
     }
     __syncthreads();
     const RelaySeg *e = s_buf ? e1 : e0;
-    for (int i = threadIdx.x; i < G; i += 1024)
+    for (int i = threadIdx.x; i < G; i += (int)blockDim.x)
         if (e[i].flags & RELAY_EXHAUSTED) atomicMin(&s_term, i);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(1024) clock_relay_finalize_kernel(const RelayS
     __syncthreads();
     const long long ii = s_ii;
     const long long carry = N - ii;
-    if (threadIdx.x < carry) tail_out[threadIdx.x] = x[ii + threadIdx.x];
+    for (long long i = threadIdx.x; i < carry; i += blockDim.x) tail_out[i] = x[ii + i];
 }
 
 // segments of the exact closure: 3 per CU (what its LDS holds of the staged walk) unless a window is given; the relay
@@ -1250,7 +1250,9 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
             else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
             else hipLaunchKernelGGL((clock_relay_kernel<false, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
         }
-        hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(1024), 0, s, a.ends[0], a.ends[1], changed,
+        // (256 threads: a block of 1024 needs sixteen free wave slots on one CU and, with the next burst's front end filling
+        // the chip behind the relay, waited ~90 us for them)
+        hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(256), 0, s, a.ends[0], a.ends[1], changed,
                            j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
                            clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), j.relay_force ? 1 : 0);
     }
@@ -1538,6 +1540,8 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     }
     // (exact closure: the first relay pass walks every segment and writes every symbol; there is no output pass)
     if (j.relay && K > 1) {
+        // (in front of the relay, not of the hand-off passes: started with those it competes with kernels that fill the
+        // chip and the burst takes 2.9 instead of 2.4 ms)
         if (before_relay) XR_TRY(before_relay());
         return enqueue_relay(relay_batch, true, s, prof);
     }
@@ -1662,7 +1666,10 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         // and a second output pass -- 0.5 ms against the 19 us the four idle launches take.
         last_passes = passes;
         const int want = passes + 1;
-        batch = want < 5 ? 5 : (want > 32 ? 32 : want);   // (small calls run on while boundaries still freeze: 10..20 passes)
+        // (small calls run on while boundaries still freeze: 10..20 passes; a call that hands over to the relay after two
+        // passes does not need five launches enqueued -- the idle ones are 10 us each)
+        const int least = job.relay && passes <= 2 ? 3 : 5;
+        batch = want < least ? least : (want > 32 ? 32 : want);
     }
     if (job.K > 1) {
         const bool clean = in_batch && hctl[NEWTON_CTL_TAKEOVER] == 0 && hctl[9] == 0 && passes <= 12;
