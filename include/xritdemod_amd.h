@@ -171,10 +171,10 @@ int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
  * pointer, count and type); at most two may be waiting.  The reference's input FIFO plays the same role
  * (demodulator.cpp:38,54-74: the frontend thread fills it while the DSP thread works).  A no-op while stage copies
  * or full per-kernel profiling are on.
- * With the exact closure on (clock_exact >= 1) the input is only registered: the process call in between starts its
+ * Unless the relay is off (clock_exact < 0) the input is only registered: the process call in between starts its
  * front end in front of its own relay kernels -- three waves per CU, next to which the front end runs almost for
- * free -- instead of under the Costas and hand-off passes that fill the chip (2.85 -> 2.37 ms per 256 Mi-sample burst
- * with clock_exact = 3); the input must stay valid until the process call that takes it has returned either way.
+ * free -- instead of under the Costas and hand-off passes that fill the chip (2.86 -> 2.35 ms per 256 Mi-sample burst
+ * in the default configuration); the input must stay valid until the process call that takes it has returned either way.
  * The second stream has the lowest stream priority: a hardware queue of its own, behind the loops where they compete. */
 int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type, void *stream);
 /* Back to the state right after xrit_demod_create (filter histories, gain, loop states, unread tail), without
