@@ -1614,11 +1614,20 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             // The default: after its three passes the segment starts of a clean signal move by a few 1e-4 sample rms from
             // pass to pass.  Where they still move by more -- low Es/N0: every decision that differs kicks mu by 2e-3 --,
             // or the hand-off passes never closed, the call is walked to closure: the serial trajectory whatever the noise.
+            // Not to closure at once: four more passes at a time until the starts have settled too (Es/N0 6 dB: after six
+            // passes, 4.4 ms per 2^28-sample burst; at 3 dB they never do before the relay closes, 40 passes).
             float shift_sq;
             memcpy(&shift_sq, &hctl[12], sizeof shift_sq);
-            if (job.relay_force || !(shift_sq <= auto_shift * auto_shift)) {
+            if (job.relay_force) {
                 relay_auto = true;
                 job.relay_budget = 0;
+            }
+            while (!job.relay_force && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
+                relay_auto = true;
+                job.relay_budget = job.relay_enq + 4;
+                XR_TRY(enqueue_relay(4, false, s, prof));
+                XR_HIP(hipStreamSynchronize(s));
+                memcpy(&shift_sq, &hctl[12], sizeof shift_sq);
             }
         }
         // the relay goes on until a pass changes nothing (or the pass budget of a partial closure is used up)

@@ -236,8 +236,8 @@ struct ClockStage {
                             // (5-6 in steady state)
     // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
     // serial trajectory is reproduced bit for bit
-    int exact = 0;              // 0 (default): two hand-off passes, auto_passes relay passes, and on to closure when the segment
-                                // starts still move by more than auto_shift by then (low Es/N0) or the hand-off never closed;
+    int exact = 0;              // 0 (default): two hand-off passes, auto_passes relay passes, four more at a time while the segment
+                                // starts still move by more than auto_shift (low Es/N0), to closure when the hand-off never closed;
                                 // 1: always until closed; n > 1: n relay passes, nothing else; -2: hand-off passes only (the
                                 // fast configuration: five of them, 2.6e-4 rms from the serial trajectory), relayed to closure
                                 // when they stall above auto_rms or never close (round 2's default); -1: never relayed
