@@ -116,11 +116,12 @@ typedef struct xrit_demod_config {
                                  * (clock_serial = 1) bit for bit.
                                  *   0 (default): two hand-off passes, then three relay passes -- soft symbols within
                                  *      5 % of the serial trajectory's own distance from the CPU chain (6e-5 rms from the
-                                 *      serial trajectory itself), 2.3 ms per 256 Mi-sample burst; walked on, four passes at
-                                 *      a time, while the segment starts still move by more than 6e-4 sample rms from pass
-                                 *      to pass (low Es/N0: hard decisions would differ from the serial loop's; 7 passes at
-                                 *      6 dB), and to closure when the hand-off passes never closed
-                                 *      (stats.clock_relay_passes / clock_relay_closed).  Calls of fewer than
+                                 *      serial trajectory itself), 2.3 ms per 256 Mi-sample burst.  Walked to closure on its own
+                                 *      when the soft symbols of the first relay pass show Es/N0 below 7 dB (hard decisions
+                                 *      would otherwise differ from the serial loop's) or the hand-off passes never closed,
+                                 *      and four passes at a time while the segment starts still move by more than 6e-4
+                                 *      sample rms from pass to pass (stats.clock_relay_passes / clock_relay_closed).  Calls
+                                 *      of fewer than
                                  *      4096 symbols: hand-off passes, which close such calls exactly or, stalled above
                                  *      3e-4 sample rms, hand over to the relay;
                                  *   1: every call to closure (~9 ms per 256 Mi-sample burst; the serial wave: 3.9 s);

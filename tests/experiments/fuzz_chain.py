@@ -47,7 +47,7 @@ for c in range(cases):
         xi = x
     per = 1 if typ == 0 else 2
     cuts = sorted(set([0, n] + cutv))
-    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), clock_min_passes=int(os.environ.get("FUZZ_CLOCK_MIN", "0")), **knobs))
+    od, gd = oracle.Demod(oracle.config(mode, fs, D)), xa.Demodulator(xa.Demodulator.config(mode, fs, D, max_passes=int(os.environ.get("FUZZ_PASSES", "0")), clock_min_passes=int(os.environ.get("FUZZ_CLOCK_MIN", "0")), clock_exact=int(os.environ.get("FUZZ_EXACT", "0")), **knobs))
     gd.keep_stages(keep)
     want, got = [], []
     ok = True

@@ -435,10 +435,10 @@ def test_partial_relay_trades_passes_for_parity(xa):
 
 
 def test_stalled_hand_off_is_closed_exactly_on_its_own(xa):
-    """Default configuration (clock_exact = 0): two hand-off passes and three relay passes; a call whose segment starts
-    still move by more than 6e-4 sample rms in the third pass -- low Es/N0 -- is walked on without being asked, four
-    passes at a time, until they have settled or the relay closes (a call of five segments, as here, closes:
-    stats.clock_relay_closed, i.e. its symbols are the serial trajectory's); a call at 12 dB stays with the three.
+    """Default configuration (clock_exact = 0): two hand-off passes and three relay passes; a call whose soft symbols
+    show Es/N0 below 7 dB is walked to closure without being asked (stats.clock_relay_closed, i.e. its symbols are the
+    serial trajectory's), one whose segment starts still move by more than 6e-4 sample rms is walked on four passes at
+    a time; a call at 12 dB stays with the three.
     The fast configuration (clock_exact = -2, the default of rounds 2-3): hand-off passes only, relayed to closure when
     they stall above 3e-4 sample rms -- the 3 dB call -- and not otherwise."""
     fs, D, n = 6.25e6, 5, 1500000

@@ -1124,7 +1124,8 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
                                                                     ClockState *__restrict__ carried_out,
                                                                     ClockResult *__restrict__ res,
                                                                     const float2 *__restrict__ x,
-                                                                    float2 *__restrict__ tail_out, long long N, int *ctl, int force)
+                                                                    float2 *__restrict__ tail_out, long long N, int *ctl, int force,
+                                                                    const unsigned long long *__restrict__ moments)
 {
     if (!ctl[0] && !force) return;      // the tiled hand-off did not close in its batch: ClockStage::finish starts over
     __shared__ int s_term, s_buf;
@@ -1163,6 +1164,13 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
             res->n_symbols = (unsigned long long)k * (unsigned long long)Lseg + (unsigned long long)e[k].n_done;
             s = e[k].s;
         }
+        {
+            // BPSK soft symbols s = +-A + noise: (mean |s|)^2 / (mean s^2 - (mean |s|)^2) ~ A^2 / sigma^2 = 2 Es/N0 (float bits)
+            const double nsym = res->ok ? (double)res->n_symbols : 0.0;
+            const double a1 = nsym > 0 ? (double)moments[0] / 1048576.0 / nsym : 0.0, a2 = nsym > 0 ? (double)moments[1] / 1048576.0 / nsym : 0.0;
+            const double var = a2 - a1 * a1;
+            ctl[14] = __float_as_int(nsym > 0 && var > 0 ? (float)(a1 * a1 / var) : 1e30f);
+        }
         long long ii = s.ii;
         if (ii > N) ii = N;
         if (ii < 0) ii = 0;
@@ -1194,7 +1202,7 @@ int ClockStage::relay_plan()
     j.cps = cps;
     j.G = (j.K + cps - 1) / cps;
     // (counters for G + 1 passes whatever the budget: the default configuration raises its own, ClockStage::finish)
-    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned)));
+    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned) + 2 * sizeof(unsigned long long)));
     if (!relay_no_rec) XR_TRY(relay_rec.reserve((size_t)j.G * cps * NS * sizeof(unsigned)));
     relay_segments = j.G;
     relay_seg_chains = cps;
@@ -1233,11 +1241,12 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     a.soft = j.soft; a.sym = j.sym; a.cap = (unsigned long long)j.cap; a.par = par;
     a.changed = changed; a.ctl = j.relay_force ? nullptr : clock_ctl(counters);
     a.rec = relay_no_rec ? nullptr : relay_rec.as<unsigned>();
+    a.moments = reinterpret_cast<unsigned long long *>(changed + ((size_t)j.G + 1 + 8) * RELAY_STAT);
     if (restart) {
         j.relay_enq = 0;
         const int words = RELAY_STAT * (j.G + 3);
         hipLaunchKernelGGL(clock_relay_init_kernel, dim3(div_up((size_t)words, 256)), dim3(256), 0, s, segs, j.G, changed,
-                           j.G + 3, clock_ctl(counters));
+                           j.G + 3, clock_ctl(counters), a.moments);
     }
     // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
     const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
@@ -1254,7 +1263,8 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
         // the chip behind the relay, waited ~90 us for them)
         hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(256), 0, s, a.ends[0], a.ends[1], changed,
                            j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
-                           clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), j.relay_force ? 1 : 0);
+                           clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), j.relay_force ? 1 : 0,
+                           a.moments);
     }
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -1618,9 +1628,17 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             // passes, 4.4 ms per 2^28-sample burst; at 3 dB they never do before the relay closes, 40 passes).
             float shift_sq;
             memcpy(&shift_sq, &hctl[12], sizeof shift_sq);
-            if (job.relay_force) {
+            float snr2;            // 2 Es/N0 as the first pass's soft symbols show it (12 dB: 32, 7 dB: 10)
+            memcpy(&snr2, &hctl[14], sizeof snr2);
+            snr_estimate = snr2;
+            // Below auto_snr the call is walked to closure: the serial trajectory whatever the noise (in a 2..6 dB fuzz
+            // slice of 60 calls up to 350 k symbols the passes-until-settled rule alone left one hard decision different
+            // from the serial trajectory's -- a call of 14 segments whose starts happened to move by 3e-4 -- and the
+            // hand-off passes of rounds 2-3 ten).
+            if (job.relay_force || !(snr2 >= auto_snr)) {
                 relay_auto = true;
                 job.relay_budget = 0;
+                shift_sq = 0.0f;
             }
             while (!job.relay_force && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
                 relay_auto = true;
@@ -1637,6 +1655,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         }
         relay_passes = hctl[10];
         relay_closed = hctl[11] != 0;
+        if (trace_env && exact == 0) fprintf(stderr, "[xrit] relay: the first pass's soft symbols show 2 Es/N0 = %.1f (to closure below %.1f)\n", (double)snr_estimate, (double)auto_snr);
         if (trace_env) {
             std::vector<unsigned> hc((size_t)relay_passes * RELAY_STAT);
             const unsigned *changed = reinterpret_cast<const unsigned *>(relay.as<RelaySeg>() + 3 * (size_t)job.G);

@@ -69,6 +69,8 @@ struct RelayArgs {
                                   // [+3] largest move of a start against the walk before (float bits) or a watchdog mark,
                                   // [+4, +5] sum of the squared moves (64 bits, 2^-40 sample^2), [+6] moves summed
     const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed (null: do not ask)
+    unsigned long long *moments;  // [2] sum |s| and sum s^2 over the soft symbols of the first relay pass, units of 2^-20 (the
+                                  // default configuration's look at the signal-to-noise ratio: ClockStage::finish)
     unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
                                   // (null: no records -- every block starts from the nominal rate)
 };
@@ -293,6 +295,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     unsigned steps = 0, rounds_total = 0;
     bool exhausted = false;
     int x_hi = x_lo, g_hi = 0;           // what the rings are known to hold (asked again only when that is not enough)
+    float m1 = 0.f, m2 = 0.f;            // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -407,6 +410,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         nv = nv < g ? nv : g;
         if (e < nv) { nv = e; exhausted = true; }
         RELAY_TICK(3);
+        if (pass == 0 && lane < nv) { m1 += fabsf(p0.x); m2 += p0.x * p0.x; }
         if (lane < nv) {
             const int o = n + lane;
             if (o < n_out) {
@@ -442,6 +446,14 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         atomicAdd(&relay_dbg[o + 6], (unsigned long long)steps);
     }
 #endif
+    if (pass == 0 && a.moments) {
+        // (lane sums in step order, lanes added in a fixed tree, segments by integer atomics: the same value run after run)
+        for (int off = 32; off > 0; off >>= 1) { m1 += __shfl_xor(m1, off, 64); m2 += __shfl_xor(m2, off, 64); }
+        if (lane == 0) {
+            atomicAdd(&a.moments[0], (unsigned long long)((double)m1 * 1048576.0));
+            atomicAdd(&a.moments[1], (unsigned long long)((double)m2 * 1048576.0));
+        }
+    }
     if (lane == 0) {
         if (RING) relay_st(&sh_done, 1);
         atomicAdd(&a.changed[RELAY_STAT * pass + 1], steps);
@@ -460,12 +472,13 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
 }
 
 // first relay pass of a call: nothing has been walked
-__global__ void __launch_bounds__(256) clock_relay_init_kernel(RelaySeg *start, int G, unsigned *changed, int npass, int *ctl)
+__global__ void __launch_bounds__(256) clock_relay_init_kernel(RelaySeg *start, int G, unsigned *changed, int npass, int *ctl,
+                                                              unsigned long long *moments)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < G) start[i].flags = 0;
     if (i < RELAY_STAT * npass) changed[i] = 0u;
-    if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; }
+    if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; ctl[14] = 0; moments[0] = 0ull; moments[1] = 0ull; }
 }
 
 }  // namespace xrit
