@@ -188,6 +188,26 @@ def test_costas_on_noise_terminates(xa):
     assert np.allclose(np.abs(y), np.abs(z), rtol=1e-4, atol=1e-6)      # a pure rotation
 
 
+def test_no_signal_is_not_walked_to_closure(xa):
+    """Noise only through the whole chain: neither loop locks, the soft symbols of the first relay pass show
+    (mean |s|)^2 / var |s| = 1.75 (|noise| alone; BPSK at Es/N0 0 dB: 2.4) and the default configuration stays with its
+    three relay passes instead of the closure it runs below 7 dB -- an unlocked loop has no trajectory to close on and
+    would take one pass per segment (fast configuration: the closure its stalled hand-off passes ask for stops after
+    its first batch)."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    x = (0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    y = dem.process(x)
+    st = dem.stats()
+    assert len(y) > 150000 and np.isfinite(y).all()
+    assert 1 <= st.clock_relay_passes <= 3 and st.clock_relay_closed == 0, (st.clock_relay_passes, st.clock_relay_closed)
+    fast = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, clock_exact=-2))
+    yf = fast.process(x)
+    sf = fast.stats()
+    assert len(yf) > 150000 and sf.clock_relay_passes <= 96 and (sf.clock_relay_closed == 0 or sf.clock_relay_segments <= 96)
+
+
 def test_clock_stage(xa, oracle_mod, lrit_1m):
     o = oracle_mod
     d = o.Demod(o.config("lrit", 1.25e6, 1))

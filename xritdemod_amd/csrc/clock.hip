@@ -1635,12 +1635,15 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             // slice of 60 calls up to 350 k symbols the passes-until-settled rule alone left one hard decision different
             // from the serial trajectory's -- a call of 14 segments whose starts happened to move by 3e-4 -- and the
             // hand-off passes of rounds 2-3 ten).
-            if (job.relay_force || !(snr2 >= auto_snr)) {
+            // (... unless there is no signal to speak of: |noise| alone shows 2 / (pi - 2) = 1.75, BPSK at Es/N0 0 dB 2.4; a
+            // loop that is not locked has no trajectory to close on, the relay would run its G + 1 passes for nothing)
+            const bool signal = snr2 >= auto_snr_floor;
+            if (signal && (job.relay_force || !(snr2 >= auto_snr))) {
                 relay_auto = true;
                 job.relay_budget = 0;
-                shift_sq = 0.0f;
             }
-            while (!job.relay_force && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
+            if (!signal || relay_auto) shift_sq = 0.0f;
+            while (!relay_auto && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
                 relay_auto = true;
                 job.relay_budget = job.relay_enq + 4;
                 XR_TRY(enqueue_relay(4, false, s, prof));
@@ -1650,6 +1653,11 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         }
         // the relay goes on until a pass changes nothing (or the pass budget of a partial closure is used up)
         while (hctl[11] == 0 && job.relay_enq < relay_limit()) {
+            // (a closure nobody asked for -- cfg.clock_exact = 0 / -2 -- is not pursued on an input without a signal: an
+            // unlocked loop has no trajectory to close on and would take all G + 1 passes)
+            float snr2;
+            memcpy(&snr2, &hctl[14], sizeof snr2);
+            if (relay_auto && exact != 1 && !(snr2 >= auto_snr_floor)) break;
             XR_TRY(enqueue_relay(relay_batch < 32 ? 32 : relay_batch, false, s, prof));
             XR_HIP(hipStreamSynchronize(s));
         }

@@ -249,6 +249,7 @@ struct ClockStage {
     int auto_passes = 3;
     float auto_shift = 6e-4f;
     float auto_snr = 10.0f;     // ... and to closure outright when the first pass's soft symbols show 2 Es/N0 below this (7 dB)
+    float auto_snr_floor = 2.0f;  // ... but not below this: no signal (noise alone shows 1.75)
     float snr_estimate = 0.f;   // (of the last call that looked)
     long long auto_min = 4096;
     bool relay_by_default() const { return exact >= 1 || (exact == 0 && auto_passes > 0); }
