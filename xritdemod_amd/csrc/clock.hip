@@ -1046,6 +1046,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
+    if (const char *e = getenv("XRIT_RELAY_PER_CU")) relay_per_cu = atoi(e) > 0 ? atoi(e) : 3;
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
     pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
@@ -1190,7 +1191,7 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
 int ClockStage::relay_plan()
 {
     Job &j = job;
-    int cps = relay_window > 0 ? relay_window : (j.K + 3 * cu_count - 1) / (3 * cu_count);
+    int cps = relay_window > 0 ? relay_window : (j.K + relay_per_cu * cu_count - 1) / (relay_per_cu * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
     // With a budget of relay passes (cfg.clock_exact = n > 1) what the passes buy is their horizon, n x the segment length

@@ -269,6 +269,7 @@ struct ClockStage {
     bool no_meanj = false;      // XRIT_NO_MEANJ=1: finite-difference Jacobians in every call
     int ng_max = 8;             // XRIT_CLOCK_NG: one-wave groups per clock workgroup at most
     bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
+    int relay_per_cu = 3;       // XRIT_RELAY_PER_CU: segments (walkers) per CU the relay plans (A/B runs)
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
     int relay_limit() const;
     int relay_plan();
