@@ -137,6 +137,9 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
                  int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af,
                  float2 *__restrict__ hist_new, const float *__restrict__ mfb = nullptr)
 {
+#ifdef XRIT_FE_SETPRIO
+    __builtin_amdgcn_s_setprio(XRIT_FE_SETPRIO);      // (experiment: the filters' waves in front of the relay's walkers at issue)
+#endif
     // (AGC in the window fill: `in` is the serially produced AGC output if the guard has tripped, else see below)
     if (hist_new != nullptr && blockIdx.x == gridDim.x - 1 && (APL == 0 || af.state_out[1] != 0.0f))
         fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
