@@ -395,6 +395,24 @@ def test_exact_walker_from_global_memory(xa, oracle_mod, lrit_1m, monkeypatch):
         assert len(so) == len(sg) and np.array_equal(so.view(np.uint32), sg.view(np.uint32))
 
 
+def test_walker_placement_does_not_change_the_words(xa, monkeypatch):
+    """The relay's workgroups pick the walking wave by where the hardware put their two waves (a walker on the SIMD of an
+    older walker takes a third longer: csrc/clock_relay.h, RelayArgs::simd_claim).  Which wave walks is arithmetic-neutral:
+    XRIT_RELAY_NO_CLAIM=1 (roles by wave number, read when the stage is created) gives the same words, in the default
+    configuration (three relay passes) and to closure, over several calls of one stream (the per-CU words are found clear)."""
+    x = synth.generate(synth.SynthParams(fs_in=1.25e6), 3000000)
+    cuts = ((0, 1000001), (1000001, 1000001), (1000001, 3000000))
+    for exact in (0, 1):
+        a = xa.Demodulator(xa.Demodulator.config("lrit", 1.25e6, 1, clock_exact=exact))
+        monkeypatch.setenv("XRIT_RELAY_NO_CLAIM", "1")
+        b = xa.Demodulator(xa.Demodulator.config("lrit", 1.25e6, 1, clock_exact=exact))
+        monkeypatch.delenv("XRIT_RELAY_NO_CLAIM")
+        for lo, hi in cuts:
+            ya, yb = a.process(x[lo:hi]), b.process(x[lo:hi])
+            assert len(ya) == len(yb) and np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), (exact, lo)
+            assert a.stats().clock_relay_passes == b.stats().clock_relay_passes
+
+
 def test_exact_closure_edge_cases(xa):
     """Against the serial wave, word for word: samples-per-symbol too large for the walker's LDS ring (21 and 68: the
     one-wave walker on global memory; the tiled evaluation on its own uses up its pass budget there and, at 68, miscounts

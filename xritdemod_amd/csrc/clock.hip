@@ -1045,6 +1045,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
+    relay_no_claim = getenv("XRIT_RELAY_NO_CLAIM") != nullptr;
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
     if (const char *e = getenv("XRIT_RELAY_PER_CU")) relay_per_cu = atoi(e) > 0 ? atoi(e) : 3;
     trace_env = getenv("XRIT_TRACE") != nullptr;
@@ -1203,7 +1204,8 @@ int ClockStage::relay_plan()
     j.cps = cps;
     j.G = (j.K + cps - 1) / cps;
     // (counters for G + 1 passes whatever the budget: the default configuration raises its own, ClockStage::finish)
-    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned) + 2 * sizeof(unsigned long long)));
+    XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned) + 2 * sizeof(unsigned long long) +
+                         RELAY_CLAIM_WORDS * sizeof(unsigned)));
     if (!relay_no_rec) XR_TRY(relay_rec.reserve((size_t)j.G * cps * NS * sizeof(unsigned)));
     relay_segments = j.G;
     relay_seg_chains = cps;
@@ -1243,11 +1245,12 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     a.changed = changed; a.ctl = j.relay_force ? nullptr : clock_ctl(counters);
     a.rec = relay_no_rec ? nullptr : relay_rec.as<unsigned>();
     a.moments = reinterpret_cast<unsigned long long *>(changed + ((size_t)j.G + 1 + 8) * RELAY_STAT);
+    a.simd_claim = relay_no_claim ? nullptr : reinterpret_cast<unsigned *>(a.moments + 2);
     if (restart) {
         j.relay_enq = 0;
-        const int words = RELAY_STAT * (j.G + 3);
+        const int words = RELAY_STAT * (j.G + 3) > RELAY_CLAIM_WORDS ? RELAY_STAT * (j.G + 3) : RELAY_CLAIM_WORDS;
         hipLaunchKernelGGL(clock_relay_init_kernel, dim3(div_up((size_t)words, 256)), dim3(256), 0, s, segs, j.G, changed,
-                           j.G + 3, clock_ctl(counters), a.moments);
+                           j.G + 3, clock_ctl(counters), a.moments, a.simd_claim);
     }
     // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
     const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
@@ -1685,6 +1688,13 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             unsigned long long hd[16] = {0}, z[16] = {0};
             XR_HIP(hipMemcpyFromSymbol(hd, HIP_SYMBOL(relay_dbg), sizeof hd));
             XR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z));
+            std::vector<unsigned> wd((size_t)RELAY_WDBG_PASSES * RELAY_WDBG_SEGS * RELAY_WDBG_WORDS);
+            XR_HIP(hipMemcpyFromSymbol(wd.data(), HIP_SYMBOL(relay_wdbg), wd.size() * sizeof(unsigned)));
+            for (int p = 0; p < relay_passes && p < RELAY_WDBG_PASSES; ++p)
+                for (int g = 0; g < job.G && g < RELAY_WDBG_SEGS; ++g) {
+                    const unsigned *w = &wd[((size_t)p * RELAY_WDBG_SEGS + g) * RELAY_WDBG_WORDS];
+                    fprintf(stderr, "[xrit] walker %d %d %u %u %u %u %u %u\n", p, g, w[0], w[1], w[2], w[3], w[4], w[5]);
+                }
             for (int o = 0; o < 16; o += 8) {
                 const double st = hd[o + 6] ? (double)hd[o + 6] : 1.0;
                 fprintf(stderr, "[xrit] relay walker cycles per step, passes %s: wait %.0f, setup %.0f, rounds %.0f, verify %.0f, commit %.0f, loop head %.0f (%llu steps)\n",

@@ -42,6 +42,7 @@ constexpr int RELAY_STAT = 8;        // counters per relay pass (RelayArgs::chan
 constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exactly from start[].s
 constexpr int RELAY_EXHAUSTED = 2;   // ends[]: the input ran out inside this segment (n_done symbols exist)
 constexpr int RELAY_DEAD = 4;        // the input ran out before this segment
+constexpr int RELAY_CLAIM_WORDS = 2048;   // one word per CU, indexed by (XCC_ID, SE_ID, SH_ID, CU_ID)
 
 struct RelaySeg {
     ClockState s;
@@ -73,6 +74,7 @@ struct RelayArgs {
                                   // default configuration's look at the signal-to-noise ratio: ClockStage::finish)
     unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
                                   // (null: no records -- every block starts from the nominal rate)
+    unsigned *simd_claim;         // [RELAY_CLAIM_WORDS] per CU: the SIMDs that hold a walker (null: roles by wave number)
 };
 
 __device__ __forceinline__ bool relay_same_state(const ClockState &a, const ClockState &b)
@@ -137,6 +139,10 @@ __device__ __forceinline__ void relay_st(int *p, int v)
 // (instrumented build, make EXTRA=-DXRIT_RELAY_TIMING: shader-clock cycles the walkers spend per phase of a step, summed
 // over all walkers and passes of a call; printed with XRIT_TRACE)
 __device__ unsigned long long relay_dbg[16];
+// per walker of the first four passes of a call: cycles from its first step to its last, cycles waiting for the rings, steps,
+// guess rounds, HW_ID, XCC_ID (where it ran: which SIMD of which CU)
+constexpr int RELAY_WDBG_SEGS = 1024, RELAY_WDBG_PASSES = 4, RELAY_WDBG_WORDS = 6;
+__device__ unsigned relay_wdbg[RELAY_WDBG_PASSES * RELAY_WDBG_SEGS * RELAY_WDBG_WORDS];
 #define RELAY_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define RELAY_TICK(i) do { } while (0)
@@ -165,11 +171,11 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
     __shared__ cf32 xr[RING ? RELAY_RX + RELAY_XMIR : 1];
     __shared__ unsigned gr[RING ? RELAY_GR : 1];
-    __shared__ int sh_xhi, sh_pos_ii, sh_done, sh_ghi, sh_pos_n;
+    __shared__ int sh_xhi, sh_pos_ii, sh_done, sh_ghi, sh_pos_n, sh_simd[2], sh_swap, sh_claim;
     clock_table_to_lds(table, a.table);
     const int s = blockIdx.x, lane = threadIdx.x & 63;
     // (wave-uniform by construction; said so, so that the two roles are two scalar branches and not two exec masks)
-    const int role = RING ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    int role = RING ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const RelaySeg *ein = a.ends[(pass + 1) & 1];
     RelaySeg *eout = a.ends[pass & 1];
     const int Lseg = a.cps * a.NS;
@@ -209,6 +215,30 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         return;
     }
     if (pass > 0 && (prev.flags & RELAY_WALKED) && relay_same_state(prev.s, T)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
+    // Which of the two waves walks.  A walker is one wave whose every instruction waits for the one before; of two waves
+    // on a SIMD the older one issues first, and a walker that the hardware has put on the SIMD of an older walker (the
+    // third workgroup of a CU, in one CU out of ten) takes a third longer than the others and sets the pace of the pass.
+    // So the workgroup looks where its two waves sit (HW_ID) and which SIMDs of the CU hold a walker already: if wave 0's
+    // is taken and wave 1's is free, the waves swap roles.  (Both waves are still here: every return above is taken by
+    // the whole workgroup.)
+    unsigned *claim = nullptr;
+    if (RING && a.simd_claim) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID: SIMD_ID 5:4; CU_ID, SH_ID, SE_ID in 15:8
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        if (lane == 0) sh_simd[threadIdx.x >> 6] = (int)((hw >> 4) & 3u);
+        __syncthreads();
+        claim = a.simd_claim + ((((xcc & 7u) << 8) | ((hw >> 8) & 255u)) & (RELAY_CLAIM_WORDS - 1));
+        if (threadIdx.x == 0) {
+            const unsigned b0 = 1u << sh_simd[0], b1 = 1u << sh_simd[1];
+            int swap = 0, mine = -1;
+            if (!(atomicOr(claim, b0) & b0)) mine = sh_simd[0];
+            else if (b1 != b0 && !(atomicOr(claim, b1) & b1)) { mine = sh_simd[1]; swap = 1; }
+            sh_swap = swap;
+            sh_claim = mine;
+        }
+        __syncthreads();
+        role ^= __builtin_amdgcn_readfirstlane(sh_swap);
+    }
     const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
     // the record of the walk before (this call's: the flags are cleared when a call's relay starts): prev.n_done symbols,
     // read indices relative to a reference that does not depend on the pass
@@ -298,6 +328,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     float m1 = 0.f, m2 = 0.f;            // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tbegin = tlast;
 #endif
     while (n < Lseg) {
         RELAY_TICK(5);
@@ -444,6 +475,15 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         const int o = pass >= 8 ? 8 : 0;
         for (int q = 0; q < 6; ++q) atomicAdd(&relay_dbg[o + q], tacc[q]);
         atomicAdd(&relay_dbg[o + 6], (unsigned long long)steps);
+        if (pass < RELAY_WDBG_PASSES && s < RELAY_WDBG_SEGS) {
+            unsigned *w = relay_wdbg + ((size_t)pass * RELAY_WDBG_SEGS + s) * RELAY_WDBG_WORDS;
+            w[0] = (unsigned)(__builtin_amdgcn_s_memtime() - tbegin);
+            w[1] = (unsigned)tacc[0];
+            w[2] = steps;
+            w[3] = rounds_total;
+            w[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+            w[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        }
     }
 #endif
     if (pass == 0 && a.moments) {
@@ -456,6 +496,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     }
     if (lane == 0) {
         if (RING) relay_st(&sh_done, 1);
+        if (RING && claim && sh_claim >= 0) atomicAnd(claim, ~(1u << sh_claim));      // (the next pass finds the CU's word clear)
         atomicAdd(&a.changed[RELAY_STAT * pass + 1], steps);
         atomicAdd(&a.changed[RELAY_STAT * pass + 2], rounds_total);
         RelaySeg st0{};
@@ -473,9 +514,10 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
 
 // first relay pass of a call: nothing has been walked
 __global__ void __launch_bounds__(256) clock_relay_init_kernel(RelaySeg *start, int G, unsigned *changed, int npass, int *ctl,
-                                                              unsigned long long *moments)
+                                                              unsigned long long *moments, unsigned *simd_claim)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (simd_claim && i < RELAY_CLAIM_WORDS) simd_claim[i] = 0u;
     if (i < G) start[i].flags = 0;
     if (i < RELAY_STAT * npass) changed[i] = 0u;
     if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; ctl[14] = 0; moments[0] = 0ull; moments[1] = 0ull; }

@@ -260,6 +260,7 @@ struct ClockStage {
     DevBuf relay;               // segment records + per-pass counters
     DevBuf relay_rec;           // per symbol: read index and interpolator arm of the last exact walk (the next walk's first guess)
     bool relay_no_rec = false;  // XRIT_RELAY_NO_REC: walkers always guess from the nominal rate (A/B runs)
+    bool relay_no_claim = false;  // XRIT_RELAY_NO_CLAIM: the walker is always wave 0 of its workgroup, wherever the hardware put it (A/B runs)
     DevBuf stage;               // soft symbols of a writing hand-off pass, in wave order (ClockPassOut::stage)
     int relay_batch = 96;       // relay passes enqueued before the host looks
     int relay_passes = 0;       // relay passes the last call ran (the closing, change-free one included)
