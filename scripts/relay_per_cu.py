@@ -17,7 +17,7 @@ from xritdemod_amd import _capi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2", type=int, default=28)
-    ap.add_argument("--bursts", type=int, default=3)
+    ap.add_argument("--bursts", type=int, default=4)
     ap.add_argument("--grid", default="3x3,2x2,2x3,1x2,4x4,4x3")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -44,13 +44,13 @@ def main():
         return outs, ms, dem.stats()
 
     ser, _, _ = run(clock_serial=1)
-    s = np.concatenate(ser[1:])
+    s = np.concatenate(ser[2:])
     for cell in args.grid.split(","):
         per_cu, passes = (int(v) for v in cell.split("x"))
         os.environ["XRIT_RELAY_PER_CU"] = str(per_cu)
         o, ms, st = run(clock_exact=passes)
-        g = np.concatenate(o[1:])
-        r = {"per_cu": per_cu, "passes": passes, "segments": int(st.clock_relay_segments), "ms_per_burst": round(float(np.mean(ms[1:])), 3)}
+        g = np.concatenate(o[2:])
+        r = {"per_cu": per_cu, "passes": passes, "segments": int(st.clock_relay_segments), "ms_per_burst": round(float(np.mean(ms[2:])), 3)}
         if len(g) == len(s):
             r["rms_vs_serial_device"] = float(np.sqrt(np.mean((g - s) ** 2)))
             r["words_differing"] = int((g.view(np.uint32) != s.view(np.uint32)).sum())
