@@ -584,6 +584,12 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     }
     // block size: keep the LDS window under 64 KiB
     threads = 256;
+    // (XRIT_DEC_THREADS, read here, when the stage is created: the decimator's workgroup size for A/B runs -- smaller
+    // workgroups hold smaller windows, and more of them fit next to the relay's walkers)
+    if (D > 1 && getenv("XRIT_DEC_THREADS")) {
+        const int t = atoi(getenv("XRIT_DEC_THREADS"));
+        if (t == 64 || t == 128 || t == 192 || t == 256) threads = t;
+    }
     for (;;) {
         long long ob = (long long)threads * RC;
         long long tl = (ob - 1) * D + T + (Wpad - W) + 8;
@@ -593,7 +599,7 @@ int FirStage::init(const float *taps, int ntaps, int decim)
             lds_bytes = (size_t)padded * 8;
             break;
         }
-        threads /= 2;
+        threads = threads == 192 ? 128 : threads / 2;
     }
     if (lds_bytes > 160 * 1024) {
         set_error("FIR window of %d taps x decimation %d does not fit LDS", T, D);
