@@ -413,6 +413,30 @@ def test_walker_placement_does_not_change_the_words(xa, monkeypatch):
             assert a.stats().clock_relay_passes == b.stats().clock_relay_passes
 
 
+def test_ab_switches_leave_the_words_alone(xa, monkeypatch):
+    """The A/B switches of the round's last measurements (read when a handle is created) change the schedule, not the
+    arithmetic: the decimator's workgroup size (XRIT_DEC_THREADS: its outputs and the AGC run maps -- one per wave -- are the
+    same) and the relay's segments per CU (XRIT_RELAY_PER_CU: to closure the words are the serial trajectory's whatever the cut)."""
+    fs = 6.25e6
+    x = synth.generate(synth.SynthParams(fs_in=fs), 5 * 700000 + 3)
+    cuts = ((0, 5 * 300000), (5 * 300000, len(x)))
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = xa.Demodulator(xa.Demodulator.config("lrit", fs, 5, clock_exact=1))
+        for k in env:
+            monkeypatch.delenv(k)
+        out = [d.process(x[lo:hi]) for lo, hi in cuts]
+        assert d.stats().clock_relay_closed == 1
+        return np.concatenate(out)
+
+    ref = run()
+    for env in ({"XRIT_DEC_THREADS": "192"}, {"XRIT_DEC_THREADS": "128"}, {"XRIT_RELAY_PER_CU": "2"}, {"XRIT_RELAY_PER_CU": "5"}):
+        got = run(**env)
+        assert len(got) == len(ref) and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), env
+
+
 def test_exact_closure_edge_cases(xa):
     """Against the serial wave, word for word: samples-per-symbol too large for the walker's LDS ring (21 and 68: the
     one-wave walker on global memory; the tiled evaluation on its own uses up its pass budget there and, at 68, miscounts
