@@ -372,7 +372,7 @@ def main():
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
                    "segments": world, "bursts_reused": bool(W + K > nbuf),
-                   "clock_recovery": "cfg.clock_exact = 0 (default): two hand-off passes, three relay passes",
+                   "clock_recovery": "cfg.clock_exact = 0 (default): %d hand-off passes, %d relay passes of %d segments on the last step" % (int(st.clock_passes), int(st.clock_relay_passes), int(st.clock_relay_segments)),
                    "front_end_of_next_burst_overlaps_loops": bool(prefetch), "costas_chain_len": args.costas_chain or 256,
                    "clock_chain_syms": args.clock_chain or "auto: whole generations of resident waves (112 at C2), 64..256"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),

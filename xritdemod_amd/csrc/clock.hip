@@ -1520,6 +1520,16 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.relay = exact >= 1 || (exact == 0 && auto_passes > 0 && (long long)K * NS >= auto_min);
     j.relay_budget = exact > 1 ? exact : (exact == 1 ? 0 : auto_passes);
     if (j.relay) XR_TRY(relay_plan());
+    // What the relay passes buy is exact history: after p passes a symbol has between (p - 1) and p segments of exactly
+    // walked trajectory in front of it, and the default's three passes are sized for the segments of the big LRIT bursts
+    // (16.5 k symbols: 33 k .. 50 k symbols of history).  Where a call's segments are three times that long -- bursts at the
+    // circuit rate, 2^28 samples without a decimator: 82 k (LRIT) or 130 k (HRIT) symbols per segment -- two passes leave more
+    // history than that (measured at 49 k symbols per segment: 4.4e-5 rms from the serial trajectory against the three
+    // passes' 6.4e-5, profiles/r3_late_experiments.txt), and the third pass, a third of the relay's time, is not run; nor is the watch on
+    // the segment starts, which compares the starts of the last two passes (here the hand-off's own): the horizon of two
+    // such passes already is that of the seven the watch would ask for.  The look at Es/N0 stays (finish()).
+    j.relay_long = j.relay && exact == 0 && auto_passes >= 3 && (long long)j.cps * NS >= auto_long_seg;
+    if (j.relay_long) j.relay_budget = 2;
     // (measured at C2: a pass that writes costs ~40 us more than one that does not -- 16-byte stores, 64 lines per wave
     // instruction --, a call whose last pass did not write pays the output pass, 175 us.  Writing from one pass earlier
     // than the previous call's last (two writing passes per call) was slower: 2.21 against 2.13 ms per step.)
@@ -1646,7 +1656,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
                 relay_auto = true;
                 job.relay_budget = 0;
             }
-            if (!signal || relay_auto) shift_sq = 0.0f;
+            if (!signal || relay_auto || job.relay_long) shift_sq = 0.0f;
             while (!relay_auto && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
                 relay_auto = true;
                 job.relay_budget = job.relay_enq + 4;

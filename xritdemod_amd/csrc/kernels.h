@@ -228,6 +228,7 @@ struct ClockStage {
         bool relay = false;                     // ... is on for this call
         bool relay_force = false;               // ... although the tiled hand-off never closed (pass budget used up)
         int relay_budget = 0;                   // relay passes at most (0: until closed)
+        bool relay_long = false;                // the default configuration on segments of >= auto_long_seg symbols: two passes, no watch on the starts
         int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
     } job;
     bool pass_writes = true;    // the last hand-off pass is the output pass (XRIT_NO_PASS_OUTPUT=1, read at init: a separate output pass)
@@ -247,6 +248,7 @@ struct ClockStage {
     // 12 dB, 1.1e-3 at 6 dB, 4.3e-3 at 3 dB (XRIT_AUTO_PASSES=n: another count; 0: the hand-off passes' result as in
     // round 2 unless they stall)
     int auto_passes = 3;
+    int auto_long_seg = 49152;  // symbols per segment from which two relay passes are the default's budget (ClockStage::begin)
     float auto_shift = 6e-4f;
     float auto_snr = 10.0f;     // ... and to closure outright when the first pass's soft symbols show 2 Es/N0 below this (7 dB)
     float auto_snr_floor = 2.0f;  // ... but not below this: no signal (noise alone shows 1.75)
