@@ -437,6 +437,31 @@ def test_ab_switches_leave_the_words_alone(xa, monkeypatch):
         assert len(got) == len(ref) and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), env
 
 
+def test_default_runs_two_relay_passes_on_long_segments(xa):
+    """Where a call's relay segments hold 49 152 symbols or more (2^28-sample bursts at the circuit rate: 82 k / 130 k symbols
+    per segment) the default configuration runs two relay passes instead of three -- more exactly walked history in front of
+    every symbol than three passes of 16.5 k-symbol segments leave (ClockStage::begin, auto_long_seg).  Forced here on a
+    10 M-sample call with cfg.clock_exact_window: two passes, hard decisions those of the serial trajectory, soft symbols
+    closer to it than the hand-off passes alone and within the default's usual distance."""
+    fs = 1.25e6
+    x = synth.generate(synth.SynthParams(fs_in=fs), 10000000)
+    ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1, clock_serial=1)).process(x)
+    fast = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1, clock_exact=-2)).process(x)
+    d = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1, clock_exact_window=1024))
+    got = d.process(x)
+    st = d.stats()
+    assert st.clock_relay_passes == 2 and st.clock_relay_closed == 0, (st.clock_relay_passes, st.clock_relay_segments)
+    assert len(got) == len(ser) == len(fast)
+    big = np.abs(ser) > 1e-3
+    assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
+    r = float(np.sqrt(np.mean((got - ser) ** 2))), float(np.sqrt(np.mean((fast - ser) ** 2)))
+    assert r[0] <= 1.0e-4 and r[0] < 0.6 * r[1], r
+    # the usual three passes where the segments are short
+    d3 = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
+    d3.process(x)
+    assert d3.stats().clock_relay_passes == 3
+
+
 def test_exact_closure_edge_cases(xa):
     """Against the serial wave, word for word: samples-per-symbol too large for the walker's LDS ring (21 and 68: the
     one-wave walker on global memory; the tiled evaluation on its own uses up its pass budget there and, at 68, miscounts
