@@ -4,20 +4,20 @@ Tolerances (float32 path, stated per check):
   * FIR / AGC / RRC / Costas outputs: max |err| <= 2e-5, rms <= 2e-6 relative to signals of amplitude ~0.5
     (different summation order, scan instead of serial gain recurrence, hand-off tolerance 1e-5 rad).
   * recovered symbols: count identical, hard-decision sign identical wherever |oracle| > 1e-3 (Es/N0 >= 6 dB; below,
-    see test_randomised_chains), rms <= 3.2e-4 on every call -- the bound of the hand-off passes alone (cfg.clock_exact
-    = -2 / -1, and what calls of fewer than 4096 symbols get: 2.0e-4 .. 2.5e-4 on every configuration and burst size,
-    pinned ~1.3x above what is measured so that a regression shows).  BASELINE.json asks for 1e-4.  Why the hand-off
-    passes miss it, measured: the M&M recurrence lives on a lattice -- mu and omega move in steps of
-    2^-21 sample (float32 near 4.25), the interpolator arm is rint(mu*128) -- and does not forget a one-step difference
-    for ~1e5 symbols.  The SAME device chain with the clock recovery run as one serial trajectory (cfg.clock_serial,
-    bit-identical to the CPU recurrence on identical input: test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit) is
-    already 0.5e-4 .. 1.3e-4 away from the oracle, because its Costas output differs from the oracle's by 1e-6; that is
-    the floor.  The DEFAULT configuration (round 3: two hand-off passes, then three relay passes of csrc/clock_relay.h)
-    is held to it: <= 1e-4, or within 20 % of the serial floor of the same samples where that is above 1e-4
-    (test_three_relay_passes_are_within_reach_of_the_floor, which also runs the default; C2 bench burst: 8.1e-5 against
-    a floor of 8.06e-5); cfg.clock_exact = 1 IS the serial trajectory, word for word (test_soft_symbol_target_of_1e_4,
-    test_exact_closure_is_the_serial_trajectory_bit_for_bit).  On calls of a few thousand chains or fewer the hand-off
-    passes go on until they close exactly and the result is the serial one too (test_clock_closes_with_more_passes).
+    see test_randomised_chains), rms <= 1.5e-4 on every call of the default configuration (check_symbols; round 4 --
+    3.2e-4 until then, which is kept for the hand-off passes alone, cfg.clock_exact = -2 / -1: 2.0e-4 .. 2.5e-4 on every
+    configuration and burst size).  BASELINE.json asks for 1e-4.  Why the hand-off passes miss it, measured (DESIGN.md
+    section 6): the M&M recurrence lives on a lattice -- mu and omega move in steps of 2^-21 sample (float32 near 4.25),
+    the interpolator arm is rint(mu*128) -- and does not forget a one-step difference for ~1e5 symbols.  The SAME device
+    chain with the clock recovery run as one serial trajectory (cfg.clock_serial, bit-identical to the CPU recurrence on
+    identical input: test_clock_serial_mode_is_the_cpu_recurrence_bit_for_bit) is already 0.5e-4 .. 1.3e-4 away from the
+    oracle, because its Costas output differs from the oracle's by 1e-6; that is the floor.  The DEFAULT configuration
+    (round 4: no hand-off passes; segments of csrc/clock_relay.h walked exactly, first from the timing guess, then from the
+    end states of the segments in front) is held to it: <= 1e-4, or within 20 % of the serial floor of the same samples
+    where that is above 1e-4 (test_default_configuration_is_within_reach_of_the_floor); cfg.clock_exact = 1 IS the serial
+    trajectory, word for word (test_soft_symbol_target_of_1e_4, test_exact_closure_is_the_serial_trajectory_bit_for_bit).
+    Calls of fewer than 4096 symbols get hand-off passes, which on so few chains go on until they close exactly and the
+    result is the serial one too (test_clock_closes_with_more_passes).
   * int8 soft symbols (what the decoder receives): within 1 LSB.
 """
 import ctypes as C
@@ -44,7 +44,7 @@ def xa():
     return xritdemod_amd
 
 
-def check_symbols(got, want, rms_tol=3.2e-4):
+def check_symbols(got, want, rms_tol=1.5e-4):
     assert len(got) == len(want), (len(got), len(want))
     if len(want) == 0:
         return 0.0
@@ -201,7 +201,7 @@ def test_no_signal_is_not_walked_to_closure(xa):
     y = dem.process(x)
     st = dem.stats()
     assert len(y) > 150000 and np.isfinite(y).all()
-    assert 1 <= st.clock_relay_passes <= 3 and st.clock_relay_closed == 0, (st.clock_relay_passes, st.clock_relay_closed)
+    assert 1 <= st.clock_relay_passes <= 4 and st.clock_relay_closed == 0, (st.clock_relay_passes, st.clock_relay_closed)
     fast = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, clock_exact=-2))
     yf = fast.process(x)
     sf = fast.stats()
@@ -311,29 +311,32 @@ def test_soft_symbol_target_of_1e_4(xa, oracle_mod, case):
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_three_relay_passes_are_within_reach_of_the_floor(xa, oracle_mod, case):
-    """cfg.clock_exact = 3 = what the default configuration runs on a clean signal: two hand-off passes, then three relay
-    passes -- no closure, 0.3 ms more per 2^28-sample burst than five hand-off passes.  The symbols are then within 20 %
-    of the floor the serial trajectory itself has against the oracle (C2 bench burst: 8.1e-5 against 8.06e-5; the
-    hand-off passes alone: 2.2e-4), hard decisions equal."""
+def test_default_configuration_is_within_reach_of_the_floor(xa, oracle_mod, case):
+    """The default configuration (cfg.clock_exact = 0, round 4): NO hand-off passes -- the relay's first pass walks every
+    segment from the timing guess, the later ones from the end states of the segments in front (two passes where a segment
+    holds 49 k symbols or more, three from 24.6 k, else four).  The symbols are then within 20 % of the floor the serial
+    trajectory itself has against the oracle, hard decisions equal, and never further from the oracle than the hand-off
+    passes alone (cfg.clock_exact = -1).  cfg.clock_exact = 3 -- rounds 3's default: two hand-off passes, then three relay
+    passes -- is held to the same bound."""
     mode, fs, D, kw, n = CASES[case]
     x = synth_signal(4 * n if case == "C2" else 2 * n, **kw)
     want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
-    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=3))
-    got = dem.process(x)
-    st = dem.stats()
-    assert 1 <= st.clock_relay_passes <= 3
-    # (the default configuration is these three passes, plus the watch on how far the segment starts still move)
     dflt = xa.Demodulator(xa.Demodulator.config(mode, fs, D))
-    gd = dflt.process(x)
-    assert dflt.stats().clock_relay_passes == st.clock_relay_passes and np.array_equal(gd.view(np.uint32), got.view(np.uint32))
+    got = dflt.process(x)
+    st = dflt.stats()
+    assert st.clock_passes == 0 and 1 <= st.clock_relay_passes <= 4, (st.clock_passes, st.clock_relay_passes)
+    d3 = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=3))
+    g3 = d3.process(x)
+    assert d3.stats().clock_passes >= 2 and 1 <= d3.stats().clock_relay_passes <= 3
     ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
     fast = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=-1)).process(x)
-    assert len(got) == len(want) == len(ser) == len(fast)
-    r, floor, rf = rms(got - want), rms(ser - want), rms(fast - want)
+    assert len(got) == len(g3) == len(want) == len(ser) == len(fast)
+    floor, rf = rms(ser - want), rms(fast - want)
     big = np.abs(want) > 1e-3
-    assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
+    for g in (got, g3):
+        r = rms(g - want)
+        assert np.array_equal(np.sign(g[big]), np.sign(want[big]))
+        assert r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -456,10 +459,10 @@ def test_default_runs_two_relay_passes_on_long_segments(xa):
     assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
     r = float(np.sqrt(np.mean((got - ser) ** 2))), float(np.sqrt(np.mean((fast - ser) ** 2)))
     assert r[0] <= 1.0e-4 and r[0] < 0.6 * r[1], r
-    # the usual three passes where the segments are short
+    # four passes where the segments are short (16 k symbols: the call's 2.35 M symbols over 144 walkers)
     d3 = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
     d3.process(x)
-    assert d3.stats().clock_relay_passes == 3
+    assert d3.stats().clock_relay_passes == 4
 
 
 def test_exact_closure_edge_cases(xa):
@@ -539,7 +542,7 @@ def test_stalled_hand_off_is_closed_exactly_on_its_own(xa):
         if low:
             assert st.clock_relay_closed == 1 and np.array_equal(got.view(np.uint32), ser.view(np.uint32))
         else:
-            assert st.clock_relay_passes <= 3 and rms(got - ser) <= 1.2e-4
+            assert st.clock_relay_passes <= 4 and rms(got - ser) <= 1.2e-4
         fast = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_exact=-2))
         gf = fast.process(x)
         sf = fast.stats()
@@ -563,7 +566,7 @@ def test_serial_device_floor_and_what_tiling_adds(xa, oracle_mod):
     til = xa.Demodulator(xa.Demodulator.config(mode, fs, D)).process(x)
     assert len(ser) == len(til) == len(want)
     floor = check_symbols(ser, want, rms_tol=2e-4)         # measured 0.6e-4 .. 1.3e-4 depending on the burst
-    tiled = check_symbols(til, want)
+    tiled = check_symbols(til, want, rms_tol=3.2e-4)       # (the hand-off passes alone)
     big = np.abs(ser) > 1e-3
     assert np.array_equal(np.sign(til[big]), np.sign(ser[big]))
     assert rms(til - ser) <= 3.2e-4
@@ -736,7 +739,7 @@ def test_stats_and_strict_mode(xa):
     got = dem.process(x)
     st = dem.stats()
     assert st.samples_in == len(x) and st.circuit_samples == len(x) // 5 and st.symbols_out == len(got)
-    assert 2 <= st.costas_passes <= 32 and 4 <= st.clock_passes <= 96
+    assert 2 <= st.costas_passes <= 32 and st.clock_passes == 0 and 1 <= st.clock_relay_passes <= 96     # (the default: relayed from the timing guess)
     assert st.costas_unconverged == 0 and st.costas_max_residual < 1e-3
     # steady state: the second call closes within the first batch of passes
     dem.process(synth.generate(synth.SynthParams(fs_in=6.25e6), 600000, start=600000))
@@ -1114,17 +1117,17 @@ def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     assert len(got) == len(want)
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert rms(s0 - want[:len(s0)]) < 3.2e-4
+    assert rms(s0 - want[:len(s0)]) < 2.5e-4
     # round 3: a rank whose Costas loop locked pi away from the stream runs its clock recovery once more on the
     # sign-flipped Costas output (xrit_demod_redo_clock_flipped) -- both polarities end at the same floor
     # (round 2: 3e-3 for the flipped one, the M&M detector slices to {0, 1})
-    assert rms(s1 - want[len(s0):]) < 3.2e-4, (pol1, rms(s1 - want[len(s0):]))
+    assert rms(s1 - want[len(s0):]) < 2.5e-4, (pol1, rms(s1 - want[len(s0):]))
 
 
 def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
     """Both locks of rank 1 are exercised: the start phase of the capture is moved by a quarter turn at a time, so that
     rank 1 (cold start over its halo) falls on either side of the stream rank 0 follows; the joined output must be the
-    uninterrupted chain's to 3.2e-4 rms with identical decisions in every case."""
+    uninterrupted chain's to 2.5e-4 rms with identical decisions in every case."""
     import threading
     import torch
     n, D = 900000, 5
@@ -1163,7 +1166,7 @@ def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
         big = np.abs(want) > 1e-3
         assert np.array_equal(np.sign(sgn * got[big]), np.sign(want[big])), ph
         if sgn > 0:
-            assert rms(s1 - want[len(s0):]) < 3.2e-4, (ph, pol1)
+            assert rms(s1 - want[len(s0):]) < 2.5e-4, (ph, pol1)
     assert seen == {1, -1}, seen
 
 
@@ -1171,7 +1174,7 @@ def test_group_streams_a_capture_call_after_call(xa, oracle_mod):
     """Consecutive slice calls are consecutive bursts of one capture: in every call after the first the last rank hands
     the end of its previous slice (halo samples, boundary symbols in the stream's polarity) to rank 0 -- the exchanges
     become a ring -- so rank 0 warms up over a halo like every other rank.  Three calls of two ranks = six slices; the
-    symbols joined in (call, rank) order are the uninterrupted chain's: same count, same decisions, 3.2e-4 rms."""
+    symbols joined in (call, rank) order are the uninterrupted chain's: same count, same decisions, 2.5e-4 rms."""
     import threading
     import torch
     n, D, calls = 700000, 5, 3
@@ -1206,13 +1209,13 @@ def test_group_streams_a_capture_call_after_call(xa, oracle_mod):
     assert len(got) == len(want), (len(got), len(want))
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert rms(got - want) < 3.2e-4, rms(got - want)
+    assert rms(got - want) < 2.5e-4, rms(got - want)
     # every (call, rank) piece on its own as well
     pos = 0
     for c in range(calls):
         for r in range(2):
             k = len(parts[(c, r)][0])
-            assert rms(parts[(c, r)][0] - want[pos:pos + k]) < 3.6e-4, (c, r, parts[(c, r)][2])
+            assert rms(parts[(c, r)][0] - want[pos:pos + k]) < 2.5e-4, (c, r, parts[(c, r)][2])
             pos += k
 
 

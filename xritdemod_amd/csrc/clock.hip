@@ -463,6 +463,7 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 
 }  // namespace xrit
 #include "clock_relay.h"
+#include "clock_relay_wide.h"
 namespace xrit {
 
 // SS symbols of one lane.  Fast path: every running lane of the wave stays inside its ring for the whole
@@ -805,6 +806,8 @@ __global__ void __launch_bounds__(512) clock_output_kernel(const float2 *__restr
     if (produced < NS) atomicMin(terminal, k);   // ran out of input: the first such chain ends the call
 }
 
+// (chains longer than this -- cfg.clock_chain_syms -- do not stage their symbols: the tile of 64 x (NS + 1) floats must fit LDS)
+constexpr int CLK_STAGE_MAX_NS = 512;
 // a hand-off pass left the soft symbols in wave order (ClockPassOut::stage): a workgroup takes the 64 chains of one
 // wave -- 64 * NS symbols that are ONE contiguous stretch of the output -- through LDS; both sides whole lines
 __global__ void __launch_bounds__(256) clock_unstage_kernel(const float4 *__restrict__ stage, float *__restrict__ soft,
@@ -1031,7 +1034,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     XR_TRY(tail.reserve(2 * 1024 * sizeof(float2)));
     XR_TRY(jmean.reserve(64));
     jmean_valid = false;
-    XR_TRY(counters.reserve((size_t)(max_passes + 8) * 8 * sizeof(unsigned)));
+    XR_TRY(counters.reserve((size_t)(max_passes + 12) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_res, 128));
     {
         int dev = 0, v = 0;
@@ -1044,6 +1047,9 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     carry = 0;
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
+    if (const char *e = getenv("XRIT_NO_HANDOFF")) relay_no_handoff = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("XRIT_RELAY_WAVES")) relay_waves = atoi(e);
+    if (const char *e = getenv("XRIT_RELAY_TEAMS")) relay_teams_per_cu = atoi(e) > 0 ? atoi(e) : 1;
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
     relay_no_claim = getenv("XRIT_RELAY_NO_CLAIM") != nullptr;
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
@@ -1069,6 +1075,8 @@ int ClockStage::reset(hipStream_t s)
     hipLaunchKernelGGL(clock_state_reset_kernel, dim3(1), dim3(1), 0, s, st.as<ClockState>(), mu0, par.omega_mid);
     cur = 0;
     carry = 0;
+    redo_ok = false;        // (nothing of an earlier call is left to run again, nor a flipped loop's state to start it from)
+    alt_valid = false;
     return XRIT_OK;
 }
 
@@ -1076,7 +1084,7 @@ void ClockStage::release()
 {
     table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
-    relay.release(); alt.release(); stage.release();
+    relay.release(); relay_rec.release(); alt.release(); stage.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -1103,10 +1111,11 @@ int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
     return XRIT_OK;
 }
 
-// control block layout in `counters`: [0..16) ctl words, [16..24) ClockResult, per-pass counter slots from 24
-constexpr int CLK_CTL_WORDS = 24;
+// control block layout in `counters`: [0..24) ctl words, [24..32) ClockResult, per-pass counter slots from 32
+constexpr int CLK_CTL_WORDS = 32;
+constexpr int CLK_RES_WORD = 24;
 static inline int *clock_ctl(const DevBuf &b) { return b.as<int>(); }
-static inline ClockResult *clock_res(const DevBuf &b) { return reinterpret_cast<ClockResult *>(b.as<unsigned>() + 16); }
+static inline ClockResult *clock_res(const DevBuf &b) { return reinterpret_cast<ClockResult *>(b.as<unsigned>() + CLK_RES_WORD); }
 static inline unsigned *clock_cnt(const DevBuf &b, int pass) { return b.as<unsigned>() + CLK_CTL_WORDS + (size_t)pass * 8; }
 
 // dynamic LDS beyond the default limit has to be asked for, once per kernel
@@ -1130,7 +1139,7 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
                                                                     const unsigned long long *__restrict__ moments)
 {
     if (!ctl[0] && !force) return;      // the tiled hand-off did not close in its batch: ClockStage::finish starts over
-    __shared__ int s_term, s_buf;
+    __shared__ int s_term, s_buf, s_stuck;
     __shared__ long long s_ii;
     if (threadIdx.x == 0) {
         int ran = enq, closed = 0;
@@ -1143,18 +1152,24 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
             const unsigned *c = changed + RELAY_STAT * (ran - 1);
             const unsigned long long sq = (unsigned long long)c[4] | ((unsigned long long)c[5] << 32);
             ctl[12] = __float_as_int(c[6] ? (float)((double)sq / 1099511627776.0 / (double)c[6]) : 0.0f);
+            ctl[16] = (int)(c[3] >= 0x80000000u ? 0x7f800000u : c[3]);     // ... and the largest move (a watchdog mark: infinity)
         }
         s_buf = (ran - 1) & 1;
         s_term = 0x7fffffff;
+        s_stuck = 0;
     }
     __syncthreads();
     const RelaySeg *e = s_buf ? e1 : e0;
-    for (int i = threadIdx.x; i < G; i += (int)blockDim.x)
+    for (int i = threadIdx.x; i < G; i += (int)blockDim.x) {
         if (e[i].flags & RELAY_EXHAUSTED) atomicMin(&s_term, i);
+        // (a walk that a watchdog ended is not the end of the input: the call fails, ClockStage::finish)
+        if (e[i].flags & RELAY_STUCK) s_stuck = 1;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         ClockState s;
-        const int k = s_term;
+        const int k = s_stuck ? G : s_term;
+        ctl[15] = s_stuck;
         if (k >= G) {
             res->ok = 0;
             res->n_symbols = 0;
@@ -1183,16 +1198,37 @@ __global__ void __launch_bounds__(256) clock_relay_finalize_kernel(const RelaySe
     }
     __syncthreads();
     const long long ii = s_ii;
-    const long long carry = N - ii;
+    long long carry = N - ii;
+    // (the hand-over slot holds 1024 samples, like clock_finalize_kernel's: a walk that did not reach the end of the input --
+    // no segment ran out of samples, or a walker gave up -- leaves more than that unread and the call fails, ClockStage::finish)
+    if (carry > 1024) {
+        carry = 1024;
+        if (threadIdx.x == 0) res->ok = 0;
+    }
     for (long long i = threadIdx.x; i < carry; i += blockDim.x) tail_out[i] = x[ii + i];
 }
 
 // segments of the exact closure: 3 per CU (what its LDS holds of the staged walk) unless a window is given; the relay
 // buffer holds three segment records per segment and four counters per pass
+// samples a block of `symbols` symbols can cover at the fastest admissible clock
+static int relay_span(const ClockPar &par, int symbols)
+{
+    return (int)ceil((double)symbols * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
+}
+
 int ClockStage::relay_plan()
 {
     Job &j = job;
-    int cps = relay_window > 0 ? relay_window : (j.K + relay_per_cu * cu_count - 1) / (relay_per_cu * cu_count);
+    // the walker: a team of 8, 4 or 2 waves (clock_relay_wide.h) where a block of 62 symbols per wave fits the team's sample
+    // ring, else one wave (64 symbols per step; any symbol rate: clock_relay.h)
+    j.relay_w = 0;
+    if (!relay_global && relay_waves >= 2) {
+        if (relay_waves >= 8 && relay_span(par, RW_OWN * 8) + 8 <= RelayWide<8>::MAX_SPAN) j.relay_w = 8;
+        else if (relay_waves >= 4 && relay_span(par, RW_OWN * 4) + 8 <= RelayWide<4>::MAX_SPAN) j.relay_w = 4;
+        else if (relay_span(par, RW_OWN * 2) + 8 <= RelayWide<2>::MAX_SPAN) j.relay_w = 2;
+    }
+    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff ? 1 : relay_per_cu);
+    int cps = relay_window > 0 ? relay_window : (j.K + per_cu * cu_count - 1) / (per_cu * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
     // With a budget of relay passes (cfg.clock_exact = n > 1) what the passes buy is their horizon, n x the segment length
@@ -1206,7 +1242,7 @@ int ClockStage::relay_plan()
     // (counters for G + 1 passes whatever the budget: the default configuration raises its own, ClockStage::finish)
     XR_TRY(relay.reserve((size_t)j.G * 3 * sizeof(RelaySeg) + ((size_t)j.G + 1 + 8) * RELAY_STAT * sizeof(unsigned) + 2 * sizeof(unsigned long long) +
                          RELAY_CLAIM_WORDS * sizeof(unsigned)));
-    if (!relay_no_rec) XR_TRY(relay_rec.reserve((size_t)j.G * cps * NS * sizeof(unsigned)));
+    if (!relay_no_rec) XR_TRY(relay_rec.reserve(((size_t)j.G * cps * NS + RW_REC_PAD) * sizeof(unsigned)));
     relay_segments = j.G;
     relay_seg_chains = cps;
     return XRIT_OK;
@@ -1253,12 +1289,22 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
                            j.G + 3, clock_ctl(counters), a.moments, a.simd_claim);
     }
     // samples a block of 64 symbols can cover; the LDS-staged walk takes what fits its refill chunk
-    const int span = (int)ceil(64.0 * ((double)par.omega_mid + (double)par.omega_lim + 0.004)) + 24;
+    const int span = relay_span(par, 64);
     const bool lds_walk = span + 8 <= RELAY_RX - RELAY_XCH - 72 && !relay_global;
     {
         ProfScope ps(prof, "clock_relay", s);
         for (int q = 0; q < count && j.relay_enq < limit; ++q, ++j.relay_enq) {
-            if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+#define XR_RELAY_WIDE(WV)                                                                                             \
+    do {                                                                                                              \
+        const int wspan = relay_span(par, RW_OWN * WV);                                                               \
+        if (j.sym) hipLaunchKernelGGL((clock_relay_wide_kernel<true, WV>), dim3(j.G), dim3(64 * (WV + 1)), 0, s, a, j.relay_enq, wspan); \
+        else hipLaunchKernelGGL((clock_relay_wide_kernel<false, WV>), dim3(j.G), dim3(64 * (WV + 1)), 0, s, a, j.relay_enq, wspan);      \
+    } while (0)
+            if (j.relay_w == 8) XR_RELAY_WIDE(8);
+            else if (j.relay_w == 4) XR_RELAY_WIDE(4);
+            else if (j.relay_w == 2) XR_RELAY_WIDE(2);
+#undef XR_RELAY_WIDE
+            else if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
             else if (lds_walk) hipLaunchKernelGGL((clock_relay_kernel<false, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
             else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
             else hipLaunchKernelGGL((clock_relay_kernel<false, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
@@ -1320,7 +1366,7 @@ int ClockStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
             const bool narrow = (j.STEP >> 16) + 1 <= 20;      // columns a sub-step adds to a ring
             // from the pass the stop test is expected to fire after (what the previous call needed, never before the
             // fourth: ClockPolicy::decide stops no earlier) the passes leave the symbols themselves
-            const bool writes = !jac && !j.relay && p >= j.write_from && j.SS == 4 && (NS & 3) == 0;
+            const bool writes = !jac && !j.relay && p >= j.write_from && j.SS == 4 && (NS & 3) == 0 && NS <= CLK_STAGE_MAX_NS;
             const ClockPassOut po{j.soft, j.sym, (unsigned long long)j.cap, clock_ctl(counters) + CLK_CTL_SYMBOLS, j.written,
                                   stage.as<float4>()};
             if (jac) XR_CLK_PASS_NV(3, false);
@@ -1374,7 +1420,7 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
         else XR_CLK_OUT(64, 64);
 #undef XR_CLK_OUT_S
 #undef XR_CLK_OUT
-        if (j.soft && j.SS == 4 && (NS & 3) == 0 && pass_writes) {
+        if (j.soft && j.SS == 4 && (NS & 3) == 0 && pass_writes && NS <= CLK_STAGE_MAX_NS) {
             const size_t lds = (size_t)64 * (NS + 1) * sizeof(float) + 64 * sizeof(int);
             clock_allow_lds(clock_unstage_kernel, lds);
             hipLaunchKernelGGL(clock_unstage_kernel, dim3(nw), dim3(256), lds, s, stage.as<float4>(), j.soft, j.nrun,
@@ -1519,7 +1565,20 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // finish() when they stall high); < 0 -- hand-off passes only
     j.relay = exact >= 1 || (exact == 0 && auto_passes > 0 && (long long)K * NS >= auto_min);
     j.relay_budget = exact > 1 ? exact : (exact == 1 ? 0 : auto_passes);
+    // Round 4: the default configuration has NO hand-off passes.  The relay's first pass walks every segment from the timing
+    // guess itself: the loop forgets a start that is 2.6e-2 sample off within ~12 time constants (37 k symbols), so with one
+    // segment per CU (49.6 k symbols at C2) the end states of that pass are as close to the serial trajectory as those of a
+    // walk from a closed hand-off, and the second pass starts from them.  Measured at C2 (steady-state bursts,
+    // profiles/r4_handoff_vs_guess.json): guess + 2 passes over 256 segments 5.3e-5 rms from the serial trajectory, where two
+    // hand-off passes + 3 relay passes over 766 segments had 6.4e-5 -- for two sweeps of the stream instead of five.
+    j.no_handoff = j.relay && (relay_no_handoff >= 0 ? relay_no_handoff != 0 : exact == 0);
     if (j.relay) XR_TRY(relay_plan());
+    if (j.no_handoff && exact == 0) {
+        // passes for the default's parity by segment length (measured, same file: 16.5 k symbols per segment: 3 passes 9.6e-5,
+        // 4 passes 6.2e-5; 24.8 k: ...; 49.6 k: 2 passes 5.3e-5, 3 passes 2.9e-5)
+        const long long L = (long long)j.cps * NS;
+        j.relay_budget = L >= auto_long_seg ? 2 : (L >= auto_long_seg / 2 ? 3 : 4);
+    }
     // What the relay passes buy is exact history: after p passes a symbol has between (p - 1) and p segments of exactly
     // walked trajectory in front of it, and the default's three passes are sized for the segments of the big LRIT bursts
     // (16.5 k symbols: 33 k .. 50 k symbols of history).  Where a call's segments are three times that long -- bursts at the
@@ -1528,7 +1587,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // passes' 6.4e-5, profiles/r3_late_experiments.txt), and the third pass, a third of the relay's time, is not run; nor is the watch on
     // the segment starts, which compares the starts of the last two passes (here the hand-off's own): the horizon of two
     // such passes already is that of the seven the watch would ask for.  The look at Es/N0 stays (finish()).
-    j.relay_long = j.relay && exact == 0 && auto_passes >= 3 && (long long)j.cps * NS >= auto_long_seg;
+    j.relay_long = j.relay && !j.no_handoff && exact == 0 && auto_passes >= 3 && (long long)j.cps * NS >= auto_long_seg;
     if (j.relay_long) j.relay_budget = 2;
     // (measured at C2: a pass that writes costs ~40 us more than one that does not -- 16-byte stores, 64 lines per wave
     // instruction --, a call whose last pass did not write pays the output pass, 175 us.  Writing from one pass earlier
@@ -1558,7 +1617,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
                                S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL, j.dirty,
                                clock_ctl(counters), (max_passes + 5) * 8, j.terminal, j.written);
         }
-        XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
+        // (no hand-off passes: the relay's first pass walks from the timing guess itself, see above)
+        if (j.no_handoff) j.relay_force = true;
+        else XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {
         XR_HIP(hipMemcpyAsync(S.p, st_in, sizeof(ClockState), hipMemcpyDeviceToDevice, s));
     }
@@ -1574,7 +1635,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
 
 bool ClockStage::closed() const
 {
-    if (job.short_input || job.K <= 1) return true;
+    if (job.short_input || job.K <= 1 || job.no_handoff) return true;
     return reinterpret_cast<const int *>(h_res)[0] != 0;
 }
 
@@ -1652,11 +1713,23 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             // (... unless there is no signal to speak of: |noise| alone shows 2 / (pi - 2) = 1.75, BPSK at Es/N0 0 dB 2.4; a
             // loop that is not locked has no trajectory to close on, the relay would run its G + 1 passes for nothing)
             const bool signal = snr2 >= auto_snr_floor;
-            if (signal && (job.relay_force || !(snr2 >= auto_snr))) {
+            if (signal && ((job.relay_force && !job.no_handoff) || !(snr2 >= auto_snr))) {
                 relay_auto = true;
                 job.relay_budget = 0;
             }
-            if (!signal || relay_auto || job.relay_long) shift_sq = 0.0f;
+            if (!signal || relay_auto || job.relay_long || job.no_handoff) shift_sq = 0.0f;
+            // Without hand-off passes nothing has settled symbol slips between the timing guess and the loop: a start that moved
+            // by the better part of a symbol between the first pass (the guess) and a later one (the end state of the segment
+            // in front) means the guess counted a symbol more or less than the loop there, and every segment behind it is one
+            // symbol off until the exact front reaches it -- the call is walked to closure.
+            if (job.no_handoff && signal && !relay_auto) {
+                float mv;
+                memcpy(&mv, &hctl[16], sizeof mv);
+                if (!(mv < 0.25f * sps)) {
+                    relay_auto = true;
+                    job.relay_budget = 0;
+                }
+            }
             while (!relay_auto && !(shift_sq <= auto_shift * auto_shift) && hctl[11] == 0 && job.relay_enq < job.G + 1) {
                 relay_auto = true;
                 job.relay_budget = job.relay_enq + 4;
@@ -1700,12 +1773,19 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
             XR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z));
             std::vector<unsigned> wd((size_t)RELAY_WDBG_PASSES * RELAY_WDBG_SEGS * RELAY_WDBG_WORDS);
             XR_HIP(hipMemcpyFromSymbol(wd.data(), HIP_SYMBOL(relay_wdbg), wd.size() * sizeof(unsigned)));
-            for (int p = 0; p < relay_passes && p < RELAY_WDBG_PASSES; ++p)
+            for (int p = 0; p < relay_passes && p < RELAY_WDBG_PASSES && job.relay_w == 0; ++p)
                 for (int g = 0; g < job.G && g < RELAY_WDBG_SEGS; ++g) {
                     const unsigned *w = &wd[((size_t)p * RELAY_WDBG_SEGS + g) * RELAY_WDBG_WORDS];
                     fprintf(stderr, "[xrit] walker %d %d %u %u %u %u %u %u\n", p, g, w[0], w[1], w[2], w[3], w[4], w[5]);
                 }
-            for (int o = 0; o < 16; o += 8) {
+            if (job.relay_w > 0) {
+                const double st = hd[7] ? (double)hd[7] : 1.0, un = hd[9] ? (double)hd[9] : 1.0;
+                fprintf(stderr, "[xrit] relay team (wave 1) cycles per step: ring wait %.0f, setup %.0f, interpolate..scan %.0f, wait for the scan mailbox %.0f, "
+                                "positions..verdict %.0f, wait for the verdicts %.0f, commit + loop %.0f (%llu steps); prefetchers: %.0f cycles waiting per unit, "
+                                "%llu units, %.1f loop turns per unit, alive %.0f cycles per unit\n",
+                        hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st, hd[5] / st, hd[6] / st, hd[7], hd[8] / un, hd[9], hd[10] / un, hd[11] / un);
+            }
+            for (int o = 0; o < 16 && job.relay_w == 0; o += 8) {
                 const double st = hd[o + 6] ? (double)hd[o + 6] : 1.0;
                 fprintf(stderr, "[xrit] relay walker cycles per step, passes %s: wait %.0f, setup %.0f, rounds %.0f, verify %.0f, commit %.0f, loop head %.0f (%llu steps)\n",
                         o ? ">= 8" : "< 8", hd[o] / st, hd[o + 1] / st, hd[o + 2] / st, hd[o + 3] / st, hd[o + 4] / st, hd[o + 5] / st, hd[o + 6]);
@@ -1731,7 +1811,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
     if (job.K > 1) {
         const bool clean = in_batch && hctl[NEWTON_CTL_TAKEOVER] == 0 && hctl[9] == 0 && passes <= 12;
         if (job.mean_j && !clean) jmean_valid = false;           // the stream has changed: measure again
-        else if (!job.mean_j && !job.gated && clean && job.K >= 1024 && jac_passes > 0) {
+        else if (!job.mean_j && !job.gated && clean && job.K >= 1024 && jac_passes > 0 && !job.no_handoff) {
             hipLaunchKernelGGL(clock_jmean_kernel, dim3(1), dim3(256), 0, s, J.as<float4>(), job.K, jmean.as<float4>());
             jmean_valid = true;
             jmean_ns = NS;
@@ -1755,11 +1835,15 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         }
     }
     ClockResult r;
-    memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + 16, sizeof r);
+    memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + CLK_RES_WORD, sizeof r);
     cur ^= 1;
     if (!r.ok && serial) {
         set_error("clock recovery produced more than the %zu symbols the output holds", job.cap);
         return XRIT_E_CAPACITY;
+    }
+    if (!r.ok && job.relay && hctl[15]) {
+        set_error("clock recovery: a relay walker gave up waiting for its sample ring or its team (watchdog)");
+        return XRIT_E_HIP;
     }
     if (!r.ok) {
         set_error("clock recovery: chain budget exhausted before the end of the input");

@@ -42,6 +42,7 @@ constexpr int RELAY_STAT = 8;        // counters per relay pass (RelayArgs::chan
 constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exactly from start[].s
 constexpr int RELAY_EXHAUSTED = 2;   // ends[]: the input ran out inside this segment (n_done symbols exist)
 constexpr int RELAY_DEAD = 4;        // the input ran out before this segment
+constexpr int RELAY_STUCK = 8;       // ends[]: a watchdog ended the walk (a ring or a mailbox never filled): the call fails
 constexpr int RELAY_CLAIM_WORDS = 2048;   // one word per CU, indexed by (XCC_ID, SE_ID, SH_ID, CU_ID)
 
 struct RelaySeg {
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     } else {
         const RelaySeg e = ein[s - 1];
         T = e.s;
-        dead = (e.flags & (RELAY_EXHAUSTED | RELAY_DEAD)) != 0;
+        dead = (e.flags & (RELAY_EXHAUSTED | RELAY_DEAD | RELAY_STUCK)) != 0;
     }
     // (the walker's state is wave-uniform: kept in scalar registers, branches on it are scalar branches)
     T.ii = __builtin_amdgcn_readfirstlane((int)T.ii);
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const int ni_w = (int)(a.ni < 0x7fffffffLL ? a.ni : 0x7fffffffLL);     // (read indices are 32-bit here: x_lo, need_x)
     int n = 0;
     unsigned steps = 0, rounds_total = 0;
-    bool exhausted = false;
+    bool exhausted = false, stuck = false;
     int x_hi = x_lo, g_hi = 0;           // what the rings are known to hold (asked again only when that is not enough)
     float m1 = 0.f, m2 = 0.f;            // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
@@ -346,16 +347,16 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 x_hi = relay_ld(&sh_xhi);
                 if (x_hi >= need_x) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x80000000u | (unsigned)s; exhausted = true; break; }
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x80000000u | (unsigned)s; stuck = true; break; }
             }
 #pragma nounroll
-            while (use_rec && !exhausted && g_hi < need_g) {
+            while (use_rec && !stuck && g_hi < need_g) {
                 g_hi = relay_ld(&sh_ghi);
                 if (g_hi >= need_g) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x90000000u | (unsigned)s; exhausted = true; break; }
+                if (++spins > (1 << 22)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0x90000000u | (unsigned)s; stuck = true; break; }
             }
-            if (exhausted) break;
+            if (stuck) break;
         }
         RELAY_TICK(0);
         // the walker's state on the lattice; the first guess puts symbol n + lane where the walk before had it, or,
@@ -507,7 +508,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         RelaySeg e{};
         e.s = T;
         e.n_done = n;
-        e.flags = exhausted ? RELAY_EXHAUSTED : 0;
+        // (a walk a watchdog ended is not the end of the input: its own flag, and the call fails -- clock_relay_finalize_kernel)
+        e.flags = stuck ? RELAY_STUCK : (exhausted ? RELAY_EXHAUSTED : 0);
         eout[s] = e;
     }
 }
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(256) clock_relay_init_kernel(RelaySeg *start, 
     if (simd_claim && i < RELAY_CLAIM_WORDS) simd_claim[i] = 0u;
     if (i < G) start[i].flags = 0;
     if (i < RELAY_STAT * npass) changed[i] = 0u;
-    if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; ctl[14] = 0; moments[0] = 0ull; moments[1] = 0ull; }
+    if (i == 0) { ctl[10] = 0; ctl[11] = 0; ctl[12] = 0; ctl[14] = 0; ctl[15] = 0; moments[0] = 0ull; moments[1] = 0ull; }
 }
 
 }  // namespace xrit

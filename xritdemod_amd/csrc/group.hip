@@ -554,33 +554,48 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     }
     unsigned long long offset = 0;
     for (int r = 0; r < rank; ++r) offset += (unsigned long long)all[(size_t)2 * r];
-    // the aligned symbols, in the stream's polarity (a rank that ran again already has them so)
-    const float emit = 1.0f;
-    size_t pre = 0;
-    if (lag < 0) {
-        pre = (size_t)(-lag);
-        const size_t nh = g->h_halo_syms.size();
-        XR_TRY(g->pre_dev.reserve(64 * sizeof(float)));
-        g->h_pre.resize(pre);
-        // (halo symbols are in this rank's own polarity, already negated above where it ran again)
-        for (size_t i = 0; i < pre; ++i) g->h_pre[i] = (pol < 0 ? 1.0f : (float)pol) * g->h_halo_syms[nh - pre + i];
-        XR_HIP(hipMemcpyAsync(d_soft, g->h_pre.data(), pre * sizeof(float), hipMemcpyHostToDevice, s));
-    }
-    const size_t skip = lag > 0 ? (size_t)lag : 0;
-    const size_t body = k > skip ? k - skip : 0;
-    if (body)
-        hipLaunchKernelGGL(group_emit_kernel, dim3(div_up(body, 256)), dim3(256), 0, s, g->soft_int.as<float>() + skip,
-                           d_soft + pre, body, emit);
-    XR_HIP(hipGetLastError());
-    if (pre) XR_HIP(hipStreamSynchronize(s));       // h_pre is read by the copy until then
-    // the last rank keeps what rank 0 needs to go on from here in the next call
-    if (world > 1 && rank + 1 == world) {
-        XR_TRY(g->keep_halo.reserve(H * esz + 16));
-        XR_TRY(g->keep_tail.reserve(GROUP_TAIL * sizeof(float)));
-        XR_HIP(hipMemcpyAsync(g->keep_halo.p, (const char *)d_samples + (n - H) * esz, H * esz, hipMemcpyDeviceToDevice, s));
-        const size_t m = count < (size_t)GROUP_TAIL ? count : (size_t)GROUP_TAIL;
-        XR_HIP(hipMemsetAsync(g->keep_tail.p, 0, GROUP_TAIL * sizeof(float), s));
-        if (m) XR_HIP(hipMemcpyAsync(g->keep_tail.as<float>() + (GROUP_TAIL - m), d_soft + (count - m), m * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // From here on nothing is exchanged any more, but `calls` is the collective switch between a capture's first call and
+    // its ring: a rank that failed now (device memory, a copy) and simply returned would count one call fewer than its
+    // peers and wait for ever in the next call's halo exchange.  It tears the transport down instead: its peers' next
+    // exchange fails and every rank begins a new capture.
+    auto tail_work = [&]() -> int {
+        // the aligned symbols, in the stream's polarity (a rank that ran again already has them so)
+        const float emit = 1.0f;
+        size_t pre = 0;
+        if (lag < 0) {
+            pre = (size_t)(-lag);
+            const size_t nh = g->h_halo_syms.size();
+            XR_TRY(g->pre_dev.reserve(64 * sizeof(float)));
+            g->h_pre.resize(pre);
+            // (halo symbols are in this rank's own polarity, already negated above where it ran again)
+            for (size_t i = 0; i < pre; ++i) g->h_pre[i] = (pol < 0 ? 1.0f : (float)pol) * g->h_halo_syms[nh - pre + i];
+            XR_HIP(hipMemcpyAsync(d_soft, g->h_pre.data(), pre * sizeof(float), hipMemcpyHostToDevice, s));
+        }
+        const size_t skip = lag > 0 ? (size_t)lag : 0;
+        const size_t body = k > skip ? k - skip : 0;
+        if (body)
+            hipLaunchKernelGGL(group_emit_kernel, dim3(div_up(body, 256)), dim3(256), 0, s, g->soft_int.as<float>() + skip,
+                               d_soft + pre, body, emit);
+        XR_HIP(hipGetLastError());
+        if (pre) XR_HIP(hipStreamSynchronize(s));       // h_pre is read by the copy until then
+        // the last rank keeps what rank 0 needs to go on from here in the next call
+        if (world > 1 && rank + 1 == world) {
+            XR_TRY(g->keep_halo.reserve(H * esz + 16));
+            XR_TRY(g->keep_tail.reserve(GROUP_TAIL * sizeof(float)));
+            XR_HIP(hipMemcpyAsync(g->keep_halo.p, (const char *)d_samples + (n - H) * esz, H * esz, hipMemcpyDeviceToDevice, s));
+            const size_t m = count < (size_t)GROUP_TAIL ? count : (size_t)GROUP_TAIL;
+            XR_HIP(hipMemsetAsync(g->keep_tail.p, 0, GROUP_TAIL * sizeof(float), s));
+            if (m) XR_HIP(hipMemcpyAsync(g->keep_tail.as<float>() + (GROUP_TAIL - m), d_soft + (count - m), m * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        return XRIT_OK;
+    };
+    {
+        const int tr_ = tail_work();
+        if (tr_ != XRIT_OK) {
+            g->calls = 0;
+            if (world > 1) g->tr->abort();
+            return tr_;
+        }
     }
     g->calls += 1;
     *n_out = count;

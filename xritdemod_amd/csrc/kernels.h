@@ -225,8 +225,10 @@ struct ClockStage {
         bool rescued = false;   // the serial walk has been tried
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr, *written = nullptr;
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
+        int relay_w = 0;                        // waves per walker team (clock_relay_wide.h); 0: the one-wave walker
         bool relay = false;                     // ... is on for this call
         bool relay_force = false;               // ... although the tiled hand-off never closed (pass budget used up)
+        bool no_handoff = false;                // ... straight from the timing guess: no hand-off passes at all
         int relay_budget = 0;                   // relay passes at most (0: until closed)
         bool relay_long = false;                // the default configuration on segments of >= auto_long_seg symbols: two passes, no watch on the starts
         int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
@@ -273,6 +275,10 @@ struct ClockStage {
     int ng_max = 8;             // XRIT_CLOCK_NG: one-wave groups per clock workgroup at most
     bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
     int relay_per_cu = 3;       // XRIT_RELAY_PER_CU: segments (walkers) per CU the relay plans (A/B runs)
+    int relay_no_handoff = -1;       // the relay's first pass starts from the timing guess, no hand-off passes: -1: in the default
+                                     // configuration (cfg.clock_exact = 0); XRIT_NO_HANDOFF=0 / 1: never / with every relayed call (A/B runs)
+    int relay_waves = 1;        // waves per walker team at most (clock_relay_wide.h; < 2: the one-wave walker of clock_relay.h)
+    int relay_teams_per_cu = 1; // segments (teams) per CU the relay plans with the wide walker
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
     int relay_limit() const;
     int relay_plan();
