@@ -1234,7 +1234,10 @@ int ClockStage::relay_plan()
     // With a budget of relay passes (cfg.clock_exact = n > 1) what the passes buy is their horizon, n x the segment length
     // -- a segment is exact once everything within the merge length in front of it is: segments no shorter than the big
     // bursts' (16 k symbols), whatever the size of the call, so that n means the same parity everywhere.
-    const int min_syms = j.relay_budget > 0 ? 16384 : 2048;
+    // (without hand-off passes -- the default configuration -- a segment must be long enough for the loop to forget the timing
+    // guess it starts from: never shorter than auto_long_seg, 49 k symbols; a call of fewer symbols is one segment, i.e. ONE
+    // exact walk from the carried state)
+    const int min_syms = j.no_handoff && exact == 0 ? auto_long_seg : (j.relay_budget > 0 ? 16384 : 2048);
     if (relay_window <= 0 && cps * NS < min_syms) cps = (min_syms + NS - 1) / NS;
     if (cps < 1) cps = 1;
     j.cps = cps;
@@ -1577,7 +1580,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         // passes for the default's parity by segment length (measured, same file: 16.5 k symbols per segment: 3 passes 9.6e-5,
         // 4 passes 6.2e-5; 24.8 k: ...; 49.6 k: 2 passes 5.3e-5, 3 passes 2.9e-5)
         const long long L = (long long)j.cps * NS;
-        j.relay_budget = L >= auto_long_seg ? 2 : (L >= auto_long_seg / 2 ? 3 : 4);
+        j.relay_budget = L >= auto_long_seg ? 2 : (L >= auto_long_seg / 2 ? 3 : 4);      // (shorter segments: cfg.clock_exact_window)
     }
     // What the relay passes buy is exact history: after p passes a symbol has between (p - 1) and p segments of exactly
     // walked trajectory in front of it, and the default's three passes are sized for the segments of the big LRIT bursts
