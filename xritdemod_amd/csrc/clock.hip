@@ -73,6 +73,7 @@ struct ClkUnwrapF {
     double sps;
     double off;       // block b covers buffer samples [off + b*BL, off + (b+1)*BL)
     int BL;
+    double rot;       // the phasor of X counts samples from buffer sample `off`, not 0: X = X_0 e^{+j rot}, rot = 2 pi off / sps
     __device__ T identity() const { return 0.0; }
     __device__ T combine(const T &lo, const T &hi) const { return lo + hi; }
     __device__ double ang(long long b) const
@@ -85,7 +86,7 @@ struct ClkUnwrapF {
     __device__ double diff(long long b) const
     {
         double cur = ang(b);
-        if (b == 0) return cur;
+        if (b == 0) return clk_wrap(cur - rot);
         return clk_wrap(cur - ang(b - 1));
     }
     __device__ T reduce_run(long long i0, int n) const
@@ -1053,7 +1054,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
     relay_no_claim = getenv("XRIT_RELAY_NO_CLAIM") != nullptr;
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
-    if (const char *e = getenv("XRIT_RELAY_PER_CU")) relay_per_cu = atoi(e) > 0 ? atoi(e) : 3;
+    if (const char *e = getenv("XRIT_RELAY_PER_CU")) { relay_per_cu = atoi(e) > 0 ? atoi(e) : 3; relay_per_cu_set = true; }
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
     pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
@@ -1075,6 +1076,8 @@ int ClockStage::reset(hipStream_t s)
     hipLaunchKernelGGL(clock_state_reset_kernel, dim3(1), dim3(1), 0, s, st.as<ClockState>(), mu0, par.omega_mid);
     cur = 0;
     carry = 0;
+    x_pending = -1;         // (samples a producer has put in place for a call that will not come)
+    in_flight = false;
     redo_ok = false;        // (nothing of an earlier call is left to run again, nor a flipped loop's state to start it from)
     alt_valid = false;
     return XRIT_OK;
@@ -1082,7 +1085,7 @@ int ClockStage::reset(hipStream_t s)
 
 void ClockStage::release()
 {
-    table.release(); xbuf.release(); st.release(); S.release(); E.release(); J.release(); om.release();
+    table.release(); xbuf[0].release(); xbuf[1].release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
     relay.release(); relay_rec.release(); alt.release(); stage.release();
     if (h_res) (void)hipHostFree(h_res);
@@ -1091,13 +1094,12 @@ void ClockStage::release()
 
 // The producer of this call's samples may deliver the timing-line statistic itself: nb blocks of BL samples,
 // block b covering buffer samples [offset + b*BL, ...).  Returns where to write it (double2 per block).
-double2 *ClockStage::om_slot(int nb, int BL, double offset)
+double2 *ClockStage::om_slot(int nb, int BL)
 {
     if (nb < 1 || om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))) != XRIT_OK) return nullptr;
     om_ext = true;
     om_nb = nb;
     om_BL = BL;
-    om_offset = offset;
     return om.as<double2>();
 }
 
@@ -1106,8 +1108,11 @@ double2 *ClockStage::om_slot(int nb, int BL, double offset)
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
     (void)s;
-    XR_TRY(xbuf.reserve((XPAD + carry + n + 64 + 16) * sizeof(float2)));
-    *slot = xbase() + carry;
+    // (while a call is between begin() and finish() its walkers read xbuf[xb]: the next call's samples go to the other one)
+    const int b = in_flight ? xb ^ 1 : xb;
+    XR_TRY(xbuf[b].reserve((XPAD + n + 64 + 16) * sizeof(float2)));
+    x_pending = b;
+    *slot = xbuf[b].as<float2>() + XPAD;
     return XRIT_OK;
 }
 
@@ -1227,7 +1232,7 @@ int ClockStage::relay_plan()
         else if (relay_waves >= 4 && relay_span(par, RW_OWN * 4) + 8 <= RelayWide<4>::MAX_SPAN) j.relay_w = 4;
         else if (relay_span(par, RW_OWN * 2) + 8 <= RelayWide<2>::MAX_SPAN) j.relay_w = 2;
     }
-    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff ? 1 : relay_per_cu);
+    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? 1 : relay_per_cu);
     int cps = relay_window > 0 ? relay_window : (j.K + per_cu * cu_count - 1) / (per_cu * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
@@ -1237,7 +1242,7 @@ int ClockStage::relay_plan()
     // (without hand-off passes -- the default configuration -- a segment must be long enough for the loop to forget the timing
     // guess it starts from: never shorter than auto_long_seg, 49 k symbols; a call of fewer symbols is one segment, i.e. ONE
     // exact walk from the carried state)
-    const int min_syms = j.no_handoff && exact == 0 ? auto_long_seg : (j.relay_budget > 0 ? 16384 : 2048);
+    const int min_syms = j.no_handoff && exact == 0 && !relay_per_cu_set ? auto_long_seg : (j.relay_budget > 0 ? 16384 : 2048);
     if (relay_window <= 0 && cps * NS < min_syms) cps = (min_syms + NS - 1) / NS;
     if (cps < 1) cps = 1;
     j.cps = cps;
@@ -1457,7 +1462,12 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     j.N = (long long)(carry + n);
     j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
     if (j.N >= (1LL << 31)) { set_error("clock recovery: more than 2^31 samples in one call"); return XRIT_E_INVALID; }
-    if (!xbase_fixed) XR_TRY(xbuf.reserve((size_t)(XPAD + j.N + 64 + 16) * sizeof(float2)));
+    if (!xbase_fixed) {
+        if (x_pending >= 0) xb = x_pending;
+        x_pending = -1;
+        XR_TRY(xbuf[xb].reserve((size_t)(XPAD + n + 64 + 16) * sizeof(float2)));
+    }
+    in_flight = true;
     float2 *x = xbase();
     if (carry)
         hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, s, tail.as<float2>() + 1024 * cur, x, (int)carry);
@@ -1544,7 +1554,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     const int K = (int)((double)j.N / (min_omega * NS)) + 3;
     j.K = K;
     const int BL = ext ? om_BL : CLK_OM_BLOCK;
-    const double om_off = ext ? om_offset : 0.0;
+    // (the producer's statistic: block b covers buffer samples [carry + b BL, ...), its phasor counted from the first new sample)
+    const double om_off = ext ? (double)carry : 0.0;
+    const double om_rot = ext ? 2.0 * XR_PI_D * ((double)carry / (double)sps - floor((double)carry / (double)sps)) : 0.0;
     const int nb = ext ? om_nb : (int)((j.N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
@@ -1611,7 +1623,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
             if (!ext)
                 hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, j.N, nb,
                                    1.0 / (double)sps);
-            ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL};
+            ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL, om_rot};
             hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
                                work.as<double>());
             hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
@@ -1630,8 +1642,12 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     if (j.relay && K > 1) {
         // (in front of the relay, not of the hand-off passes: started with those it competes with kernels that fill the
         // chip and the burst takes 2.9 instead of 2.4 ms)
-        if (before_relay) XR_TRY(before_relay());
-        return enqueue_relay(relay_batch, true, s, prof);
+        // (the stream's other work starts when the relay kernels do -- an event recorded here -- but is enqueued BEHIND them: the
+        // host takes ~0.2 ms to enqueue a front end and a Costas loop, which the relay kernels need not wait for)
+        if (before_relay) XR_TRY(before_relay(0));
+        int rc_relay = enqueue_relay(relay_batch, true, s, prof);
+        if (rc_relay == XRIT_OK && before_relay) rc_relay = before_relay(1);
+        return rc_relay;
     }
     return enqueue_output(s, prof);
 }
@@ -1647,6 +1663,7 @@ bool ClockStage::closed() const
 int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
 {
     *n_out = 0;
+    in_flight = false;      // (the caller has synchronised: whatever finish() still enqueues it waits for itself)
     if (job.short_input) {
         carry = (size_t)job.N;
         last_symbols = 0;
@@ -1901,7 +1918,7 @@ int ClockStage::redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_
     if (!redo_ok) { set_error("clock recovery: no finished call to run again"); return XRIT_E_INVALID; }
     // finish() moved on to the other state / tail slot: back to the one the call started from (untouched since)
     cur ^= 1;
-    float2 *data = xbuf.as<float2>() + XPAD + (16 - prev_carry % 16) % 16 + prev_carry;     // where the call's input lies
+    float2 *data = xdata();     // where the call's input lies
     const size_t n = prev_n;
     if (alt_valid) {
         // the flipped loop's own state (make_alt) in place of this one's

@@ -58,10 +58,14 @@ struct xrit_demod {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
     hipEvent_t ev_relay = nullptr;                                  // the relay kernels of the current call come next
+    hipEvent_t ev_costas = nullptr;                                 // the Costas loop started ahead on stream2 has run its batch
+    bool costas_idle = false;   // the current call's Costas loop was finished before its clock recovery began: the stage is free
     int last_fe_set = -1;       // set of the front end that ran last (its event orders the next one behind it)
     struct Prefetched {
         const void *samples = nullptr; size_t n = 0; int type = 0; int set = 0;
         size_t length = 0; const float2 *rrc = nullptr; bool stat_ready = false; const float *agc_flag = nullptr;
+        bool costas_begun = false;      // the Costas loop of this input has been started too (on stream2, behind its front end)
+        float2 *slot = nullptr;         // ... writing here (the clock recovery's next input buffer)
         bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
                                 // starts the front end of the next burst in front of the relay kernels of the current one,
                                 // which leave most of the chip idle, instead of under the loops that fill it
@@ -213,7 +217,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_relay, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+            hipEventCreateWithFlags(&d->ev_relay, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_costas, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
@@ -246,6 +251,7 @@ void xrit_demod_destroy(xrit_demod *d)
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
     if (d->ev_relay) (void)hipEventDestroy(d->ev_relay);
+    if (d->ev_costas) (void)hipEventDestroy(d->ev_costas);
     for (int i = 0; i < 2; ++i) if (d->ev_fe[i]) (void)hipEventDestroy(d->ev_fe[i]);
     for (int i = 0; i < 2; ++i) { d->bufA[i].release(); d->bufB[i].release(); d->bufC[i].release(); d->bufR[i].release(); d->stat[i].release(); }
     d->rtl.release();
@@ -389,48 +395,96 @@ static int launch_prefetched(xrit_demod *d, xrit_demod::Prefetched &f, hipEvent_
     return XRIT_OK;
 }
 
-static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, size_t *nsym, hipStream_t s, Profiler *prof)
+// the Costas loop of a slice (demodulator.cpp:152): guess, a batch of passes with a device-side stop test and the final pass,
+// enqueued on s; it writes into the clock recovery's (next) input buffer
+static int costas_enqueue(xrit_demod *d, const SliceIO &io, hipStream_t s, Profiler *prof, float2 **slot_out)
 {
     const size_t length = io.length;
     const int L = d->costas.L;
     float2 *slot = nullptr;
     XR_TRY(d->clock.input_slot(length, &slot, s));
-    const size_t carry0 = d->clock.carry;
     double2 *om = nullptr;
-    if (length) om = d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L, (double)carry0);
-    // Costas (:152) and clock recovery (:156, SymbolManager.cpp:104) are enqueued back to back -- guesses, a batch
-    // of hand-off passes each with a device-side stop test, final / output passes -- and the host waits once.
-    // Only when a batch did not close (cold start, unlocked input) does it continue pass by pass.
+    if (length) om = d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L);
+    const double inv_sps = 1.0 / (double)d->sps;
+    const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
+    XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, 0, inv_sps));
+    if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
+    *slot_out = slot;
+    return XRIT_OK;
+}
+
+// (a registered front end of the next burst goes in front of this call's relay kernels -- and behind it, where this call's
+// own Costas loop is done with the stage, the next burst's Costas loop)
+static void set_relay_hook(xrit_demod *d, hipStream_t s)
+{
+    d->clock.before_relay = [d, s](int phase) -> int {
+        // phase 0: in front of the relay kernels (an event marks the spot); phase 1: once they are enqueued
+        if (phase == 0) {
+            if (d->pf_count > 0 && !d->pf[0].launched) XR_HIP(hipEventRecord(d->ev_relay, s));
+            return XRIT_OK;
+        }
+        if (d->pf_count > 0 && !d->pf[0].launched) {
+            if (d->clock.trace_env) fprintf(stderr, "[xrit] the registered front end starts with the relay kernels%s\n", d->costas_idle ? ", its Costas loop behind it" : "");
+            XR_TRY(launch_prefetched(d, d->pf[0], d->ev_relay));
+            if (d->costas_idle) {
+                xrit_demod::Prefetched &f = d->pf[0];
+                SliceIO io;
+                io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+                int rc = costas_enqueue(d, io, d->stream2, d->prof.enabled ? &d->prof : nullptr, &f.slot);
+                if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+                XR_HIP(hipEventRecord(d->ev_costas, d->stream2));
+                f.costas_begun = true;
+            }
+        }
+        return XRIT_OK;
+    };
+}
+
+// clock recovery (:156, SymbolManager.cpp:104) of a slice whose Costas loop has been enqueued on s (costas_done: has been
+// finished ahead of this call, on stream2)
+static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, size_t *nsym, hipStream_t s, Profiler *prof,
+                 bool costas_done = false, float2 *slot_done = nullptr)
+{
+    const size_t length = io.length;
+    float2 *slot = slot_done;
+    // Costas (:152) and clock recovery are enqueued back to back -- guesses, a batch of hand-off passes each with a
+    // device-side stop test, final / output passes -- and the host waits once.  Only when a batch did not close (cold
+    // start, unlocked input) does it continue pass by pass.
+    if (!costas_done) XR_TRY(costas_enqueue(d, io, s, prof, &slot));
+    if (!costas_done && d->pf_count > 0 && !d->pf[0].launched) {
+        // A stream with its next input registered: this call's Costas loop is finished FIRST (one more wait of the host), so
+        // that the stage is free for the next burst's loop behind its front end, under this call's relay -- from the next
+        // call on that is how every Costas loop of the stream runs and the extra wait is gone.
+        XR_HIP(hipEventRecord(d->ev_costas, s));
+        XR_HIP(hipEventSynchronize(d->ev_costas));
+        if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
+        bool redone = false;
+        XR_TRY(d->costas.finish(s, prof, &redone));
+        costas_done = true;
+    }
     float2 *sym = nullptr;
     if (d->keep_stages || d->keep_symbols) {
         XR_TRY(d->stage_buf[4].reserve((cap + 1) * sizeof(float2)));
         sym = d->stage_buf[4].as<float2>();
     }
-    const double inv_sps = 1.0 / (double)d->sps;
-    const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
-    XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, (long long)carry0, inv_sps));
-    // (a registered front end of the next burst goes in front of this call's relay kernels)
-    d->clock.before_relay = [d, s]() -> int {
-        if (d->pf_count > 0 && !d->pf[0].launched) {
-            if (d->clock.trace_env) fprintf(stderr, "[xrit] the registered front end starts in front of the relay kernels\n");
-            XR_HIP(hipEventRecord(d->ev_relay, s));
-            return launch_prefetched(d, d->pf[0], d->ev_relay);
-        }
-        return XRIT_OK;
-    };
+    d->costas_idle = costas_done;
+    set_relay_hook(d, s);
     const int rc_begin = d->clock.begin(length, d_soft, sym, cap, s, prof);
     d->clock.before_relay = nullptr;
+    d->costas_idle = false;
     XR_TRY(rc_begin);
-    if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
     XR_HIP(hipStreamSynchronize(s));
-    if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
-    bool redone = false;
-    XR_TRY(d->costas.finish(s, prof, &redone));
-    if (redone) {
-        // the Costas output was rewritten after more passes: the clock recovery starts over on it
-        if (length) (void)d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L, (double)carry0);
-        XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
-        XR_HIP(hipStreamSynchronize(s));
+    if (!costas_done) {
+        if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
+        bool redone = false;
+        XR_TRY(d->costas.finish(s, prof, &redone));
+        if (redone) {
+            // the Costas output was rewritten after more passes: the clock recovery starts over on it
+            const int L = d->costas.L;
+            if (length) (void)d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L);
+            XR_TRY(d->clock.begin(length, d_soft, sym, cap, s, prof));
+            XR_HIP(hipStreamSynchronize(s));
+        }
     }
     XR_TRY(keep_stage(d, 3, slot, length, s));
     int rc = d->clock.finish(nsym, s, prof);
@@ -468,6 +522,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->agc_fallback_seen = false;
     SliceIO io;
     int rc = XRIT_OK;
+    bool costas_ahead = false;
     if (d->pf_count > 0) {
         // the front end of this call ran ahead (xrit_demod_prefetch_device): the loops wait for it, nothing else
         if (d->pf[0].samples != d_samples || d->pf[0].n != n || d->pf[0].type != type) {
@@ -482,6 +537,20 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         --d->pf_count;
         io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
         XR_HIP(hipStreamWaitEvent(s, d->ev_fe[f.set], 0));
+        if (f.costas_begun) {
+            // its Costas loop ran ahead as well (under the relay of the call before): the host looks at its stop test now
+            // (continuing the passes on stream2 in the rare case the batch did not close), the clock recovery follows on s
+            XR_HIP(hipEventSynchronize(d->ev_costas));
+            if (io.length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
+            bool redone = false;
+            rc = d->costas.finish(d->stream2, prof, &redone);
+            if (rc == XRIT_OK) {
+                XR_HIP(hipEventRecord(d->ev_costas, d->stream2));
+                XR_HIP(hipStreamWaitEvent(s, d->ev_costas, 0));
+                rc = loops(d, io, d_soft, cap, &total_sym, s, prof, true, f.slot);
+            }
+            costas_ahead = true;
+        }
     } else {
         const int set = d->next_set;
         d->next_set ^= 1;
@@ -490,7 +559,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         rc = front_end(d, d_samples, n, type, set, s, prof, &io);
         if (rc == XRIT_OK) { XR_HIP(hipEventRecord(d->ev_fe[set], s)); d->last_fe_set = set; }
     }
-    if (rc == XRIT_OK) rc = loops(d, io, d_soft, cap, &total_sym, s, prof);
+    if (rc == XRIT_OK && !costas_ahead) rc = loops(d, io, d_soft, cap, &total_sym, s, prof);
     if (rc != XRIT_OK) {
         // some stage has flipped its ping-pong state, a later one has not: the handle cannot go on
         d->poisoned = true;

@@ -160,14 +160,19 @@ struct ClockStage {
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
-    DevBuf xbuf;            // [pad | carry | new] input samples of the call
-    // The new samples (the Costas loop's output rows of 128 bytes) start on a 128-byte boundary: the carried tail
-    // sits right-aligned in front of it.  Unaligned, every output row straddled two lines (partial-line writes).
-    // (XPAD samples of room in front: a call that is run again from another carried state -- redo_flipped -- puts that
-    // state's unread tail in front of the input where it lies)
+    DevBuf xbuf[2];         // [pad | carry | new] input samples of a call.  Two of them: the producer of the NEXT call's samples
+                            // (the Costas loop of the next burst, started under this call's relay: xrit_demod_prefetch_device)
+                            // fills one while the walkers of the call in flight read the other
+    int xb = 0;             // the buffer the call in flight (the last call) reads
+    int x_pending = -1;     // the buffer input_slot() handed out for the next call
+    bool in_flight = false; // between begin() and finish()
+    // The new samples (the Costas loop's output rows of 128 bytes) start at a fixed place, XPAD samples into the buffer, on a
+    // 128-byte boundary -- wherever the producer writes them it does not need to know how many samples the call before left
+    // unread --; those `carry` samples (at most XPAD) are copied in right in front of them when the call begins.
     static constexpr size_t XPAD = 1024;
     float2 *xbase_fixed = nullptr;
-    float2 *xbase() const { return xbase_fixed ? xbase_fixed : xbuf.as<float2>() + XPAD + (16 - carry % 16) % 16; }
+    float2 *xdata() const { return xbuf[xb].as<float2>() + XPAD; }
+    float2 *xbase() const { return xbase_fixed ? xbase_fixed : xdata() - carry; }
     DevBuf st;              // carried ClockState + carry count
     DevBuf S, E, J, om, work, counters, sym, dlin, flags, wsolve, jmean;
     bool jmean_valid = false;         // jmean holds the mean chain Jacobian of an earlier, locked call with ...
@@ -189,10 +194,10 @@ struct ClockStage {
     void release();
     // where the producer must write the n new samples of this call
     int input_slot(size_t n, float2 **slot, hipStream_t s);
-    double2 *om_slot(int nb, int BL, double offset);
+    // (the statistic's phasor counts samples from the first NEW sample of the call: begin() turns it by the carried ones)
+    double2 *om_slot(int nb, int BL);
     bool om_ext = false;
     int om_nb = 0, om_BL = 256;
-    double om_offset = 0;
     // soft (real parts) and/or complex symbols; either may be null
     int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
     // The last call once more on its sign-flipped input (one capture across GPUs: this rank's Costas loop turned out
@@ -259,7 +264,7 @@ struct ClockStage {
     bool relay_by_default() const { return exact >= 1 || (exact == 0 && auto_passes > 0); }
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
-    std::function<int()> before_relay;   // called by begin() in front of the relay kernels of a call that plans them (the chain
+    std::function<int(int)> before_relay;   // called by begin() in front of the relay kernels of a call that plans them (the chain
                                          // starts the front end of the next burst there: xrit_demod_prefetch_device)
     DevBuf relay;               // segment records + per-pass counters
     DevBuf relay_rec;           // per symbol: read index and interpolator arm of the last exact walk (the next walk's first guess)
@@ -275,6 +280,7 @@ struct ClockStage {
     int ng_max = 8;             // XRIT_CLOCK_NG: one-wave groups per clock workgroup at most
     bool relay_global = false;  // walk from global memory even where the LDS-staged kernel applies (A/B runs)
     int relay_per_cu = 3;       // XRIT_RELAY_PER_CU: segments (walkers) per CU the relay plans (A/B runs)
+    bool relay_per_cu_set = false;
     int relay_no_handoff = -1;       // the relay's first pass starts from the timing guess, no hand-off passes: -1: in the default
                                      // configuration (cfg.clock_exact = 0); XRIT_NO_HANDOFF=0 / 1: never / with every relayed call (A/B runs)
     int relay_waves = 1;        // waves per walker team at most (clock_relay_wide.h; < 2: the one-wave walker of clock_relay.h)
