@@ -1054,6 +1054,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     relay_no_rec = getenv("XRIT_RELAY_NO_REC") != nullptr;
     relay_no_claim = getenv("XRIT_RELAY_NO_CLAIM") != nullptr;
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
+    if (const char *e = getenv("XRIT_AUTO_LONG_SEG")) auto_long_seg = atoi(e);
     if (const char *e = getenv("XRIT_RELAY_PER_CU")) { relay_per_cu = atoi(e) > 0 ? atoi(e) : 3; relay_per_cu_set = true; }
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
@@ -1228,11 +1229,12 @@ int ClockStage::relay_plan()
     // ring, else one wave (64 symbols per step; any symbol rate: clock_relay.h)
     j.relay_w = 0;
     if (!relay_global && relay_waves >= 2) {
-        if (relay_waves >= 8 && relay_span(par, RW_OWN * 8) + 8 <= RelayWide<8>::MAX_SPAN) j.relay_w = 8;
-        else if (relay_waves >= 4 && relay_span(par, RW_OWN * 4) + 8 <= RelayWide<4>::MAX_SPAN) j.relay_w = 4;
+        if (relay_waves >= 4 && relay_span(par, RW_OWN * 4) + 8 <= RelayWide<4>::MAX_SPAN) j.relay_w = 4;
         else if (relay_span(par, RW_OWN * 2) + 8 <= RelayWide<2>::MAX_SPAN) j.relay_w = 2;
     }
-    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? 1 : relay_per_cu);
+    // (without hand-off passes: two walkers per CU -- 24.8 k symbols per segment at C2, three passes; measured in the streamed
+    // bench against one per CU with two passes and three per CU with four: 2.12 / 2.35 / 2.27 ms per burst)
+    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? 2 : relay_per_cu);
     int cps = relay_window > 0 ? relay_window : (j.K + per_cu * cu_count - 1) / (per_cu * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
@@ -1240,9 +1242,14 @@ int ClockStage::relay_plan()
     // -- a segment is exact once everything within the merge length in front of it is: segments no shorter than the big
     // bursts' (16 k symbols), whatever the size of the call, so that n means the same parity everywhere.
     // (without hand-off passes -- the default configuration -- a segment must be long enough for the loop to forget the timing
-    // guess it starts from: never shorter than auto_long_seg, 49 k symbols; a call of fewer symbols is one segment, i.e. ONE
-    // exact walk from the carried state)
-    const int min_syms = j.no_handoff && exact == 0 && !relay_per_cu_set ? auto_long_seg : (j.relay_budget > 0 ? 16384 : 2048);
+    // guess it starts from: never shorter than auto_long_seg / 2, 24.6 k symbols, which three passes go with.  A call of up
+    // to three such segments is ONE segment instead -- one exact walk from the carried state takes no longer than three
+    // passes over a third of it, and it IS the serial trajectory.)
+    int min_syms = j.relay_budget > 0 ? 16384 : 2048;
+    if (j.no_handoff && exact == 0 && !relay_per_cu_set) {
+        const long long all = (long long)j.K * NS;
+        min_syms = all <= 3LL * (auto_long_seg / 2) ? (int)all : auto_long_seg / 2;
+    }
     if (relay_window <= 0 && cps * NS < min_syms) cps = (min_syms + NS - 1) / NS;
     if (cps < 1) cps = 1;
     j.cps = cps;
@@ -1305,11 +1312,10 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
 #define XR_RELAY_WIDE(WV)                                                                                             \
     do {                                                                                                              \
         const int wspan = relay_span(par, RW_OWN * WV);                                                               \
-        if (j.sym) hipLaunchKernelGGL((clock_relay_wide_kernel<true, WV>), dim3(j.G), dim3(64 * (WV + 1)), 0, s, a, j.relay_enq, wspan); \
-        else hipLaunchKernelGGL((clock_relay_wide_kernel<false, WV>), dim3(j.G), dim3(64 * (WV + 1)), 0, s, a, j.relay_enq, wspan);      \
+        if (j.sym) hipLaunchKernelGGL((clock_relay_wide_kernel<true, WV>), dim3(j.G), dim3(64 * WV), 0, s, a, j.relay_enq, wspan);       \
+        else hipLaunchKernelGGL((clock_relay_wide_kernel<false, WV>), dim3(j.G), dim3(64 * WV), 0, s, a, j.relay_enq, wspan);            \
     } while (0)
-            if (j.relay_w == 8) XR_RELAY_WIDE(8);
-            else if (j.relay_w == 4) XR_RELAY_WIDE(4);
+            if (j.relay_w == 4) XR_RELAY_WIDE(4);
             else if (j.relay_w == 2) XR_RELAY_WIDE(2);
 #undef XR_RELAY_WIDE
             else if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
@@ -1800,10 +1806,10 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
                 }
             if (job.relay_w > 0) {
                 const double st = hd[7] ? (double)hd[7] : 1.0, un = hd[9] ? (double)hd[9] : 1.0;
-                fprintf(stderr, "[xrit] relay team (wave 1) cycles per step: ring wait %.0f, setup %.0f, interpolate..scan %.0f, wait for the scan mailbox %.0f, "
-                                "positions..verdict %.0f, wait for the verdicts %.0f, commit + loop %.0f (%llu steps); prefetchers: %.0f cycles waiting per unit, "
-                                "%llu units, %.1f loop turns per unit, alive %.0f cycles per unit\n",
-                        hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st, hd[5] / st, hd[6] / st, hd[7], hd[8] / un, hd[9], hd[10] / un, hd[11] / un);
+                (void)un;
+                fprintf(stderr, "[xrit] relay team (wave 1) cycles per step: rings %.0f, setup %.0f, interpolate..scan %.0f, meeting + sums %.0f, "
+                                "positions..verdict %.0f, meeting + verdicts %.0f, commit + loop %.0f (%llu steps)\n",
+                        hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st, hd[5] / st, hd[6] / st, hd[7]);
             }
             for (int o = 0; o < 16 && job.relay_w == 0; o += 8) {
                 const double st = hd[o + 6] ? (double)hd[o + 6] : 1.0;

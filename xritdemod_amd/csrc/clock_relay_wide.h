@@ -4,9 +4,8 @@
 // demodulator.cpp:156,449) exactly, 64 symbols per step, with ONE wave: guess where the next 64 symbols sit, form their
 // timing errors side by side, two integer prefix sums give every lane its state on the float32 lattice, the literal
 // float32 step verifies.  That wave issues one instruction every 5..7 cycles and a pass over all segments takes
-// (segment length / 64) steps whatever the chip could do beside it; what the passes buy in parity is their horizon --
-// passes x segment length -- so the lever is symbols per step.  Here W waves (one per SIMD; 8: two) take a step
-// together:
+// (segment length / 64) steps whatever the chip could do beside it.  Here W waves of one workgroup, one per SIMD, take a
+// step together:
 //  * wave w owns symbols 62 w .. 62 w + 61 of the block (lanes 2..63).  Lanes 0 and 1 hold the two symbols in FRONT of
 //    them -- the history the timing error needs -- which the wave interpolates itself from the same (read index, arm)
 //    as their owner (wave w - 1's lanes 62, 63; for wave 0: the walker's carried p0, p1).  No interpolated value ever
@@ -18,11 +17,11 @@
 //    them do, and the literal state after the last one.  All waves read all verdicts and come to the same conclusion:
 //    another round (some (index, arm) moved), or commit the verified prefix of the block and go on from the literal
 //    state behind it.
-//  * a further wave streams samples and first guesses into LDS rings with loads that write LDS themselves
-//    (global_load_lds_dwordx4), six refill units in flight, and tells the walkers how far the rings are filled.
-// Waves wait for one another on sequence-numbered mailbox words (a wave's DS operations execute in order; the
-// prefetching wave never takes part, so s_barrier is not used); every wait has a watchdog that marks the segment
-// RELAY_STUCK instead of hanging the device.
+//  * the waves feed themselves: at the top of a step each wave loads its share of the samples (and first guesses) the team
+//    will read two steps later into registers and drops them into the LDS rings at the top of the next step -- a whole
+//    step hides the memory latency, no wave is set aside for it, and so the team can meet at s_barrier (two per round:
+//    after the sums, after the verdicts) instead of polling mailbox words.  The symbols a step commits are stored
+//    behind the next step's loads, so that the wait in front of a drop never includes a young store.
 #pragma once
 
 #include "clock_relay.h"
@@ -30,40 +29,25 @@
 namespace xrit {
 
 constexpr int RW_OWN = 62;            // symbols a wave owns per step
-constexpr int RW_XUNIT = 512;         // samples per refill unit: four loads of 1 KB (+ one of 64 bytes for the mirror)
-constexpr int RW_GUNIT = 1280;        // first guesses per refill unit: five loads of 1 KB
-constexpr int RW_UNIT_LOADS = 5;      // ... so that every unit in flight is five counts of vmcnt
-constexpr int RW_DEPTH = 6;           // refill units in flight at most
 constexpr int RW_SLOT = 8;            // mailbox words per wave
-constexpr int RW_REC_PAD = 2048;      // words behind the last segment's records a refill unit may touch
+constexpr int RW_REC_PAD = 2048;      // words behind the last segment's records a refill may touch
+constexpr int RW_XLOADS = 8;          // samples a lane loads per refill unit (a wave: 512 samples: more than its share of a step)
 
 template <int W> struct RelayWide {
-    static constexpr int RX = W <= 2 ? 2048 : (W <= 4 ? 4096 : 8192);     // sample ring
-    static constexpr int GR = W <= 4 ? 2048 : 4096;                       // ring of first guesses (symbols)
-    // samples a block may span at most: the ring holds the block, a unit being refilled, the 128-sample rounding of
-    // the ring's start and some slack
-    static constexpr int MAX_SPAN = RX - RW_XUNIT - 128 - 80;
-    static constexpr size_t lds_bytes()
-    {
-        return sizeof(float) * (XR_MM_NSTEPS + 1) * XR_MM_NTAPS + sizeof(cf32) * (RX + RELAY_XMIR) + sizeof(unsigned) * GR +
-               sizeof(int) * (3 * RW_SLOT * W + 16);
-    }
+    static constexpr int RX = W <= 2 ? 4096 : 8192;                       // sample ring
+    static constexpr int GR = 1024;                                       // ring of first guesses (symbols)
+    static constexpr int XU = 64 * RW_XLOADS * W;                         // samples per refill unit
+    // samples a block may span at most: the ring holds three blocks (the one being walked, the next one, and the one whose
+    // samples are dropped in at the end of this step -- readable from the step after next) and a unit of slack
+    static constexpr int MAX_SPAN = (RX - XU - 64) / 3 < XU - 32 ? (RX - XU - 64) / 3 : XU - 32;     // (... and a unit refills more than a step uses up)
 };
 
-// wait for the oldest of `inflight` refill units (LDS-direct loads complete in the order issued; s_waitcnt takes an
-// immediate)
-__device__ __forceinline__ void rw_wait_oldest(int inflight)
+// the team meets: LDS traffic of every wave is done (the mailbox, the rings), nothing else is waited for -- global
+// loads and stores stay in flight across it (__syncthreads() would drain them)
+__device__ __forceinline__ void rw_barrier()
 {
-    switch (inflight) {
-    case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-
 __device__ __forceinline__ void rw_st4(int *p, int a, int b, int c, int d)
 {
     typedef int rw_v4i __attribute__((ext_vector_type(4)));
@@ -80,32 +64,28 @@ __device__ __forceinline__ int rw_ld_lane(const int *p)
 __device__ __forceinline__ int rw_word(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 
 #ifdef XRIT_RELAY_TIMING
-// (instrumented build: cycles per phase of a step summed over wave 1's of all teams -- relay_dbg[0..6] --, steps in [7];
-// the prefetchers: cycles waiting for their oldest unit [8], units landed [9], loop turns [10], cycles alive [11])
+// (instrumented build: cycles per phase of a step summed over wave 1's of all teams -- relay_dbg[0..6] --, steps in [7])
 #define RW_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wacc[i] += t_ - wlast; wlast = t_; } while (0)
 #else
 #define RW_TICK(i) do { } while (0)
 #endif
 
-constexpr int RW_SPIN_LIMIT = 1 << 20;      // polls of a mailbox (~100 cycles each) before a wave gives up
-
-// Segment s of the call, walked by W waves (threads 0 .. 64 W - 1) fed by one more (the last 64 threads).
+// Segment s of the call, walked by W waves.
 template <bool SYM, int W>
-__global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArgs a, int pass, int span)
+__global__ void __launch_bounds__(64 * W) clock_relay_wide_kernel(RelayArgs a, int pass, int span)
 {
     using CFG = RelayWide<W>;
-    constexpr int RX = CFG::RX, GR = CFG::GR;
+    constexpr int RX = CFG::RX, GR = CFG::GR, XU = CFG::XU, GU = 64 * W;
     if (a.ctl && !a.ctl[0]) return;                              // the tiled hand-off has not closed: nothing to refine yet
     if (pass > 0 && a.changed[RELAY_STAT * (pass - 1)] == 0) return;      // closed in an earlier pass
     __shared__ __attribute__((aligned(16))) float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
     __shared__ __attribute__((aligned(16))) cf32 xr[RX + RELAY_XMIR];
     __shared__ __attribute__((aligned(16))) unsigned gr[GR];
-    __shared__ __attribute__((aligned(16))) int mailA[RW_SLOT * W];          // scan totals, one generation
-    __shared__ __attribute__((aligned(16))) int mailC[2 * RW_SLOT * W];      // verdicts, two generations
-    __shared__ int sh_xhi, sh_pos_ii, sh_done, sh_ghi, sh_pos_n;
+    __shared__ __attribute__((aligned(16))) int mailA[RW_SLOT * W];          // scan totals
+    __shared__ __attribute__((aligned(16))) int mailC[RW_SLOT * W];          // verdicts
     clock_table_to_lds(table, a.table);
     const int s = blockIdx.x, lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // 0 .. W - 1: walkers; W: the prefetcher
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const RelaySeg *ein = a.ends[(pass + 1) & 1];
     RelaySeg *eout = a.ends[pass & 1];
     const int Lseg = a.cps * a.NS;
@@ -129,15 +109,7 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
     T.p0 = cf32{relay_lane(T.p0.x, 0), relay_lane(T.p0.y, 0)}; T.p1 = cf32{relay_lane(T.p1.x, 0), relay_lane(T.p1.y, 0)};
     dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;
     const RelaySeg prev = a.start[s];
-    const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
-    // ring positions are sample indices + shx, so that an even position is a 16-byte aligned address (the samples are
-    // 8-byte aligned only when a call is run again from another carried state, ClockStage::redo_flipped: the sample in
-    // front of the buffer's first then exists, kernels.h)
-    const int shx = (int)((reinterpret_cast<unsigned long long>(xs) >> 3) & 1ull);
-    const int x_lo = ((int)(T.ii > 4 ? T.ii - 4 : 0) + shx) & ~127;          // position the ring starts at
-    for (int i = threadIdx.x; i < RW_SLOT * W; i += blockDim.x) { mailA[i] = -1; mailC[i] = -1; mailC[RW_SLOT * W + i] = -1; }
-    if (threadIdx.x == 0) { sh_xhi = x_lo; sh_pos_ii = (int)T.ii + shx; sh_done = 0; sh_ghi = 0; sh_pos_n = 0; }
-    __syncthreads();      // (the only barrier: all waves pass it before any can leave)
+    __syncthreads();      // (the table is in place)
     if (dead) {
         if (pass > 0 && (prev.flags & RELAY_DEAD)) { if (threadIdx.x == 0) eout[s] = ein[s]; return; }
         if (threadIdx.x == 0) {
@@ -157,94 +129,14 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
     const int ref = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii)) -
                     RELAY_REF_MARGIN;
     unsigned *recs = a.rec ? a.rec + obase : nullptr;
+    const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
     const int ni_w = (int)(a.ni < 0x7fffffffLL ? a.ni : 0x7fffffffLL);     // (read indices are 32-bit here)
+    const int nlast = (int)(a.N > 0 ? (a.N - 1 < 0x7fffffffLL ? a.N - 1 : 0x7fffffffLL) : 0);
 
-    if (wv == W) {
-        // ---- the prefetcher.  Positions [walker, x_landed) of the samples sit in the ring; a slot is overwritten only when
-        // the walker's published position is past it.  Same for the first guesses, by symbol number.
-        const int plast = (int)(a.N > 1 ? a.N - 1 : 1) + shx;
-        const int pmax = (plast + 32) & ~1;           // (the input buffer has 64 samples of room behind its end)
-        const float4 *x4 = reinterpret_cast<const float4 *>(xs - shx);       // position p (even) at x4[p / 2]
-        int x_iss = x_lo, x_land = x_lo, g_iss = 0, g_land = 0, inflight = 0;
-        unsigned types = 0, rounds = 0;
-#ifdef XRIT_RELAY_TIMING
-        unsigned long long pf_wait = 0, pf_units = 0;
-        const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
-#endif
-        while (!relay_ld(&sh_done)) {
-            if (++rounds > (1u << 24)) { if (lane == 0) a.changed[RELAY_STAT * pass + 3] = 0xc0000000u | (unsigned)s; break; }   // watchdog
-            const int ppos = relay_ld(&sh_pos_ii);
-            const bool fx = x_iss + RW_XUNIT - RX <= ppos && x_iss <= plast + span + 16;
-            bool fg = false;
-            int pn = 0;
-            if (use_rec) { pn = relay_ld(&sh_pos_n); fg = g_iss < n_rec && g_iss + RW_GUNIT - GR <= pn; }
-            if (inflight < RW_DEPTH && (fx || fg)) {
-                // (first guesses first when they are the scarcer of the two: less than three blocks ahead)
-                const bool do_g = fg && (!fx || g_iss - pn < 3 * RW_OWN * W);
-                if (do_g) {
-#pragma unroll
-                    for (int q = 0; q < RW_UNIT_LOADS; ++q)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + g_iss + 256 * q + 4 * lane),
-                                                         (__attribute__((address_space(3))) void *)(gr + ((g_iss + 256 * q) & (GR - 1))), 16, 0, 0);
-                    g_iss += RW_GUNIT;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int p = x_iss + 128 * q + 2 * lane;
-                        p = p < pmax ? p : pmax;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x4 + (p >> 1)),
-                                                         (__attribute__((address_space(3))) void *)(xr + ((x_iss + 128 * q) & (RX - 1))), 16, 0, 0);
-                    }
-                    // the ring's first samples again behind its end (a window never wraps): those of the revolution this unit
-                    // belongs to -- the real thing for the unit at the ring's start, the same bytes once more for the others
-                    {
-                        int p = (x_iss & ~(RX - 1)) + 2 * (lane & 3);
-                        p = p < pmax ? p : pmax;
-                        if (lane < 4)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x4 + (p >> 1)),
-                                                             (__attribute__((address_space(3))) void *)(xr + RX), 16, 0, 0);
-                    }
-                    x_iss += RW_XUNIT;
-                }
-                types |= (do_g ? 1u : 0u) << inflight;
-                ++inflight;
-                continue;
-            }
-            if (inflight > 0) {
-#ifdef XRIT_RELAY_TIMING
-                const unsigned long long tw_ = __builtin_amdgcn_s_memtime();
-                rw_wait_oldest(inflight);
-                pf_wait += __builtin_amdgcn_s_memtime() - tw_;
-                ++pf_units;
-#else
-                rw_wait_oldest(inflight);
-#endif
-                if (types & 1u) { g_land += RW_GUNIT; if (lane == 0) relay_st(&sh_ghi, g_land); }
-                else { x_land += RW_XUNIT; if (lane == 0) relay_st(&sh_xhi, x_land); }
-                types >>= 1;
-                --inflight;
-                continue;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        // (nothing may still be on its way into this workgroup's LDS when the wave ends)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef XRIT_RELAY_TIMING
-        if (lane == 0 && pass < 8) {
-            atomicAdd(&relay_dbg[8], pf_wait);
-            atomicAdd(&relay_dbg[9], pf_units);
-            atomicAdd(&relay_dbg[10], (unsigned long long)rounds);
-            atomicAdd(&relay_dbg[11], __builtin_amdgcn_s_memtime() - pf_t0);
-        }
-#endif
-        return;
-    }
-
-    // ---- the walkers
     if (threadIdx.x == 0) {
         atomicAdd(&a.changed[RELAY_STAT * pass], 1u);
         // how far this start is from the one the segment was last walked from (samples): what the automatic closure
-        // looks at (ClockStage::finish).  Non-negative floats order like their bits; watchdog marks stay on top.
+        // looks at (ClockStage::finish).  Non-negative floats order like their bits.
         if (pass > 0 && (prev.flags & RELAY_WALKED)) {
             const float mv = fabsf(clock_tdiff(prev.s, T));
             atomicMax(&a.changed[RELAY_STAT * pass + 3], __float_as_uint(mv));
@@ -264,11 +156,67 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
     const bool owned = lane >= 2;
     const int jw = RW_OWN * wv;                   // the block's symbol this wave's lane 2 holds
     const int jl = lane - 2;                      // this lane's symbol, relative to that
+    const bool hist_t = wv == 0 && lane < 2;      // wave 0's history lanes: the walker's own p1, p0
+    const bool first = wv == 0 && lane == 2;      // the block's first symbol starts from the walker's state itself
+
+    // ---- the rings.  Samples [x_lo, x_wr) and first guesses [0, g_wr) have been dropped in; what was dropped in before the
+    // team's last meeting can be read.  A unit (XU samples / GU guesses: more than a step uses up) is loaded at the top of
+    // step k, dropped in at the top of step k + 1 -- a whole step for the memory to answer -- and read from step k + 2 on.
+    const int x_lo = (int)(T.ii > 4 ? T.ii - 4 : 0) & ~(XU - 1);       // (units start on multiples of XU: the ring's slot 0 too)
+    int x_wr = x_lo, g_wr = 0;
+    cf32 xst[RW_XLOADS];
+    unsigned gst = RELAY_NOGUESS;
+    bool x_pend = false, g_pend = false;          // a unit is loaded and not yet dropped in
+    auto load_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < RW_XLOADS; ++q) {
+            const unsigned i = (unsigned)(x_wr + 64 * RW_XLOADS * wv + lane + 64 * q);
+            xst[q] = xs[i < (unsigned)nlast ? i : (unsigned)nlast];
+        }
+    };
+    auto drop_x = [&]() {
+        const int slot0 = (x_wr & (RX - 1)) + 64 * RW_XLOADS * wv + lane;
+#pragma unroll
+        for (int q = 0; q < RW_XLOADS; ++q) xr[slot0 + 64 * q] = xst[q];
+        // (the ring's first samples again behind its end, so that a window never wraps)
+        if ((x_wr & (RX - 1)) == 0 && wv == 0 && lane < RELAY_XMIR) xr[RX + lane] = xst[0];
+    };
+    auto load_g = [&]() {
+        const int m = g_wr + 64 * wv + lane;
+        gst = m < n_rec ? recs[(unsigned)m] : RELAY_NOGUESS;
+    };
+    auto drop_g = [&]() { gr[(g_wr + 64 * wv + lane) & (GR - 1)] = gst; };
+    // prologue: what the first two steps read, loaded and dropped in at once
+    {
+#pragma nounroll
+        while (x_wr < (int)T.ii + 2 * span + 16) { load_x(); drop_x(); x_wr += XU; }
+        if (use_rec) {
+#pragma nounroll
+            while (g_wr < 2 * RW_OWN * W && g_wr < n_rec) { load_g(); drop_g(); g_wr += GU; }
+        }
+    }
+    rw_barrier();
+    int x_vis = x_wr, g_vis = g_wr;               // what every wave may read
+
+    // the symbols a step commits leave at the top of the NEXT step, between the drop and the new loads: the wait in front of
+    // a drop is then for loads and stores of a step ago and nothing younger
+    float pc_x = 0.f, pc_y = 0.f;
+    unsigned pc_rec = 0, pc_o = 0;
+    bool pc_soft = false, pc_any = false;
+    auto flush_commit = [&]() {
+        if (pc_any) {
+            if (pc_soft) {
+                if (softs) softs[pc_o] = pc_x;
+                if (SYM && syms) syms[pc_o] = make_float2(pc_x, pc_y);
+            }
+            if (recs) recs[pc_o] = pc_rec;
+        }
+        pc_any = false;
+    };
+
     int n = 0;
     unsigned steps = 0, rounds_total = 0;
-    unsigned q = 0;                               // mailbox sequence number: one per round
     bool exhausted = false, stuck = false;
-    int x_hi = x_lo, g_hi = 0;                    // what the rings are known to hold
     float m1 = 0.f, m2 = 0.f;                     // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
     unsigned long long wacc[7] = {0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_amdgcn_s_memtime();
@@ -278,37 +226,35 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
         ++steps;
         const int ii0 = (int)T.ii;
         if ((unsigned)ii0 >= (unsigned)ni_w) { exhausted = true; break; }
-        const int need_x = ii0 + shx + span + 8;                // (a position)
+        // what the step before loaded goes into the rings (every wave is past its reads of that step; what is overwritten lies
+        // behind the walker) ...
+        x_vis = x_wr; g_vis = g_wr;
+        if (x_pend) { drop_x(); x_wr += XU; }
+        if (g_pend) { drop_g(); g_wr += GU; }
+        // ... the symbols of the step before leave (nothing is in flight at this point: whatever the compiler makes these
+        // stores wait for costs nothing) ...
+        flush_commit();
+        // ... and the next unit is asked for, as far as the ring has room (a slot is free once the walker stands behind it)
+        // (the guesses first: this compiler waits for everything in flight before it reuses their register)
+        g_pend = use_rec && g_wr < n + 3 * RW_OWN * W && g_wr < n_rec && g_wr + GU - GR <= n;
+        if (g_pend) load_g();
+        x_pend = x_wr < ii0 + 3 * span + 16 && x_wr + XU - RX <= ii0 && x_wr <= nlast + span + 16;
+        if (x_pend) load_x();
+        const int need_x = ii0 + span + 8;
         const int blk = n + RW_OWN * W < Lseg ? n + RW_OWN * W : Lseg;
         const int need_g = blk < n_rec ? blk : n_rec;
-        if (x_hi < need_x || (use_rec && g_hi < need_g)) {
-            int spins = 0;
-#pragma nounroll
-            while (x_hi < need_x) {
-                x_hi = relay_ld(&sh_xhi);
-                if (x_hi >= need_x) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { stuck = true; break; }
-            }
-#pragma nounroll
-            while (use_rec && !stuck && g_hi < need_g) {
-                g_hi = relay_ld(&sh_ghi);
-                if (g_hi >= need_g) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { stuck = true; break; }
-            }
-            if (stuck) break;
-        }
+        // (the refill rule keeps what can be read a block ahead of the walker -- a unit is more than a step uses up, and one is
+        // asked for whenever less than three blocks are in place; if that ever fails the walk gives up rather than read
+        // samples that are not there)
+        if (x_vis < need_x || (use_rec && g_vis < need_g)) { stuck = true; break; }
         RW_TICK(0);
-        // the walker's state on the lattice; this wave's lane 2 at the walker's rate (64-bit on the scalar side: 500
-        // symbols at the rate's fraction overflow 32 bits), the lanes relative to it
+        // the walker's state on the lattice; this wave's lane 2 at the walker's rate (64-bit on the scalar side), the lanes
+        // relative to it
         const int mu0u = (int)(T.mu * 16777216.0f), W0 = (int)(T.omega * 16777216.0f);
         const int wint = W0 >> 24, wfrac = W0 & 0xffffff;
         const long long fb = (long long)mu0u + (long long)jw * (long long)wfrac;
         const int bii_w = ii0 + jw * wint + (int)(fb >> 24), fr_w = (int)(fb & 0xffffff);
         const int fr0 = fr_w + jl * wfrac, bii = bii_w + jl * wint;
-        const bool hist_t = wv == 0 && lane < 2;           // wave 0's history lanes: the walker's own p1, p0
-        const bool first = wv == 0 && lane == 2;           // the block's first symbol starts from the walker's state itself
         int cii = bii + (fr0 >> 24), carm;
         float cmu = (float)(fr0 & 0xffffff) * (1.0f / 16777216.0f), com = T.omega;
         if (first) { cii = ii0; cmu = T.mu; }
@@ -323,16 +269,15 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
         cf32 p0{0.f, 0.f};
         float mm = 0.f;
         ClockState st{};
-        int cnt = 0, src = -1, nv = 0;
+        int nv = 0;
         bool any_exh = false;
         RW_TICK(1);
         for (int round = 0; round < RELAY_ROUNDS; ++round) {
             ++rounds_total;
-            ++q;
-            const bool inrange = hist_t || (cii >= ii0 && cii + shx + XR_MM_NTAPS <= need_x);
+            const bool inrange = hist_t || (cii >= ii0 && cii + XR_MM_NTAPS <= need_x);
             {
                 cf32 w[XR_MM_NTAPS];
-                const cf32 *wp = xr + ((cii + shx) & (RX - 1));
+                const cf32 *wp = xr + (cii & (RX - 1));
 #pragma unroll
                 for (int k = 0; k < XR_MM_NTAPS; ++k) w[k] = wp[k];
                 p0 = clock_interp_arm(w, table, carm);
@@ -354,23 +299,13 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
             // ... and across the waves: totals, and the two local prefixes the successor's history lanes stand behind
             if (wv < W - 1) {
                 const int l62 = relay_dpp<0x138>(ldx);          // lane 63 <- lane 62
-                if (lane == 63) {
-                    rw_st4(&mailA[RW_SLOT * wv], lc, ldx + le, l62, ldx);
-                    relay_st(&mailA[RW_SLOT * wv + 4], (int)q);
-                }
+                if (lane == 63) rw_st4(&mailA[RW_SLOT * wv], lc, ldx + le, l62, ldx);
             }
-            int Cp = 0, Dp = 0, Dh0 = 0, Dh1 = 0;
             RW_TICK(2);
+            rw_barrier();
+            int Cp = 0, Dp = 0, Dh0 = 0, Dh1 = 0;
             if (wv > 0) {
-                int v, spins = 0;
-#pragma nounroll
-                for (;;) {
-                    v = rw_ld_lane(&mailA[lane < RW_SLOT * W ? lane : 0]);
-                    const bool mine = lane < RW_SLOT * wv && (lane & (RW_SLOT - 1)) == 4;       // sequence words of the waves in front
-                    if (!__any(mine && v != (int)q)) break;
-                    if (++spins > RW_SPIN_LIMIT) { stuck = true; break; }
-                }
-                if (stuck) break;
+                const int v = rw_ld_lane(&mailA[lane < RW_SLOT * W ? lane : 0]);
 #pragma unroll
                 for (int u = 0; u < W - 1; ++u) {
                     if (u < wv) {
@@ -424,26 +359,19 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
             // the verdict: the lane behind whose symbol the wave's verified stretch ends leaves its literal state
             {
                 const int wl = c > 0 ? c + 1 : 2;
-                const int packed = (int)(((q & 0xffffu) << 16) | (wstale ? 0x200u : 0u) | (exh ? 0x100u : 0u) | (full ? 0x80u : 0u) | (unsigned)c);
+                const int packed = (int)((wstale ? 0x200u : 0u) | (exh ? 0x100u : 0u) | (full ? 0x80u : 0u) | (unsigned)c);
                 if (lane == wl) {
-                    int *slot = &mailC[(q & 1u) * (RW_SLOT * W) + RW_SLOT * wv];
+                    int *slot = &mailC[RW_SLOT * wv];
                     rw_st4(slot, (int)st.ii, __float_as_int(st.mu), __float_as_int(st.omega), __float_as_int(st.p0.x));
                     rw_st4(slot + 4, __float_as_int(st.p0.y), __float_as_int(st.p1.x), __float_as_int(st.p1.y), packed);
                 }
             }
             RW_TICK(4);
-            int v, spins = 0;
-#pragma nounroll
-            for (;;) {
-                v = rw_ld_lane(&mailC[(q & 1u) * (RW_SLOT * W) + (lane < RW_SLOT * W ? lane : 0)]);
-                const bool seqw = lane < RW_SLOT * W && (lane & (RW_SLOT - 1)) == 7;
-                if (!__any(seqw && ((unsigned)v >> 16) != (q & 0xffffu))) break;
-                if (++spins > RW_SPIN_LIMIT) { stuck = true; break; }
-            }
-            if (stuck) break;
-            RW_TICK(5);
+            rw_barrier();
+            const int v = rw_ld_lane(&mailC[lane < RW_SLOT * W ? lane : 0]);
             bool any_stale = false;
-            nv = 0; src = -1; any_exh = false;
+            int src = -1;
+            nv = 0; any_exh = false;
             {
                 bool chain = true;
 #pragma unroll
@@ -458,7 +386,10 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
                     }
                 }
             }
-            cnt = c;
+            RW_TICK(5);
+            // (everybody has read the verdicts and the sums before anybody writes the next round's: the next meeting is
+            // behind the next round's sums, and those are written only by waves that have passed this point -- a wave that
+            // is still reading mailA of this round has not met the others at the verdicts yet)
             if (any_stale && round + 1 < RELAY_ROUNDS) continue;
             // the literal state behind the last verified symbol: where the next block starts
             if (src >= 0) {
@@ -470,28 +401,23 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
             }
             break;
         }
-        if (stuck) break;
-        // commit the verified prefix of the block
+        // the verified prefix of the block: its symbols leave at the top of the next step
         {
             const int jb = jw + jl;            // this lane's symbol within the block
-            if (owned && jb < nv) {
+            pc_any = owned && jb < nv;
+            if (pc_any) {
                 if (pass == 0) { m1 += fabsf(p0.x); m2 += p0.x * p0.x; }
-                const int o = n + jb;
-                if (o < n_out) {
-                    if (softs) softs[o] = p0.x;
-                    if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
-                }
-                if (recs) {
-                    const unsigned rel = (unsigned)(cii - ref);
-                    recs[o] = rel < (1u << 24) ? (rel << 8) | (unsigned)carm : RELAY_NOGUESS;
-                }
+                const unsigned rel = (unsigned)(cii - ref);
+                pc_rec = rel < (1u << 24) ? (rel << 8) | (unsigned)carm : RELAY_NOGUESS;
+                pc_o = (unsigned)(n + jb);
+                pc_soft = n + jb < n_out;
+                pc_x = p0.x; pc_y = p0.y;
             }
         }
-        (void)cnt;
         n += nv;
-        if (threadIdx.x == 0) { relay_st(&sh_pos_ii, (int)T.ii + shx); relay_st(&sh_pos_n, n); }
         if (any_exh || nv == 0) { exhausted = true; break; }      // (nv == 0 without exhaustion cannot happen: the first lane is good)
     }
+    flush_commit();
 #ifdef XRIT_RELAY_TIMING
     if (lane == 0 && wv == (W > 1 ? 1 : 0) && pass < 8) {
         for (int i = 0; i < 7; ++i) atomicAdd(&relay_dbg[i], wacc[i]);
@@ -507,7 +433,6 @@ __global__ void __launch_bounds__(64 * (W + 1)) clock_relay_wide_kernel(RelayArg
         }
     }
     if (threadIdx.x == 0) {
-        relay_st(&sh_done, 1);
         atomicAdd(&a.changed[RELAY_STAT * pass + 1], steps);
         atomicAdd(&a.changed[RELAY_STAT * pass + 2], rounds_total);
         if (stuck) a.changed[RELAY_STAT * pass + 3] = 0x80000000u | (unsigned)s;
