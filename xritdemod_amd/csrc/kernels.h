@@ -260,7 +260,7 @@ struct ClockStage {
     float auto_snr = 10.0f;     // ... and to closure outright when the first pass's soft symbols show 2 Es/N0 below this (7 dB)
     float auto_snr_floor = 2.0f;  // ... but not below this: no signal (noise alone shows 1.75)
     float snr_estimate = 0.f;   // (of the last call that looked)
-    long long auto_min = 4096;
+    long long auto_min = 1;     // (round 4: a short call is one exact walk of a few dozen steps -- cheaper than hand-off passes that run until they close)
     bool relay_by_default() const { return exact >= 1 || (exact == 0 && auto_passes > 0); }
     bool relay_auto = false;    // ... the last call was
     int relay_window = 0;       // chains per segment (0: chosen per call, ~4 segments per CU)
