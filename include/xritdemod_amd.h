@@ -52,6 +52,9 @@ const char *xrit_last_error(void);
 const char *xrit_version(void);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int xrit_device_count(void);
+/* 1 when the library was built with the measurement switches of DESIGN.md section 7 (make EXTRA=-DXRIT_EXPERIMENTS: the
+ * matrix-pipe decimator, walker teams, A/B environment switches); the shipped build has none of them: 0 */
+int xrit_build_experiments(void);
 
 /* ------------------------------------------------------------------------
  * Tap designers -- SatHelper::Filters (demodulator.cpp:443-444), host only.

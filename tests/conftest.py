@@ -19,6 +19,23 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: needs a library built with make EXTRA=-DXRIT_EXPERIMENTS (the A/B "
+                            "switches of DESIGN.md section 7 are not in the shipped build)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests of the measurement switches run only against a library that carries them."""
+    try:
+        import xritdemod_amd
+        have = xritdemod_amd.build_experiments()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="library built without -DXRIT_EXPERIMENTS")
+    for it in items:
+        if "experiments" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

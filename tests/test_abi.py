@@ -133,3 +133,24 @@ def test_integration_md_snippets_compile_against_the_header(tmp_path):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_shipped_build_has_no_matrix_pipe_code():
+    """BASELINE.json's north star: no MFMA on this path.  The f32-MFMA decimator of round 3 (an experiment that lost its
+    A/B, profiles/r3_mfma_decimator.txt) is compiled only with make EXTRA=-DXRIT_EXPERIMENTS: the device code of a default
+    build of csrc/fir.hip holds no v_mfma instruction, and the library says which build it is."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "xritdemod_amd", "csrc", "fir.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "fir.s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                               "-o", out, src], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    assert "fir_decim_kernel" in text and "v_mfma" not in text
+    import xritdemod_amd
+    assert xritdemod_amd.build_experiments() is False

@@ -113,6 +113,7 @@ def test_fir_straight_line_kernels_are_the_generic_ones_bit_for_bit(xa, oracle_m
     assert len(fast) == sum(n_out) and np.array_equal(fast.view(np.uint32), generic.view(np.uint32))
 
 
+@pytest.mark.experiments
 def test_mfma_decimator_experiment_is_bit_identical(xa, oracle_mod, monkeypatch):
     """XRIT_MFMA_DEC=1 (read when the filter is created): the C2 decimator as a block-Toeplitz product on
     v_mfma_f32_16x16x4_f32 -- an experiment that is NOT the default (slower: profiles/r3_mfma_decimator.txt) but must stay
@@ -405,6 +406,7 @@ def test_exact_walker_from_global_memory(xa, oracle_mod, lrit_1m, monkeypatch):
         assert len(so) == len(sg) and np.array_equal(so.view(np.uint32), sg.view(np.uint32))
 
 
+@pytest.mark.experiments
 def test_walker_placement_does_not_change_the_words(xa, monkeypatch):
     """The relay's workgroups pick the walking wave by where the hardware put their two waves (a walker on the SIMD of an
     older walker takes a third longer: csrc/clock_relay.h, RelayArgs::simd_claim).  Which wave walks is arithmetic-neutral:
@@ -423,6 +425,7 @@ def test_walker_placement_does_not_change_the_words(xa, monkeypatch):
             assert a.stats().clock_relay_passes == b.stats().clock_relay_passes
 
 
+@pytest.mark.experiments
 def test_ab_switches_leave_the_words_alone(xa, monkeypatch):
     """The A/B switches of the round's last measurements (read when a handle is created) change the schedule, not the
     arithmetic: the decimator's workgroup size (XRIT_DEC_THREADS: its outputs and the AGC run maps -- one per wave -- are the

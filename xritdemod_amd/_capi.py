@@ -52,6 +52,7 @@ _SIGNATURES = {
     "xrit_last_error": (C.c_char_p, []),
     "xrit_version": (C.c_char_p, []),
     "xrit_device_count": (C.c_int, []),
+    "xrit_build_experiments": (C.c_int, []),
     "xrit_lowpass_taps": (C.c_int, [C.c_double] * 4 + [_vp, C.c_int]),
     "xrit_rrc_taps": (C.c_int, [C.c_double] * 4 + [C.c_int, _vp, C.c_int]),
     "xrit_mmse_table": (None, [_vp]),
@@ -160,6 +161,11 @@ def _check(rc):
 
 def device_count():
     return lib().xrit_device_count()
+
+
+def build_experiments():
+    """True when the library carries the measurement switches (make EXTRA=-DXRIT_EXPERIMENTS)."""
+    return bool(lib().xrit_build_experiments())
 
 
 def version():

@@ -464,7 +464,11 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 
 }  // namespace xrit
 #include "clock_relay.h"
-#include "clock_relay_wide.h"
+#ifdef XRIT_EXPERIMENTS
+#include "clock_relay_wide.h"      // walker teams: built, verified, no faster
+#else
+namespace xrit { constexpr int RW_REC_PAD = 0; }
+#endif
 namespace xrit {
 
 // SS symbols of one lane.  Fast path: every running lane of the wave stays inside its ring for the whole
@@ -1046,8 +1050,13 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     }
     cur = 0;
     carry = 0;
+    // diagnostics, read once, here (a host that calls setenv races with getenv on a launch path): the fallback paths of the
+    // shipped configuration
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
     relay_global = getenv("XRIT_RELAY_GLOBAL") != nullptr;
+    trace_env = getenv("XRIT_TRACE") != nullptr;
+#ifdef XRIT_EXPERIMENTS
+    // A/B switches of the measurements in DESIGN.md (make EXTRA=-DXRIT_EXPERIMENTS: not in the shipped library)
     if (const char *e = getenv("XRIT_NO_HANDOFF")) relay_no_handoff = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("XRIT_RELAY_WAVES")) relay_waves = atoi(e);
     if (const char *e = getenv("XRIT_RELAY_TEAMS")) relay_teams_per_cu = atoi(e) > 0 ? atoi(e) : 1;
@@ -1056,10 +1065,10 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     if (const char *e = getenv("XRIT_AUTO_PASSES")) auto_passes = atoi(e);
     if (const char *e = getenv("XRIT_AUTO_LONG_SEG")) auto_long_seg = atoi(e);
     if (const char *e = getenv("XRIT_RELAY_PER_CU")) { relay_per_cu = atoi(e) > 0 ? atoi(e) : 3; relay_per_cu_set = true; }
-    trace_env = getenv("XRIT_TRACE") != nullptr;
     no_meanj = getenv("XRIT_NO_MEANJ") != nullptr;
     pass_writes = getenv("XRIT_NO_PASS_OUTPUT") == nullptr;
     ng_max = getenv("XRIT_CLOCK_NG") ? atoi(getenv("XRIT_CLOCK_NG")) : 8;
+#endif
     return XRIT_OK;
 }
 
@@ -1228,10 +1237,12 @@ int ClockStage::relay_plan()
     // the walker: a team of 8, 4 or 2 waves (clock_relay_wide.h) where a block of 62 symbols per wave fits the team's sample
     // ring, else one wave (64 symbols per step; any symbol rate: clock_relay.h)
     j.relay_w = 0;
+#ifdef XRIT_EXPERIMENTS
     if (!relay_global && relay_waves >= 2) {
         if (relay_waves >= 4 && relay_span(par, RW_OWN * 4) + 8 <= RelayWide<4>::MAX_SPAN) j.relay_w = 4;
         else if (relay_span(par, RW_OWN * 2) + 8 <= RelayWide<2>::MAX_SPAN) j.relay_w = 2;
     }
+#endif
     // (without hand-off passes: two walkers per CU -- 24.8 k symbols per segment at C2, three passes; measured in the streamed
     // bench against one per CU with two passes and three per CU with four: 2.12 / 2.35 / 2.27 ms per burst)
     const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? 2 : relay_per_cu);
@@ -1309,6 +1320,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     {
         ProfScope ps(prof, "clock_relay", s);
         for (int q = 0; q < count && j.relay_enq < limit; ++q, ++j.relay_enq) {
+#ifdef XRIT_EXPERIMENTS
 #define XR_RELAY_WIDE(WV)                                                                                             \
     do {                                                                                                              \
         const int wspan = relay_span(par, RW_OWN * WV);                                                               \
@@ -1317,8 +1329,10 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
     } while (0)
             if (j.relay_w == 4) XR_RELAY_WIDE(4);
             else if (j.relay_w == 2) XR_RELAY_WIDE(2);
+            else
 #undef XR_RELAY_WIDE
-            else if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
+#endif
+            if (lds_walk && j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
             else if (lds_walk) hipLaunchKernelGGL((clock_relay_kernel<false, true>), dim3(j.G), dim3(128), 0, s, a, j.relay_enq, span);
             else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);
             else hipLaunchKernelGGL((clock_relay_kernel<false, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span);

@@ -444,7 +444,9 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     XR_TRY(counters.reserve((size_t)(max_passes + 6) * 8 * sizeof(unsigned)));
     XR_HIP(hipHostMalloc((void **)&h_counters, COSTAS_CTL_WORDS * sizeof(unsigned)));
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
+#ifdef XRIT_EXPERIMENTS
     keep_spare = getenv("XRIT_KEEP_SPARE") != nullptr;
+#endif
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_serial_walk = getenv("XRIT_NO_SERIAL_WALK") != nullptr;
     cur = 0;

@@ -213,7 +213,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         int prio_least = 0, prio_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if (hipStreamCreate(&d->stream) != hipSuccess ||
-            hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, getenv("XRIT_FE_NORMAL_PRIORITY") ? 0 : prio_least) != hipSuccess ||
+            hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess ||
@@ -231,7 +231,9 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;
         d->clock.exact = cfg->clock_exact;
+#ifdef XRIT_EXPERIMENTS
         d->no_defer = getenv("XRIT_NO_DEFER") != nullptr;
+#endif
         d->clock.relay_window = cfg->clock_exact_window > 0 ? cfg->clock_exact_window : 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
@@ -278,6 +280,15 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_TRY(d->clock.reset(s));
     d->poisoned = false;
     return XRIT_OK;
+}
+
+int xrit_build_experiments(void)
+{
+#ifdef XRIT_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 void *xrit_demod_stream(xrit_demod *d) { return d ? (void *)d->stream : nullptr; }

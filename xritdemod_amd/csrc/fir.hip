@@ -233,6 +233,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     const float2 *w = tile + lane_base;
     // PAD: window index i sits at i + i/D; walk it D samples at a time
     if (MF) {
+#ifdef XRIT_EXPERIMENTS      // (make EXTRA=-DXRIT_EXPERIMENTS: not in the shipped library)
         // EXPERIMENT (round 2's review, item 7): the same sums on the matrix pipe.  A decimating FIR is a block-Toeplitz
         // product: for 16 groups of 16 consecutive outputs (rows G, columns j; output 16 G + j of the workgroup),
         //     Y[G][j] = sum_s X[G][s] * H[s][j],   X[G][s] = tile[16 DS G + s],   H[s][j] = g[s - DS j]  (0 outside the filter),
@@ -293,6 +294,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < RC; ++c) acc[c] = tile[tid * RC + c];
+#endif
     } else if (TS > 0) {
         // row 0 of g is the reversed filter, g[i] = h[TS-1-i] (zero behind it); output c takes sample i with tap
         // g[i - c].  Taps sit in scalar registers as aligned pairs and v_pk_fma_f32 broadcasts either half of a
@@ -553,7 +555,9 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     // diagnostic switches are read once, here: never on the launch path (a host that calls setenv races with getenv)
     no_static_dec = getenv("XRIT_NO_STATIC_DEC") != nullptr;
     no_static_mf = getenv("XRIT_NO_STATIC_MF") != nullptr;
+#ifdef XRIT_EXPERIMENTS
     mfma_dec = getenv("XRIT_MFMA_DEC") != nullptr;
+#endif
     T = ntaps;
     D = decim < 1 ? 1 : decim;
     // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
@@ -608,10 +612,12 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     threads = 256;
     // (XRIT_DEC_THREADS, read here, when the stage is created: the decimator's workgroup size for A/B runs -- smaller
     // workgroups hold smaller windows, and more of them fit next to the relay's walkers)
+#ifdef XRIT_EXPERIMENTS
     if (D > 1 && getenv("XRIT_DEC_THREADS")) {
         const int t = atoi(getenv("XRIT_DEC_THREADS"));
         if (t == 64 || t == 128 || t == 192 || t == 256) threads = t;
     }
+#endif
     for (;;) {
         long long ob = (long long)threads * RC;
         long long tl = (ob - 1) * D + T + (Wpad - W) + 8;
@@ -675,12 +681,15 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
                        out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
                        f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
+#ifdef XRIT_EXPERIMENTS
     if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && f.mfma_dec && f.threads == 256)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5, (RC == 3 && !PAD)>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes + (f.tile_len / 80 + 1) * 20 * 8, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
                            f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr,
                            f.mfb.as<float>());
-    else if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
+    else
+#endif
+    if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
                            f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
