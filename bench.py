@@ -176,7 +176,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         # the CPU baseline's samples, taken before the detail pass reuses the buffers
         n_cpu0 = min(n_burst, 1 << args.cpu_sample_log2)
+        # (a whole number of decimation periods: the chain drops n mod D samples per call like the reference,
+        # demodulator.cpp:137, and the steady-state leg below goes on from here through the rest of the stream)
+        n_cpu0 -= n_cpu0 % D
         host0 = bursts[0, :n_cpu0].cpu().numpy().view(np.complex64).reshape(-1)
+        # (the parity leg also looks at a steady-state burst: the rest of burst 0 and burst 1, through the oracle after the
+        # timed sample)
+        host0_rest = bursts[0, n_cpu0:].cpu().numpy().view(np.complex64).reshape(-1) if n_cpu0 < n_burst else None
+        host1 = bursts[1].cpu().numpy().view(np.complex64).reshape(-1) if (W >= 2 and nbuf >= 2 and not args.no_serial_floor) else None
         host_segs = []
         if cpu_threads > 1:
             # one segment per thread: consecutive pieces of the resident bursts (4 Mi samples each, 32 MB, so that
@@ -198,10 +205,13 @@ def main():
     def step(b):
         return dem.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
 
+    soft1 = None
     for b in range(W):
         ns = step(b)
         if b == 0:
             soft0 = soft[:ns].clone()
+        if b == 1:
+            soft1 = soft[:ns].clone()
     if W == 0:
         soft0 = None
 
@@ -212,8 +222,8 @@ def main():
 
     if not args.no_profile:
         dem.profile(2)       # events around the decimating FIR only: an event record is a queue barrier
-    # Streaming: the front end (decimator, AGC, matched filter) of burst b + 1 runs on the handle's second stream while
-    # the feedback loops of burst b iterate -- every timed step still pays one front end and one set of loops, all
+    # Streaming: the front end (decimator, AGC, matched filter) and the Costas loop of burst b + 1 run on the handle's second
+    # stream beside the relay kernels of burst b -- every timed step still pays one front end and one set of loops, all
     # inside the timed region (nothing is prefetched before the clock starts).
     prefetch = not args.no_prefetch
 
@@ -372,8 +382,9 @@ def main():
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
                    "segments": world, "bursts_reused": bool(W + K > nbuf),
-                   "clock_recovery": "cfg.clock_exact = 0 (default): %d hand-off passes, %d relay passes of %d segments on the last step" % (int(st.clock_passes), int(st.clock_relay_passes), int(st.clock_relay_segments)),
-                   "front_end_of_next_burst_overlaps_loops": bool(prefetch), "costas_chain_len": args.costas_chain or 256,
+                   "clock_recovery": "cfg.clock_exact = 0 (default): no hand-off passes; %d relay passes over %d exactly walked segments, the first from the timing guess (last step: %d hand-off passes)" % (int(st.clock_relay_passes), int(st.clock_relay_segments), int(st.clock_passes)),
+                   "front_end_of_next_burst_overlaps_loops": bool(prefetch),
+                   "next_burst_under_the_relay": "decimator, AGC, matched filter and Costas loop" if prefetch else "nothing", "costas_chain_len": args.costas_chain or 256,
                    "clock_chain_syms": args.clock_chain or "auto: whole generations of resident waves (112 at C2), 64..256"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
         "algorithmic_bytes_per_sample": round(b_alg, 4),
@@ -391,8 +402,8 @@ def main():
 
     # ---- two other configurations beside it, the same stream from its first burst through a second handle each, timed over
     # their own steady-state steps: cfg.clock_exact = 1 (csrc/clock_relay.h: relayed to closure -- bit for bit the serial
-    # trajectory) and -2 (hand-off passes only).  Not `value`: the headline is the default configuration (two hand-off
-    # passes and three relay passes).
+    # trajectory) and -2 (hand-off passes only).  Not `value`: the headline is the default configuration (no hand-off
+    # passes, three relay passes from the timing guess).
     soft0_alt = {}
     if rank == 0 and world == 1 and not args.no_exact:
         def alt_leg(key, clock_exact, what, steps):
@@ -437,7 +448,7 @@ def main():
     # bounded sample of the same workload, one thread like the reference's DSP thread.
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle
-        n_cpu = min(n_burst, 1 << args.cpu_sample_log2)
+        n_cpu = len(host0)
         host = host0
         od = oracle.Demod(oracle.config(mode, fs_in, D))
         c0 = time.perf_counter()
@@ -445,8 +456,8 @@ def main():
         c1 = time.perf_counter()
         out["cpu_baseline"] = {"value": round(n_cpu / (c1 - c0) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                "kind": "port",
-                               "sample": "first %d Mi samples of burst 0, oracle/xrit_oracle.c single thread "
-                                         "(gcc -O3 -mavx2 -ffp-contract=off)" % (n_cpu >> 20),
+                               "sample": "first %d samples (%.0f Mi) of burst 0, oracle/xrit_oracle.c single thread "
+                                         "(gcc -O3 -mavx2 -ffp-contract=off)" % (n_cpu, n_cpu / 2.0 ** 20),
                                "seconds": round(c1 - c0, 3)}
         if cpu_threads > 1:
             # N independent segments on N threads (the C call releases the GIL): what the node's cores do together
@@ -502,14 +513,31 @@ def main():
                     ex["words_differing_from_serial_gpu"] = int((ge[:min(len(ge), len(ser))].view(np.uint32) !=
                                                                  ser[:min(len(ge), len(ser))].view(np.uint32)).sum())
                     out["parity_vs_oracle"][key] = ex
+                # a steady-state burst: burst 1 of the same stream (the oracle and the serial device chain go on from where the
+                # samples above ended: the rest of burst 0, then burst 1)
+                steady = None
+                if host1 is not None and soft1 is not None:
+                    if host0_rest is not None:
+                        od.process(host0_rest)
+                        sd.process(host0_rest)
+                    so1, ser1 = od.process(host1), sd.process(host1)
+                    g1 = soft1.cpu().numpy()
+                    if len(g1) == len(so1) == len(ser1):
+                        steady = {"burst": 1, **compare(g1, so1), "serial_gpu_rms": compare(ser1, so1)["rms"],
+                                  "vs_serial_gpu_rms": compare(g1, ser1)["rms"]}
+                    else:
+                        steady = {"burst": 1, "symbol_count": [len(g1), len(so1), len(ser1)]}
+                    out["parity_vs_oracle"]["steady_state"] = steady
                 out["parity_vs_oracle"]["target_rms"] = 1e-4
                 out["parity_vs_oracle"]["target_met"] = {
-                    "default (value)": bool(out["parity_vs_oracle"]["rms"] <= 1e-4),
-                    **{k: bool(out["parity_vs_oracle"][k]["rms"] <= 1e-4) for k in soft0_alt if k in out["parity_vs_oracle"]},
-                    "serial_gpu (the floor)": bool(fl["rms"] <= 1e-4),
-                    "note": "measured on the first burst of the stream (cold start); on steady-state bursts the serial "
-                            "trajectory itself is 1.08e-4 from the CPU chain and the default 1.13e-4 "
-                            "(profiles/r3_parity_vs_throughput.json)"}
+                    "default (value), steady-state burst": None if not steady or "rms" not in steady else bool(steady["rms"] <= 1e-4),
+                    "serial_gpu (the floor), steady-state burst": None if not steady or "rms" not in steady else bool(steady["serial_gpu_rms"] <= 1e-4),
+                    "default (value), burst 0 (cold start)": bool(out["parity_vs_oracle"]["rms"] <= 1e-4),
+                    **{k + ", burst 0": bool(out["parity_vs_oracle"][k]["rms"] <= 1e-4) for k in soft0_alt if k in out["parity_vs_oracle"]},
+                    "serial_gpu (the floor), burst 0": bool(fl["rms"] <= 1e-4),
+                    "note": "the serial trajectory (cfg.clock_serial, bit-identical to the CPU recurrence on identical input) is the "
+                            "floor of any float32 M&M on this chain's Costas output, which differs from the oracle's by 1e-6; where "
+                            "the floor itself is above 1e-4 no configuration can meet the target (DESIGN.md section 6)"}
                 out["parity_vs_oracle"]["floor_note"] = ("serial_gpu_rms is the measured floor of a hand-off-free float32 "
                                                          "M&M on this chain's Costas output; the time-tiled evaluation "
                                                          "adds the rest")

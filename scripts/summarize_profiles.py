@@ -34,6 +34,7 @@ if os.path.exists(os.path.join(src, "bench_c2_noprefetch.json")):
 copy(os.path.join("stats", "c2_kernel_stats.csv"), f"{tag}_c2_kernel_stats.csv")
 copy(os.path.join("stats_np", "c2_kernel_stats.csv"), f"{tag}_c2_kernel_stats_noprefetch.csv")
 copy("timeline.txt", f"{tag}_c2_timeline.txt")
+copy("timeline_streamed.txt", f"{tag}_c2_timeline_streamed.txt")
 copy("small_calls.txt", f"{tag}_small_calls.txt")
 copy("parity_floor_c2.json", f"{tag}_parity_floor_c2.json")
 copy("parity_floor_chain_sweep.json", f"{tag}_parity_floor_chain_sweep.json")
@@ -69,9 +70,17 @@ if os.path.exists(fpath) and os.path.exists(wpath):
         top = max(v for _, v in vals)
         return [v for _, v in vals if v > 0.05 * top] if top > 0 else []
 
+    STREAMED = not tag.startswith(("r1", "r2", "r3"))      # round 4 on: the counter passes run the headline's command
+    WARM, STEPS = 3, 3
+
     def last_burst(acc):
-        """sum over the dispatches of the run's LAST burst (steady state; the first one, cold-started, runs more passes)"""
+        """rounds 1-3 (one burst at a time): sum over the dispatches of the run's LAST burst (steady state; the first one,
+        cold-started, runs more passes).  Round 4 on (bursts streamed, three timed steps behind three warm-up steps): everything
+        dispatched from the first timed step's decimator on -- bench.py registers it when the clock starts --, per step."""
         starts = sorted(d for k, vals in acc.items() if k.startswith("fir_decim_kernel<3, false, 0, 0") for d, _ in vals)
+        if STREAMED:
+            lo = starts[WARM] if len(starts) > WARM else 0
+            return sum(v for k, vals in acc.items() if "synth_kernel" not in k and "read_bw" not in k for d, v in vals if d >= lo) / STEPS
         lo = starts[-1] if starts else 0
         return sum(v for k, vals in acc.items() if "synth_kernel" not in k and "read_bw" not in k for d, v in vals if d >= lo)
 
@@ -82,7 +91,8 @@ if os.path.exists(fpath) and os.path.exists(wpath):
     tot_f, tot_w = last_burst(f), last_burst(w)
     with open(os.path.join(dst, f"{tag}_c2_pmc_hbm.csv"), "w") as fo:
         fo.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (separate passes), "
-                 "bench.py --steps 1 --warmup 3 --no-prefetch, C2 burst (256 Mi samples): four bursts per run\n")
+                 + ("bench.py --steps 3 --warmup 3 (the headline's command: bursts streamed), C2 burst (256 Mi samples)\n" if STREAMED else
+                    "bench.py --steps 1 --warmup 3 --no-prefetch, C2 burst (256 Mi samples): four bursts per run\n"))
         fo.write("# FETCH_SIZE/WRITE_SIZE are in KiB per dispatch, averaged over the dispatches of the run that did work (the "
                  "passes a batch enqueues beyond the last needed one return at once and are left out).\n")
         fo.write("# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the bytes of a coalesced "
@@ -108,7 +118,8 @@ if os.path.exists(fpath) and os.path.exists(wpath):
     # the whole step: every kernel of the chain (the synthetic generator is not part of it) over the LAST burst of the
     # run, i.e. the steady state (the first burst is cold-started and runs more hand-off passes)
     out["_step"] = {"burst_log2": 28, "hbm_bytes_per_step": round((2 * tot_f + tot_w) * 1024),
-                    "source": src_note + ", all kernels of the chain over the run's last (steady-state) burst"}
+                    "source": src_note + (", all kernels of the chain over the run's three timed (steady-state, streamed) steps, per step"
+                                          if STREAMED else ", all kernels of the chain over the run's last (steady-state) burst")}
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 
 b = json.load(open(os.path.join(dst, f"{tag}_bench_c2.json")))
