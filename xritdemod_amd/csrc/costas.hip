@@ -446,6 +446,8 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
 #ifdef XRIT_EXPERIMENTS
     keep_spare = getenv("XRIT_KEEP_SPARE") != nullptr;
+    // (scripts/r4_floor_vs_frontend.py: the hand-off's stop rule tightened or loosened by a factor)
+    if (const char *e = getenv("XRIT_COSTAS_TOL")) { const float k = (float)atof(e); if (k > 0) { tol_phase *= k; tol_freq *= k; } }
 #endif
     trace_env = getenv("XRIT_TRACE") != nullptr;
     no_serial_walk = getenv("XRIT_NO_SERIAL_WALK") != nullptr;

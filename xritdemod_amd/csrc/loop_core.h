@@ -101,7 +101,10 @@ XR_HD CostasGains costas_gains(float loop_bw)
 // sin and cos of a loop phase (|x| stays within a few multiples of pi).
 XR_HD void loop_sincos(float x, float &s, float &c)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(XRIT_ACCURATE_SINCOS)
+    // (make EXTRA=-DXRIT_ACCURATE_SINCOS, scripts/r4_floor_vs_frontend.py: the math library's sincosf, ~1 ulp, ~25 instructions)
+    ::sincosf(x, &s, &c);
+#elif defined(__HIP_DEVICE_COMPILE__)
     // v_sin_f32 / v_cos_f32 take turns (|t| <= 256; here |x| <= 2 pi + 1.5).  Quarter rate, but three
     // instructions against ~25 for a Cody-Waite reduction with two polynomials -- the Costas passes are VALU
     // bound and this call was a third of their per-sample work (measured: -16 % per pass).  Absolute error
