@@ -1286,6 +1286,10 @@ def test_group_api_over_rccl_with_one_rank(xa, oracle_mod):
     # independent segments: the rank's chain as a plain handle
     k2 = g.chain_process_device(xt.data_ptr(), n, soft.data_ptr(), cap)
     assert k2 > 0
+    # ONE copy of RCCL in the process: the library does not link it, it takes the copy the host has loaded (torch's,
+    # in this test process) and loads /opt/rocm's only when there is none
+    copies = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+    assert len(copies) == 1, copies
 
 
 def test_agc_inside_the_matched_filter_fill_is_the_same_chain(xa, oracle_mod):

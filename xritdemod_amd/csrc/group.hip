@@ -17,7 +17,9 @@
 // device-to-device copies): the latter is what a single-GPU box can test.
 #include "kernels.h"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is looked up at run time (RcclApi below)
+
+#include <dlfcn.h>
 
 #include <condition_variable>
 #include <mutex>
@@ -42,11 +44,58 @@ struct Transport {
     virtual void abort() {}
 };
 
+// ONE copy of RCCL per process.  A host that has brought its own (PyTorch ships librccl.so.1 inside its wheel and loads it
+// for torch.distributed) must not end up with /opt/rocm's beside it -- two copies do not share communicators, device
+// state or the bootstrap network --, so libxritdemod_amd.so does not link RCCL: the first group call takes the copy that is
+// already in the process (dlopen RTLD_NOLOAD by soname) and loads /opt/rocm's only when there is none.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string why;
+    RcclApi()
+    {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already has
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        bool all = true;
+#define XR_SYM(F) do { F = reinterpret_cast<decltype(F)>(dlsym(h, "nccl" #F)); if (!F) { all = false; why = "RCCL lacks nccl" #F; } } while (0)
+        XR_SYM(GetUniqueId); XR_SYM(CommInitRank); XR_SYM(CommInitAll); XR_SYM(CommDestroy); XR_SYM(CommAbort);
+        XR_SYM(GroupStart); XR_SYM(GroupEnd); XR_SYM(Send); XR_SYM(Recv); XR_SYM(AllGather); XR_SYM(AllReduce);
+        XR_SYM(GetErrorString);
+#undef XR_SYM
+        ok = all;
+    }
+};
+static RcclApi &rccl()
+{
+    static RcclApi api;
+    return api;
+}
+#define XR_RCCL_READY()                                                                 \
+    do {                                                                                \
+        if (!rccl().ok) { set_error("%s", rccl().why.c_str()); return XRIT_E_HIP; }     \
+    } while (0)
+
 #define XR_NCCL(expr)                                                                   \
     do {                                                                                \
+        XR_RCCL_READY();                                                                \
         ncclResult_t _r = (expr);                                                       \
         if (_r != ncclSuccess) {                                                        \
-            set_error("%s failed: %s", #expr, ncclGetErrorString(_r));                  \
+            set_error("%s failed: %s", #expr, rccl().GetErrorString(_r));                  \
             return XRIT_E_HIP;                                                          \
         }                                                                               \
     } while (0)
@@ -58,21 +107,21 @@ struct RcclTransport : Transport {
     DevBuf scratch;
     ~RcclTransport() override
     {
-        if (comm && owns) (void)ncclCommDestroy(comm);
+        if (comm && owns && rccl().ok) (void)rccl().CommDestroy(comm);
         scratch.release();
     }
     void abort() override
     {
-        if (comm) (void)ncclCommAbort(comm);      // pending and future operations of every rank on it return an error
+        if (comm && rccl().ok) (void)rccl().CommAbort(comm);      // pending and future operations of every rank on it return an error
         comm = nullptr;
     }
     int exchange(const void *send, size_t send_bytes, int to, void *recv, size_t recv_bytes, int from,
                  hipStream_t s) override
     {
-        XR_NCCL(ncclGroupStart());
-        if (to >= 0 && send_bytes) XR_NCCL(ncclSend(send, send_bytes, ncclChar, to, comm, s));
-        if (from >= 0 && recv_bytes) XR_NCCL(ncclRecv(recv, recv_bytes, ncclChar, from, comm, s));
-        XR_NCCL(ncclGroupEnd());
+        XR_NCCL(rccl().GroupStart());
+        if (to >= 0 && send_bytes) XR_NCCL(rccl().Send(send, send_bytes, ncclChar, to, comm, s));
+        if (from >= 0 && recv_bytes) XR_NCCL(rccl().Recv(recv, recv_bytes, ncclChar, from, comm, s));
+        XR_NCCL(rccl().GroupEnd());
         return XRIT_OK;
     }
     int allgather2(const long long mine[2], long long *all, hipStream_t s) override
@@ -80,7 +129,7 @@ struct RcclTransport : Transport {
         XR_TRY(scratch.reserve((size_t)(2 * world + 2) * sizeof(long long)));
         long long *d = scratch.as<long long>();
         XR_HIP(hipMemcpyAsync(d, mine, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
-        XR_NCCL(ncclAllGather(d, d + 2, 2, ncclInt64, comm, s));
+        XR_NCCL(rccl().AllGather(d, d + 2, 2, ncclInt64, comm, s));
         XR_HIP(hipMemcpyAsync(all, d + 2, (size_t)2 * world * sizeof(long long), hipMemcpyDeviceToHost, s));
         XR_HIP(hipStreamSynchronize(s));
         return XRIT_OK;
@@ -90,7 +139,7 @@ struct RcclTransport : Transport {
         XR_TRY(scratch.reserve((size_t)(2 * world + 2) * sizeof(long long)));
         double *d = scratch.as<double>();
         XR_HIP(hipMemcpyAsync(d, v, sizeof(double), hipMemcpyHostToDevice, s));
-        XR_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, comm, s));
+        XR_NCCL(rccl().AllReduce(d, d, 1, ncclDouble, ncclMax, comm, s));
         XR_HIP(hipMemcpyAsync(v, d, sizeof(double), hipMemcpyDeviceToHost, s));
         XR_HIP(hipStreamSynchronize(s));
         return XRIT_OK;
@@ -273,7 +322,7 @@ int xrit_group_unique_id(void *id128)
     if (!id128) { set_error("null argument"); return XRIT_E_INVALID; }
     static_assert(sizeof(ncclUniqueId) <= XRIT_GROUP_ID_BYTES, "ncclUniqueId fits the ABI's id buffer");
     ncclUniqueId id;
-    XR_NCCL(ncclGetUniqueId(&id));
+    XR_NCCL(rccl().GetUniqueId(&id));
     memset(id128, 0, XRIT_GROUP_ID_BYTES);
     memcpy(id128, &id, sizeof id);
     return XRIT_OK;
@@ -283,6 +332,7 @@ int xrit_group_create(const xrit_demod_config *cfg, int rank, int world, const v
 {
     if (!cfg || !out || !id128 || world < 1 || rank < 0 || rank >= world) { set_error("bad argument"); return XRIT_E_INVALID; }
     *out = nullptr;
+    XR_RCCL_READY();
     xrit_group *g = new (std::nothrow) xrit_group();
     if (!g) return XRIT_E_NOMEM;
     g->rank = rank;
@@ -299,8 +349,8 @@ int xrit_group_create(const xrit_demod_config *cfg, int rank, int world, const v
             memcpy(&id, id128, sizeof id);
             if (hipSetDevice(g->device) != hipSuccess) { set_error("hipSetDevice failed"); rc = XRIT_E_HIP; }
             else {
-                ncclResult_t r = ncclCommInitRank(&t->comm, world, id, rank);
-                if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); rc = XRIT_E_HIP; }
+                ncclResult_t r = rccl().CommInitRank(&t->comm, world, id, rank);
+                if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(r)); rc = XRIT_E_HIP; }
             }
         }
     }
@@ -314,7 +364,7 @@ int xrit_group_create_all(const xrit_demod_config *cfg, const int *devices, int 
     if (!cfg || !out || !devices || world < 1) { set_error("bad argument"); return XRIT_E_INVALID; }
     for (int i = 0; i < world; ++i) out[i] = nullptr;
     std::vector<ncclComm_t> comms((size_t)world);
-    XR_NCCL(ncclCommInitAll(comms.data(), world, devices));
+    XR_NCCL(rccl().CommInitAll(comms.data(), world, devices));
     int rc = XRIT_OK;
     for (int i = 0; i < world && rc == XRIT_OK; ++i) {
         xrit_group *g = new (std::nothrow) xrit_group();
@@ -335,7 +385,7 @@ int xrit_group_create_all(const xrit_demod_config *cfg, const int *devices, int 
     }
     if (rc != XRIT_OK) {
         for (int i = 0; i < world; ++i) { if (out[i]) xrit_group_destroy(out[i]); out[i] = nullptr; }
-        for (auto c : comms) if (c) (void)ncclCommDestroy(c);
+        for (auto c : comms) if (c && rccl().ok) (void)rccl().CommDestroy(c);
     }
     return rc;
 }
