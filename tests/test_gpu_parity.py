@@ -320,9 +320,10 @@ def test_soft_symbol_target_of_1e_4(xa, oracle_mod, case):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_default_configuration_is_within_reach_of_the_floor(xa, oracle_mod, case):
-    """The default configuration (cfg.clock_exact = 0, round 4): NO hand-off passes -- the relay's first pass walks every
-    segment from the timing guess, the later ones from the end states of the segments in front (two passes where a segment
-    holds 49 k symbols or more, three from 24.6 k, else four).  The symbols are then within 20 % of the floor the serial
+    """The default configuration (cfg.clock_exact = 0, round 4): bursts that fill the chip (6 M symbols or more) have NO hand-off
+    passes -- the relay's first pass walks every segment from the timing guess, the later ones from the end states of the
+    segments in front (two passes where a segment holds 49 k symbols or more, three from 24.6 k); calls of up to 74 k symbols are
+    ONE exact walk; calls in between -- the sizes of this test -- keep round 3's two hand-off passes and three relay passes.  The symbols are then within 20 % of the floor the serial
     trajectory itself has against the oracle, hard decisions equal, and never further from the oracle than the hand-off
     passes alone (cfg.clock_exact = -1).  cfg.clock_exact = 3 -- rounds 3's default: two hand-off passes, then three relay
     passes -- is held to the same bound."""
@@ -332,7 +333,9 @@ def test_default_configuration_is_within_reach_of_the_floor(xa, oracle_mod, case
     dflt = xa.Demodulator(xa.Demodulator.config(mode, fs, D))
     got = dflt.process(x)
     st = dflt.stats()
-    assert st.clock_passes == 0 and 1 <= st.clock_relay_passes <= 4, (st.clock_passes, st.clock_relay_passes)
+    # (calls of 74 k .. 6 M symbols -- these -- keep two hand-off passes in front of the relay, more on a cold start: few
+    # walkers, whose latency counts; bursts that fill the chip and calls of one segment are relayed from the timing guess)
+    assert 1 <= st.clock_relay_passes <= 4, (st.clock_passes, st.clock_relay_passes)
     d3 = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_exact=3))
     g3 = d3.process(x)
     assert d3.stats().clock_passes >= 2 and 1 <= d3.stats().clock_relay_passes <= 3
@@ -345,6 +348,35 @@ def test_default_configuration_is_within_reach_of_the_floor(xa, oracle_mod, case
         r = rms(g - want)
         assert np.array_equal(np.sign(g[big]), np.sign(want[big]))
         assert r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
+
+
+def test_bursts_that_fill_the_chip_are_relayed_from_the_timing_guess(xa, oracle_mod):
+    """6 M symbols or more in one call (here 26 M samples of LRIT at the circuit rate, two consecutive calls): the default
+    configuration runs NO hand-off pass -- every segment but the first is walked from the timing guess, then from the end
+    states of the segments in front, three passes over segments of 24.6 k symbols.  Count and hard decisions are the serial
+    trajectory's, the soft symbols within the default's usual distance of it and within 20 % of its floor against the oracle."""
+    import torch
+    from xritdemod_amd import _capi
+    n, fs = 26000000, 1.25e6
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    sp = _capi.synth_params(fs_in=fs)
+    dflt = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
+    ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1, clock_serial=1))
+    ref = oracle_mod.Demod(oracle_mod.config("lrit", fs, 1))
+    for b in range(2):
+        _capi.synth_generate_device(sp, b * n, n, buf.data_ptr(), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        x = buf.cpu().numpy().view(np.complex64).reshape(-1)
+        got, flo, want = dflt.process(x), ser.process(x), ref.process(x)
+        st = dflt.stats()
+        assert st.clock_passes == 0 and st.clock_relay_passes == 3 and 200 <= st.clock_relay_segments <= 260, \
+            (st.clock_passes, st.clock_relay_passes, st.clock_relay_segments)
+        assert len(got) == len(flo) == len(want) > 6000000
+        big = np.abs(want) > 1e-3
+        assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
+        r, floor, rs = rms(got - want), rms(flo - want), rms(got - flo)
+        assert rs <= 1.0e-4 and r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4, (b, r, floor, rs)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -469,10 +501,11 @@ def test_default_runs_two_relay_passes_on_long_segments(xa):
     assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
     r = float(np.sqrt(np.mean((got - ser) ** 2))), float(np.sqrt(np.mean((fast - ser) ** 2)))
     assert r[0] <= 1.0e-4 and r[0] < 0.6 * r[1], r
-    # left to itself the library cuts the call's 2.35 M symbols into some 96 segments of 24.6 k: three passes
+    # left to itself the library cuts the call's 2.35 M symbols into some 145 segments of 16 k behind two hand-off passes:
+    # three relay passes
     d3 = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
     d3.process(x)
-    assert d3.stats().clock_relay_passes == 3 and 90 <= d3.stats().clock_relay_segments <= 100, d3.stats().clock_relay_segments
+    assert d3.stats().clock_relay_passes == 3 and 140 <= d3.stats().clock_relay_segments <= 150, d3.stats().clock_relay_segments
 
 
 def test_exact_closure_edge_cases(xa):

@@ -1606,7 +1606,12 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // walk from a closed hand-off, and the second pass starts from them.  Measured at C2 (steady-state bursts,
     // profiles/r4_handoff_vs_guess.json): guess + 2 passes over 256 segments 5.3e-5 rms from the serial trajectory, where two
     // hand-off passes + 3 relay passes over 766 segments had 6.4e-5 -- for two sweeps of the stream instead of five.
-    j.no_handoff = j.relay && (relay_no_handoff >= 0 ? relay_no_handoff != 0 : exact == 0);
+    // (... where the call fills the chip with such segments, or is one segment: in between -- 74 k to 6 M symbols: C5's bursts,
+    // calls of 2^19 .. 2^22 samples -- the walkers are few and it is their latency that counts: two hand-off passes, which
+    // cost such a call 0.1 ms, start them close enough for three passes over segments of 16 k symbols)
+    const long long all_syms = (long long)K * NS;
+    j.no_handoff = j.relay && (relay_no_handoff >= 0 ? relay_no_handoff != 0
+                                                     : exact == 0 && (all_syms <= 3LL * (auto_long_seg / 2) || all_syms >= auto_guess_min));
     if (j.relay) XR_TRY(relay_plan());
     if (j.no_handoff && exact == 0) {
         // passes for the default's parity by segment length (measured, same file: 16.5 k symbols per segment: 3 passes 9.6e-5,

@@ -255,6 +255,7 @@ struct ClockStage {
     // 12 dB, 1.1e-3 at 6 dB, 4.3e-3 at 3 dB (XRIT_AUTO_PASSES=n: another count; 0: the hand-off passes' result as in
     // round 2 unless they stall)
     int auto_passes = 3;
+    long long auto_guess_min = 6000000;   // symbols from which the default configuration relays straight from the timing guess
     int auto_long_seg = 49152;  // symbols per segment from which two relay passes are the default's budget (ClockStage::begin)
     float auto_shift = 6e-4f;
     float auto_snr = 10.0f;     // ... and to closure outright when the first pass's soft symbols show 2 Es/N0 below this (7 dB)
