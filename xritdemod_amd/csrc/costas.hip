@@ -23,30 +23,71 @@ namespace xrit {
 
 constexpr int COSTAS_HEAD = 64;   // chains covered by the sequential coarse model
 constexpr int COSTAS_CTL_WORDS = 16;   // control words in front of the per-pass counter slots
+constexpr int COSTAS_CTL_MODEL = 9;    // control word: this call's guesses went through the model step
 
 // ---------------------------------------------------------------- statistics
-// stat[k] = sum z^2 over chain k (squaring removes the BPSK modulation)
-__global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restrict__ z, float2 *__restrict__ stat,
-                                                          long long n, int L, int K)
+// sub[r] = sum z^2 over the run of COSTAS_SUB samples [8 r, 8 r + 8) (squaring removes the BPSK modulation).  In the
+// chain the matched filter's epilogue leaves it (fir.hip); a stand-alone stage computes it here.
+constexpr int COSTAS_SUB = 8;
+
+__global__ void __launch_bounds__(256) costas_sub_kernel(const float2 *__restrict__ z, float2 *__restrict__ sub,
+                                                         long long n, long long runs)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long k = (long long)blockIdx.x * 4 + wave;
-    if (k >= K) return;
-    const long long base = k * L;
+    // eight lanes per run, one sample each (a wave reads 512 consecutive bytes), three row shifts add the run up
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
     float sr = 0.f, si = 0.f;
-    for (int i = lane; i < L; i += 64) {
-        long long j = base + i;
-        if (j < n) {
-            float2 v = z[j];
-            sr += v.x * v.x - v.y * v.y;
-            si += 2.0f * v.x * v.y;
+    if (j < n) {
+        const float2 v = z[j];
+        sr = v.x * v.x - v.y * v.y;
+        si = 2.0f * v.x * v.y;
+    }
+    sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x111, 0xf, 0xf, true));      // row_shr:1
+    si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x111, 0xf, 0xf, true));
+    sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x112, 0xf, 0xf, true));      // row_shr:2
+    si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x112, 0xf, 0xf, true));
+    sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x114, 0xf, 0xf, true));      // row_shr:4
+    si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x114, 0xf, 0xf, true));
+    if ((threadIdx.x & 7) == 7 && (j >> 3) < runs) sub[j >> 3] = make_float2(sr, si);
+}
+
+// stat[k] = sum z^2 over chain k, from the runs.  RPC32 (chains of 256 samples = 32 runs): a lane takes two runs
+// (one 16-byte load, a wave reads 1 KB in one piece), a row of 16 lanes holds a chain, four row shifts add it up in a
+// fixed order.  Otherwise a thread adds one chain's runs in order.  Deterministic either way.
+template <bool RPC32>
+__global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restrict__ sub, float2 *__restrict__ stat,
+                                                          long long runs, int rpc, int K)
+{
+    if (RPC32) {
+        const long long q = (long long)blockIdx.x * 256 + threadIdx.x;     // pair of runs 2 q, 2 q + 1
+        float sr = 0.f, si = 0.f;
+        if (2 * q + 1 < runs) {
+            const float4 v = reinterpret_cast<const float4 *>(sub)[q];
+            sr = v.x + v.z;
+            si = v.y + v.w;
+        } else if (2 * q < runs) {
+            const float2 v = sub[2 * q];
+            sr = v.x;
+            si = v.y;
         }
+#define XR_ROW_ADD(CTRL)                                                                                          \
+        sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), CTRL, 0xf, 0xf, true));           \
+        si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), CTRL, 0xf, 0xf, true));
+        XR_ROW_ADD(0x111) XR_ROW_ADD(0x112) XR_ROW_ADD(0x114) XR_ROW_ADD(0x118)      // row_shr:1, 2, 4, 8
+#undef XR_ROW_ADD
+        const long long k = q >> 4;
+        if ((threadIdx.x & 15) == 15 && k < K) stat[k] = make_float2(sr, si);
+        return;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        sr += __shfl_down(sr, off, 64);
-        si += __shfl_down(si, off, 64);
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const long long r0 = k * rpc;
+    const int cnt = (int)min((long long)rpc, runs - r0);
+    float sr = 0.f, si = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const float2 v = sub[r0 + i];
+        sr += v.x; si += v.y;
     }
-    if (lane == 0) stat[k] = make_float2(sr, si);
+    stat[k] = make_float2(sr, si);
 }
 
 // -------------------------------------------------------------------- guess
@@ -145,6 +186,8 @@ struct CostasPolicy {
     float trust_p, trust_f, tol_p, tol_f;
     float accept, gate;      // stop test: accept when max residual <= accept; trust gate needed while > gate
     const int *expansive;    // ctl[7]: some chain of this call saw the loop expansive
+    int model = 0;           // this solve follows the pass over the sub-block model (costas_model_pass_kernel), not a pass over the samples
+    float model_accept = 0.f;   // first pass over the samples behind a model step: accept on prediction when no residual exceeds this
     // In lock an error in a chain's start decays along the chain and the hand-off tolerance (1e-5 rad) is what is
     // left of it in the output.  While the loop pulls in it is expansive for stretches (d phase / d start up to 2
     // per chain over several chains in a row, more through a cycle slip): what one call leaves within tolerance
@@ -212,6 +255,12 @@ struct CostasPolicy {
     __device__ void decide(int *ctl) const
     {
         const unsigned changed = newton_cnt_load(cnt + 0), open_ = newton_cnt_load(cnt + 1), mr = newton_cnt_load(cnt + 2);
+        if (model) {
+            // the step on the model refines the guesses; it is no pass of the loop and decides nothing
+            ctl[COSTAS_CTL_MODEL] = 1;
+            ctl[5] = __uint_as_float(mr) > gate ? 1 : 0;
+            return;
+        }
         ctl[1] += 1;
         ctl[2] = (int)open_;
         const float max_r = __uint_as_float(mr);
@@ -223,6 +272,16 @@ struct CostasPolicy {
         // (max_r comes in units of the scaled tolerance: update() multiplies by 1 / scale())
         if (changed == 0 || max_r <= accept) { ctl[0] = 1; ctl[2] = 0; }
         else if (r_prev > 0.0f && max_r < 0.25f * r_prev && 4.0f * max_r * (max_r / r_prev) * (max_r / r_prev) <= accept) {
+            ctl[0] = 1;
+            ctl[6] = 1;
+        }
+        // The first pass behind a model step has no earlier pass to take C from.  Its residuals measure the model's error
+        // (4e-4 rad rms, 2..3e-3 at worst over a burst's 2e5 chains at C2); the update this solve applied leaves C r^2
+        // with C ~ 0.15: 1e-6.  Up to model_accept the final pass runs right away -- and is verified like any
+        // hand-off accepted on prediction.
+        // Only on a tracking loop: the call before closed in the minimum number of passes (model_accept is 0 otherwise) and no
+        // chain of this pass saw the loop expansive.
+        else if (ctl[COSTAS_CTL_MODEL] && ctl[1] == 1 && !*expansive && max_r <= model_accept) {
             ctl[0] = 1;
             ctl[6] = 1;
         }
@@ -411,6 +470,78 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
 }
 
 
+// ------------------------------------------------------------------ model step
+// The guesses above are block averages (1/2 arg sum z^2 over 256 samples): 1.4e-2..2.2e-2 rad rms away from the loop's
+// phase, which answers the noise with its own second-order response -- the first Newton step over the samples then
+// lands at 3e-5 rad and a second pass has to follow.  The loop's response is cheap to model: over a run of R = 8
+// samples the phase moves little, so the run's summed detector is 1/2 Im(sub[r] e^{-2j phi_mid}) and
+//      f += beta e,   phi += R f + (alpha + beta (R + 1) / 2) e
+// (the R per-sample updates with e spread evenly).  That recurrence, run serially over the whole stream, stays within
+// 4e-4 rad rms of the loop (scripts/costas_model.py; the error halves with R), on an eighth of a sweep.  Here it is
+// run the way the loop itself is: one lane per chain from the guessed start, with its tangent, and ONE Newton step
+// (the same solve) corrects all starts -- they come out at the model's floor, 35 x closer than the block averages, the
+// first pass over the samples lands far inside the hand-off tolerance, and the final pass follows it directly
+// (CostasPolicy::decide, verified by costas_verify_kernel as every hand-off accepted on prediction is).
+__global__ void __launch_bounds__(64) costas_model_pass_kernel(const float2 *__restrict__ sub, const float2 *__restrict__ S,
+                                                               float2 *__restrict__ E, float4 *__restrict__ J, int rpc, int K,
+                                                               long long runs, CostasGains g, CostasPolicy pol,
+                                                               AffMap *__restrict__ aggs)
+{
+    // the wave's 64 chains x rpc runs are one contiguous piece of sub[]: loaded 16 bytes per lane (1 KB per wave
+    // instruction) into rows of rpc + 1 pairs, so that HBM sees whole lines while each lane walks its own row
+    extern __shared__ float2 rows[];
+    const int lane = threadIdx.x;
+    const int kbase = blockIdx.x * 64;
+    const int k = kbase + lane;
+    const int stride = rpc + 1;
+    {
+        const long long r0 = (long long)kbase * rpc;               // first run of the wave (even: rpc is)
+        const int pairs = 32 * rpc;                                 // 64 chains x rpc / 2
+        const float4 *q = reinterpret_cast<const float4 *>(sub + r0);
+        const long long last = (runs - 1 - r0) >> 1;                // last pair that lies inside sub[] (buffer: 2 runs of slack)
+        for (int i = lane; i < pairs; i += 64) {
+            const float4 v = q[i <= last ? i : (last > 0 ? last : 0)];
+            const int r = 2 * i, row = r / rpc, col = r - row * rpc;
+            rows[row * stride + col] = make_float2(v.x, v.y);
+            rows[row * stride + col + 1] = make_float2(v.z, v.w);
+        }
+    }
+    __syncthreads();
+    constexpr float R = (float)COSTAS_SUB, H = 0.5f * (COSTAS_SUB - 1);
+    const float ka = g.alpha + g.beta * (0.5f * (COSTAS_SUB + 1));
+    AffMap e = aff_identity();
+    if (k < K - 1) {        // whole chains only: the last one hands nothing over
+        const float2 s = S[k];
+        float p = s.x, f = s.y;
+        CostasTan t{1.f, 0.f, 0.f, 1.f};
+        const float2 *q = rows + lane * stride;
+        for (int b = 0; b < rpc; ++b) {
+            const float2 c = q[b];
+            const float pm = p + H * f;
+            float sn, cs;
+            loop_sincos(-2.0f * pm, sn, cs);
+            const float wr = c.x * cs - c.y * sn, wi = c.x * sn + c.y * cs;
+            const float err = 0.5f * wi, ed = -wr;          // d err / d phi_mid
+            const float dp = ed * (t.pp + H * t.fp), df = ed * (t.pf + H * t.ff);
+            const float npp = t.pp + R * t.fp + ka * dp, npf = t.pf + R * t.ff + ka * df;
+            t.fp += g.beta * dp;
+            t.ff += g.beta * df;
+            t.pp = npp;
+            t.pf = npf;
+            p = p + R * f + ka * err;
+            f = f + g.beta * err;
+        }
+        CostasPolicy::Elem el;
+        el.e = make_float2(p, f);
+        el.j = make_float4(t.pp, t.pf, t.fp, t.ff);
+        el.s = S[k + 1];
+        E[k] = el.e;
+        J[k] = el.j;
+        e = newton_element(pol, el, false);
+    }
+    newton_wave_aggregate(e, (int)blockIdx.x, aggs);
+}
+
 // After the final pass of a hand-off that was accepted on prediction (ctl[6]): the residuals its starts leave
 // must be inside the acceptance, else the call is not closed (ctl[0] = 0) and the host goes on iterating.
 __global__ void __launch_bounds__(256) costas_verify_kernel(CostasPolicy p, long long n, int *ctl)
@@ -447,6 +578,8 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 #ifdef XRIT_EXPERIMENTS
     keep_spare = getenv("XRIT_KEEP_SPARE") != nullptr;
     // (scripts/r4_floor_vs_frontend.py: the hand-off's stop rule tightened or loosened by a factor)
+    if (const char *e = getenv("XRIT_COSTAS_MODEL")) { model_step = atoi(e) != 0; }      // A/B: 0 = block-average guesses only
+    if (const char *e = getenv("XRIT_COSTAS_MODEL_ACCEPT")) { model_accept = (float)atof(e); }
     if (const char *e = getenv("XRIT_COSTAS_TOL")) { const float k = (float)atof(e); if (k > 0) { tol_phase *= k; tol_freq *= k; } }
 #endif
     trace_env = getenv("XRIT_TRACE") != nullptr;
@@ -468,7 +601,7 @@ int CostasStage::reset(hipStream_t s)
 
 void CostasStage::release()
 {
-    state.release(); S.release(); E.release(); J.release(); stat.release(); dlin.release();
+    state.release(); S.release(); E.release(); J.release(); stat.release(); sub.release(); dlin.release();
     work.release(); flags.release(); counters.release(); wsolve.release(); rescue.release();
     if (h_counters) (void)hipHostFree(h_counters);
     h_counters = nullptr;
@@ -559,7 +692,7 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 {
     const long long nel = job.K - 1;
     CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
-                     tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7};
+                     tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7, 0, job.model_accept};
     const unsigned gridK = div_up((size_t)job.K, 64);
     // wave-aligned solve (newton.h) unless this call has gone over to the gated three-launch one
     const bool wave = !job.gated;
@@ -598,7 +731,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
                        costas_ctl(counters), CostasPolicy{}, (AffMap *)nullptr);
     if (job.K > 1) {
         CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
-                         tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7};
+                         tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7, 0, job.model_accept};
         hipLaunchKernelGGL(costas_verify_kernel, dim3(div_up((size_t)job.K - 1, 256)), dim3(256), 0, s, pol,
                            (long long)job.K - 1, costas_ctl(counters));
     }
@@ -611,7 +744,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
 // no-op once the device-side test has declared the hand-off closed), the final pass and the copy of the control
 // block.  finish() is called after the caller has synchronised the stream.
 int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof,
-                       const float2 *stat_ext, double2 *om, long long om_off, double inv_sps)
+                       const float2 *sub_ext, double2 *om, long long om_off, double inv_sps)
 {
     const bool locked = passes > 0 && passes <= 3 && unconverged == 0;      // how the previous call went
     passes = 0;
@@ -620,6 +753,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     job = Job{};
     walked = false;
     job.in = in; job.out = out; job.n = n; job.om = om; job.om_off = om_off; job.inv_sps = inv_sps;
+    job.model_accept = locked ? model_accept : 0.f;
     if (n == 0) return XRIT_OK;
     const int K = (int)((n + (size_t)L - 1) / (size_t)L);
     job.K = K;
@@ -642,14 +776,22 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     const int ctl_words = (max_passes + 4) * 8;
     if (K <= 1) XR_HIP(hipMemsetAsync(counters.p, 0, (size_t)ctl_words * sizeof(unsigned), s));
     if (K > 1) {
+        const int rpc = L / COSTAS_SUB;
+        const long long runs = (long long)((n + COSTAS_SUB - 1) / COSTAS_SUB);
+        const float2 *sb = sub_ext;       // the runs' statistic left by the producer (matched filter's epilogue) or computed here
         {
             ProfScope ps(prof, "costas_guess", s);
-            const float2 *st = stat_ext;      // statistic left by the producer (FIR epilogue) or computed here
-            if (!st) {
-                hipLaunchKernelGGL(costas_stat_kernel, dim3(div_up((size_t)K, 4)), dim3(256), 0, s, in, stat.as<float2>(),
-                                   (long long)n, L, K);
-                st = stat.as<float2>();
+            if (!sb) {
+                XR_TRY(sub.reserve((size_t)(runs + 2) * sizeof(float2)));
+                hipLaunchKernelGGL(costas_sub_kernel, dim3(div_up((size_t)runs * COSTAS_SUB, 256)), dim3(256), 0, s, in,
+                                   sub.as<float2>(), (long long)n, runs);
+                sb = sub.as<float2>();
             }
+            if (rpc == 32)
+                hipLaunchKernelGGL(costas_stat_kernel<true>, dim3(div_up((size_t)K * 16, 256)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
+            else
+                hipLaunchKernelGGL(costas_stat_kernel<false>, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
+            const float2 *st = stat.as<float2>();
             UnwrapF uf{st, th2};
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
@@ -662,6 +804,19 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
             if (!locked)
                 hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
                                    COSTAS_HEAD);
+        }
+        if (model_step && !job.gated && K > 2 && (rpc & 1) == 0 && rpc <= 120) {
+            // one Newton step on the sub-block model of the loop (costas_model_pass_kernel)
+            ProfScope ps(prof, "costas_model", s);
+            CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), costas_cnt(counters, max_passes),
+                             trust, trust / 256.0f, tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust,
+                             costas_ctl(counters) + 7, 1, job.model_accept};
+            const int nw = (int)div_up((size_t)K, 64);
+            AffMap *aggs = wsolve.as<AffMap>();
+            NewtonStat *wslots = reinterpret_cast<NewtonStat *>(wsolve.as<AffMap>() + nw + 1);
+            hipLaunchKernelGGL(costas_model_pass_kernel, dim3(nw), dim3(64), (size_t)64 * (rpc + 1) * sizeof(float2), s, sb,
+                               S.as<float2>(), E.as<float2>(), J.as<float4>(), rpc, K, runs, gains, pol, aggs);
+            newton_apply_waves(pol, (long long)K - 1, aggs, costas_ctl(counters), wslots, s);
         }
         XR_TRY(enqueue_passes(batch < max_passes ? batch : max_passes, s, prof));
     } else {
@@ -704,24 +859,38 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         stable = (in_batch && passes == last_passes) ? stable + 1 : 0;
         last_passes = passes;
         const int want = passes + ((stable >= 2 && !keep_spare) ? 0 : 1);
-        batch = want < 2 ? 2 : (want > 6 ? 6 : want);
+        batch = want < 1 ? 1 : (want > 6 ? 6 : want);
     }
     unconverged = job.K > 1 && h_counters[0] == 0 ? h_counters[2] : 0;
     uint32_t bits = h_counters[3];
     memcpy(&max_residual, &bits, sizeof(float));
     if (trace_env && job.K > 1) {
-        std::vector<unsigned> hc((size_t)passes * 8);
+        if (h_counters[COSTAS_CTL_MODEL]) {
+            unsigned hm[8];
+            XR_HIP(hipMemcpy(hm, costas_cnt(counters, max_passes), sizeof hm, hipMemcpyDeviceToHost));
+            float mr;
+            unsigned long long qf;
+            memcpy(&mr, &hm[2], 4);
+            memcpy(&qf, &hm[4], 8);
+            fprintf(stderr, "[xrit] costas model step: K=%d changed=%u open=%u max_r=%.3e rms_r=%.3e\n", job.K, hm[0], hm[1], mr,
+                    hm[1] ? sqrtf((float)((double)qf / 1099511627776.0) / hm[1]) : 0.f);
+        }
+        // (a slot per pass enqueued: those that returned at once -- hand-off closed, or taken over by the gated solve -- are empty)
+        std::vector<unsigned> hc((size_t)job.enqueued * 8);
         XR_HIP(hipMemcpy(hc.data(), costas_cnt(counters, 0), hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (int p = 0; p < passes; ++p) {
+        for (int p = 0; p < job.enqueued; ++p) {
             float mr;
             unsigned long long qf;
             memcpy(&mr, &hc[(size_t)p * 8 + 2], 4);
             memcpy(&qf, &hc[(size_t)p * 8 + 4], 8);
             const float q = (float)((double)qf / 1099511627776.0);
-            fprintf(stderr, "[xrit] costas pass %d: K=%d changed=%u open=%u max_r=%.3e rms_r=%.3e\n", p, job.K,
+            if (hc[(size_t)p * 8 + 7] == 0 && hc[(size_t)p * 8 + 1] == 0) continue;
+            fprintf(stderr, "[xrit] costas pass slot %d: K=%d changed=%u open=%u max_r=%.3e rms_r=%.3e\n", p, job.K,
                     hc[(size_t)p * 8], hc[(size_t)p * 8 + 1], mr,
                     hc[(size_t)p * 8 + 1] ? sqrtf(q / hc[(size_t)p * 8 + 1]) : 0.f);
         }
+        fprintf(stderr, "[xrit] costas: %d passes, closed %u, on prediction %u, left open %u, max residual %.3e\n", passes, h_counters[0],
+                h_counters[6], h_counters[2], max_residual);
     }
     cur ^= 1;     // the carried state now is the one the final pass left
     return XRIT_OK;
@@ -756,10 +925,10 @@ int CostasStage::serial_rescue(hipStream_t s, Profiler *prof)
     return XRIT_OK;
 }
 
-int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext,
+int CostasStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *sub_ext,
                      double2 *om, long long om_off, double inv_sps)
 {
-    XR_TRY(begin(in, out, n, s, prof, stat_ext, om, om_off, inv_sps));
+    XR_TRY(begin(in, out, n, s, prof, sub_ext, om, om_off, inv_sps));
     XR_HIP(hipStreamSynchronize(s));
     return finish(s, prof, nullptr);
 }

@@ -369,14 +369,14 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     XR_TRY(keep_stage(d, 1, B, length, s));
     // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
-    const int L = d->costas.L;
-    const size_t K = (length + (size_t)L - 1) / (size_t)L;
-    XR_TRY(d->stat[set].reserve((K + 2) * sizeof(float2)));
-    io->stat_ready = length > 0 && d->rrc.stat_supported(L);
+    // (sum z^2 per run of 8 outputs: the chain sums and the loop's sub-block model both come from it, costas.hip)
+    constexpr int SUB = 8;
+    XR_TRY(d->stat[set].reserve(((length + SUB - 1) / SUB + 2) * sizeof(float2)));
+    io->stat_ready = length > 0 && d->rrc.stat_supported(SUB) && d->costas.L % SUB == 0;
     // (fused: A holds the decimator output, which the fill reads; the filter output goes to B's place instead)
     const bool fill_on = agc_in_rrc || agc_in_rrc_d1;
     float2 *rrc_out = fill_on ? B : A;
-    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, L,
+    XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, SUB,
                       nullptr, fill_on ? &fill : nullptr)); // :148
     XR_TRY(keep_stage(d, 2, rrc_out, length, s));
     io->rrc = rrc_out;

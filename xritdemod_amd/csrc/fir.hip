@@ -394,29 +394,50 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         if (lane == 0 && m0 < n_out) agc.maps[m0 / (64 * RC)] = v;
     }
     if (stat != nullptr) {
-        // sum z^2 per run of statL outputs, from the outputs staged in LDS above (statL divides the block's outputs):
-        // one wave per run (round robin), lane l adds outputs l, l + 64, ... of the run, then a fixed-order shuffle
-        // tree over the lanes -- deterministic.  (Round 2 took it from per-thread partial sums split at run
-        // boundaries: 0.05 ms of the matched filter's 0.30.)
-        const int runs = (int)(OB / statL);
-        const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+        // sum z^2 per run of statL outputs, from the outputs staged in LDS above (statL divides the block's outputs).
         const float2 *ot = tile;
-        for (int j = wave; j < runs; j += nwaves) {
-            const long long first = out_base + (long long)j * statL;      // wave-uniform
-            if (first >= n_out) break;
-            float sr = 0.f, si = 0.f;
-            for (int i = lane; i < statL; i += 64) {
-                if (first + i < n_out) {
-                    const float2 z = ot[j * statL + i];
-                    sr += z.x * z.x - z.y * z.y;
-                    si += 2.0f * z.x * z.y;
+        if (statL == 8) {
+            // Round 4: runs of 8 -- the statistic of the Costas loop's sub-block model (costas_refine_kernel), from which the
+            // chain-level one is summed.  Thread t takes outputs t, t + nthr, ...: eight neighbouring lanes hold a run, three
+            // row shifts add it up (fixed order: deterministic), the run's last lane stores it.
+            for (int i = tid; i < (int)OB; i += nthr) {
+                const long long o = out_base + i;
+                float sr = 0.f, si = 0.f;
+                if (o < n_out) {
+                    const float2 z = ot[i];
+                    sr = z.x * z.x - z.y * z.y;
+                    si = 2.0f * z.x * z.y;
                 }
+                sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x111, 0xf, 0xf, true));      // row_shr:1
+                si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x111, 0xf, 0xf, true));
+                sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x112, 0xf, 0xf, true));      // row_shr:2
+                si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x112, 0xf, 0xf, true));
+                sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x114, 0xf, 0xf, true));      // row_shr:4
+                si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x114, 0xf, 0xf, true));
+                if ((tid & 7) == 7 && o - 7 < n_out) stat[o >> 3] = make_float2(sr, si);
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                sr += __shfl_down(sr, off, 64);
-                si += __shfl_down(si, off, 64);
+        } else {
+            // one wave per run (round robin), lane l adds outputs l, l + 64, ... of the run, then a fixed-order shuffle
+            // tree over the lanes -- deterministic
+            const int runs = (int)(OB / statL);
+            const int wave = tid >> 6, lane = tid & 63, nwaves = nthr >> 6;
+            for (int j = wave; j < runs; j += nwaves) {
+                const long long first = out_base + (long long)j * statL;      // wave-uniform
+                if (first >= n_out) break;
+                float sr = 0.f, si = 0.f;
+                for (int i = lane; i < statL; i += 64) {
+                    if (first + i < n_out) {
+                        const float2 z = ot[j * statL + i];
+                        sr += z.x * z.x - z.y * z.y;
+                        si += 2.0f * z.x * z.y;
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    sr += __shfl_down(sr, off, 64);
+                    si += __shfl_down(si, off, 64);
+                }
+                if (lane == 0) stat[first / statL] = make_float2(sr, si);
             }
-            if (lane == 0) stat[first / statL] = make_float2(sr, si);
         }
     }
 }

@@ -105,7 +105,11 @@ struct CostasStage {
     int max_passes = 32;
     float trust = 1.0f, tol_phase = 1e-5f, tol_freq = 3e-8f;
     DevBuf state;           // float2 (phase, freq) carried across calls
-    DevBuf S, E, J, stat, dlin, work, flags, counters, wsolve, rescue;
+    DevBuf S, E, J, stat, sub, dlin, work, flags, counters, wsolve, rescue;
+    // round 4: one Newton step on a model of the loop over runs of 8 samples refines the guesses before the first pass
+    // over the samples (costas_model_pass_kernel); that pass is accepted on prediction up to model_accept (rad)
+    bool model_step = true;
+    float model_accept = 5e-3f;
     bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1)
     bool keep_spare = false, trace_env = false, no_serial_walk = false;   // XRIT_KEEP_SPARE, XRIT_TRACE, XRIT_NO_SERIAL_WALK (read in init)
     // a hand-off still open after rescue_after passes is walked serially between its first and last open boundary
@@ -123,13 +127,13 @@ struct CostasStage {
     int init(float loop_bw, int chain_len, int max_passes);
     int reset(hipStream_t s);
     void release();
-    // stat_ext (optional): sum z^2 per chain already left by the producer (FIR epilogue); om (optional): receives
+    // sub_ext (optional): sum z^2 per run of 8 samples already left by the producer (FIR epilogue); om (optional): receives
     // the clock recovery's timing-line statistic per chain (index offset om_off in that stage's input buffer)
-    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext = nullptr,
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *sub_ext = nullptr,
             double2 *om = nullptr, long long om_off = 0, double inv_sps = 0.0);
     // the same in two halves: begin() only enqueues (guess, a batch of passes with a device-side stop test, final
     // pass); finish() runs after the caller synchronised the stream and continues the passes if they did not close
-    int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *stat_ext,
+    int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *sub_ext,
               double2 *om, long long om_off, double inv_sps);
     bool closed() const;
     int finish(hipStream_t s, Profiler *prof, bool *redone);
@@ -140,6 +144,7 @@ struct CostasStage {
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
         bool gated = false;     // this call has gone over to the gated solve
         bool rescued = false;   // the serial walk has been tried
+        float model_accept = 0; // CostasPolicy::model_accept of this call: the stage's on a tracking loop, else 0
     } job;
     int batch = 4;          // passes enqueued before the host looks: what the previous call needed + a spare one
     int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
@@ -228,6 +233,7 @@ struct ClockStage {
         bool mean_j = false;    // the passes use the stream's mean Jacobian: no finite-difference pass
         bool gated = false;     // this call has gone over to the gated solve
         bool rescued = false;   // the serial walk has been tried
+        float model_accept = 0; // CostasPolicy::model_accept of this call: the stage's on a tracking loop, else 0
         int *dirty = nullptr, *counts = nullptr, *nrun = nullptr, *terminal = nullptr, *written = nullptr;
         int G = 0, cps = 0, relay_enq = 0;      // exact closure: segments, chains per segment, passes enqueued
         int relay_w = 0;                        // waves per walker team (clock_relay_wide.h); 0: the one-wave walker
