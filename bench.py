@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="one burst at a time: do not run the front end of the next burst (xrit_demod_prefetch_device, second "
                          "stream) under the feedback loops of the current one")
-    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode and fast-mode legs (cfg.clock_exact = 1, -2)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode, fast-mode and quick-mode legs (cfg.clock_exact = 1, -2, -3)")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
@@ -443,6 +443,9 @@ def main():
                                  "float32 recurrence on this chain's Costas output", 5)
         alt_leg("fast_mode", -2, "cfg.clock_exact = -2 (the default of rounds 2-3): hand-off passes only, five on this signal, "
                                  "relayed only when they stall; soft symbols 2.2e-4 .. 2.6e-4 rms from the CPU chain", 10)
+        alt_leg("quick_mode", -3, "cfg.clock_exact = -3 (round 4): the default's relay with the passes in front of its last walked "
+                                  "approximately (one guess round, then two; no verification, nothing stored); soft symbols "
+                                  "1.15e-4 rms from the serial trajectory", 10)
 
     # ---- CPU baseline: the oracle (a CPU restatement; the reference binary cannot be built here) on a
     # bounded sample of the same workload, one thread like the reference's DSP thread.

@@ -117,23 +117,28 @@ typedef struct xrit_demod_config {
                                  * knows of its past by one segment (no shorter than 16 384 symbols unless the relay
                                  * runs to closure); a pass that changes nothing has reproduced the serial trajectory
                                  * (clock_serial = 1) bit for bit.
-                                 *   0 (default): two hand-off passes, then three relay passes -- soft symbols within
-                                 *      5 % of the serial trajectory's own distance from the CPU chain (6e-5 rms from the
-                                 *      serial trajectory itself), 2.3 ms per 256 Mi-sample burst.  Walked to closure on its own
+                                 *   0 (default), by call size (round 4): up to 74 k symbols ONE exact walk from the carried
+                                 *      state (the serial trajectory itself); from 6 M symbols -- every BASELINE burst -- no hand-off
+                                 *      passes at all: two walkers per CU, the first relay pass from the timing guess, three passes at
+                                 *      24.8 k symbols per segment, two from 49 k (soft symbols 5.6e-5 rms from the serial
+                                 *      trajectory, within 5 % of its own distance from the CPU chain; 2.1 ms per streamed 256 Mi-sample
+                                 *      burst); in between two hand-off passes, then three relay passes.  Walked to closure on its own
                                  *      when the soft symbols of the first relay pass show Es/N0 below 7 dB (hard decisions
-                                 *      would otherwise differ from the serial loop's) or the hand-off passes never closed,
+                                 *      would otherwise differ from the serial loop's), when a segment start moves by a quarter of
+                                 *      a symbol between passes (the guess miscounted) or the hand-off passes never closed,
                                  *      and four passes at a time while the segment starts still move by more than 6e-4
-                                 *      sample rms from pass to pass (stats.clock_relay_passes / clock_relay_closed).  Calls
-                                 *      of fewer than
-                                 *      4096 symbols: hand-off passes, which close such calls exactly or, stalled above
-                                 *      3e-4 sample rms, hand over to the relay;
+                                 *      sample rms from pass to pass (stats.clock_relay_passes / clock_relay_closed);
                                  *   1: every call to closure (~9 ms per 256 Mi-sample burst; the serial wave: 3.9 s);
                                  *   n > 1: two hand-off passes and n relay passes, nothing else;
                                  *   -2: hand-off passes only, five of them on a clean signal -- the fast configuration
                                  *      (2.1 ms per burst, soft symbols 2.2e-4 .. 2.6e-4 rms from the serial trajectory:
                                  *      DESIGN.md section 6); a call whose passes stall above 3e-4 sample rms (low Es/N0)
                                  *      or never close is still relayed to closure (rounds 2-3's default);
-                                 *   -1: hand-off passes only, never relayed. */
+                                 *   -1: hand-off passes only, never relayed;
+                                 *   -3: the quick relay -- the default's plan with the passes in front of its last walked
+                                 *      approximately (one guess round, then two; no literal verification, nothing stored: they are
+                                 *      there for their end states): 1.92 ms per streamed burst, 1.15e-4 rms from the serial
+                                 *      trajectory.  Faster AND closer than -2. */
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
     int32_t  reserved[3];
 } xrit_demod_config;

@@ -570,6 +570,32 @@ def test_partial_relay_trades_passes_for_parity(xa):
     assert st.clock_relay_closed == 1 and prev == 0.0
 
 
+def test_quick_relay_is_closer_than_the_hand_off_passes(xa, oracle_mod):
+    """cfg.clock_exact = -3: the default's relay plan on a burst that fills the chip, its first pass walked in one guess
+    round and its second in two (clock_relay_kernel's apx: no literal verification, no symbols -- those passes are run for
+    their end states), the last one exactly.  Same symbol count, hard decisions equal, between the default and the hand-off
+    passes alone in its distance from the serial trajectory; a call of one segment stays ONE exact walk."""
+    fs, D, n = 6.25e6, 5, 1 << 27        # 6.3 M symbols: two walkers per CU, no hand-off passes
+    x = synth.generate(synth.SynthParams(fs_in=fs), n)
+    ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_serial=1)).process(x)
+    out = {}
+    for ce in (0, -3, -2):
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_exact=ce))
+        got = dem.process(x)
+        st = dem.stats()
+        assert len(got) == len(ser)
+        big = np.abs(ser) > 1e-3
+        assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
+        out[ce] = rms(got - ser)
+        if ce != -2:
+            assert st.clock_passes == 0 and 2 <= st.clock_relay_passes <= 4, (ce, st.clock_passes, st.clock_relay_passes)
+    assert out[0] <= out[-3] <= out[-2] and out[-3] <= 1.6e-4, out
+    x = x[:300000]
+    ser = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_serial=1)).process(x)
+    got = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_exact=-3)).process(x)
+    assert np.array_equal(got.view(np.uint32), ser.view(np.uint32))
+
+
 def test_stalled_hand_off_is_closed_exactly_on_its_own(xa):
     """Default configuration (clock_exact = 0): two hand-off passes and three relay passes; a call whose soft symbols
     show Es/N0 below 7 dB is walked to closure without being asked (stats.clock_relay_closed, i.e. its symbols are the

@@ -43,6 +43,8 @@ constexpr int RELAY_WALKED = 1;      // start[]: the segment has been walked exa
 constexpr int RELAY_EXHAUSTED = 2;   // ends[]: the input ran out inside this segment (n_done symbols exist)
 constexpr int RELAY_DEAD = 4;        // the input ran out before this segment
 constexpr int RELAY_STUCK = 8;       // ends[]: a watchdog ended the walk (a ring or a mailbox never filled): the call fails
+constexpr int RELAY_APPROX = 16;     // start[]: the segment has been walked from start[].s by an approximate pass (apx > 0): not exactly
+constexpr int RELAY_REC = 32;        // start[]: ... which left the record of its (index, arm) guesses
 constexpr int RELAY_CLAIM_WORDS = 2048;   // one word per CU, indexed by (XCC_ID, SE_ID, SH_ID, CU_ID)
 
 struct RelaySeg {
@@ -163,8 +165,17 @@ constexpr int RELAY_REF_MARGIN = 1 << 20;     // a segment's reference index sit
 
 // RING: two waves per workgroup, samples through the LDS ring (span = samples a block of 64 symbols can cover
 // <= RELAY_RX - RELAY_XCH - 72); else one wave that reads its windows from global memory (any symbol rate).
+// apx (round 4, cfg.clock_exact = -3: the passes in front of the last): an APPROXIMATE walk.  What those passes are for is
+// the end state of every segment -- the start of the segment behind it in the next pass -- and the loop forgets: an end state
+// is as good as the loop's memory of the errors made on the way.  So the walk takes its guess rounds and stops there:
+//   apx = 1   ONE round: every symbol interpolated where the walker's own rate puts it (off by up to an arm, 8e-3 sample, at
+//             the end of a block), the timing errors from that, the states from their sums; nothing is stored;
+//   apx = 2   two rounds at most (the second with the arms the first one's sums gave: all but a few per cent of the symbols
+//             are then where the exact walk has them), and the record of (index, arm) is left for the next pass' first guesses.
+// No literal verification (a block is 64 symbols unless the input ends), no symbols, the segment is not marked as walked:
+// an exact pass (apx = 0) walks it whatever its start was.
 template <bool SYM, bool RING>
-__global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs a, int pass, int span)
+__global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs a, int pass, int span, int apx)
 {
     if (a.ctl && !a.ctl[0]) return;                              // the tiled hand-off has not closed: nothing to refine yet
                                                                  // (null: it never will -- pass budget used up -- go anyway)
@@ -244,7 +255,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     // the record of the walk before (this call's: the flags are cleared when a call's relay starts): prev.n_done symbols,
     // read indices relative to a reference that does not depend on the pass
     const bool use_rec = RING && a.rec != nullptr &&
-                         __builtin_amdgcn_readfirstlane((int)((prev.flags & RELAY_WALKED) != 0 && prev.n_done > 0)) != 0;
+                         __builtin_amdgcn_readfirstlane((int)((prev.flags & (RELAY_WALKED | RELAY_REC)) != 0 && prev.n_done > 0)) != 0;
     const int n_rec = __builtin_amdgcn_readfirstlane(prev.n_done);
     const int ref = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii)) -
                     RELAY_REF_MARGIN;
@@ -301,7 +312,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         atomicAdd(&a.changed[RELAY_STAT * pass], 1u);
         // how far this start is from the one the segment was last walked from (samples): what the automatic closure
         // looks at (ClockStage::finish).  Non-negative floats order like their bits; watchdog marks stay on top.
-        if (pass > 0 && (prev.flags & RELAY_WALKED)) {
+        if (pass > 0 && (prev.flags & (RELAY_WALKED | RELAY_APPROX))) {
             const float mv = fabsf(clock_tdiff(prev.s, T));
             atomicMax(&a.changed[RELAY_STAT * pass + 3], __float_as_uint(mv));
             // (sum of squares in units of 2^-40 sample^2, moves beyond a sample count as one)
@@ -382,7 +393,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         float mm = 0.f;
         ClockState hs{};               // the history symbol n + lane sees: (p0, p1) of the two symbols in front of it
         bool stale = false, inrange = true;
-        for (int round = 0; round < RELAY_ROUNDS; ++round) {
+        const int max_rounds = apx == 1 ? 1 : (apx == 2 ? 2 : RELAY_ROUNDS);
+        for (int round = 0; round < max_rounds; ++round) {
             ++rounds_total;
             // (re)interpolate where the read index or the arm moved
             inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
@@ -430,8 +442,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         const int nxt_ii = relay_dpp<0x130>(cii);
         const float nxt_mu = relay_shl1(cmu), nxt_om = relay_shl1(com);
         const bool exists = (unsigned)cii < (unsigned)ni_w;
-        const bool good = !stale && inrange;                      // this lane's interpolation belongs to its state
-        const bool ok = good && exists && lane < 63 && (int)st.ii == nxt_ii && st.mu == nxt_mu && st.omega == nxt_om;
+        const bool good = (!stale || apx) && inrange;             // this lane's interpolation belongs to its state (apx: near enough)
+        const bool ok = good && exists && lane < 63 && (apx || ((int)st.ii == nxt_ii && st.mu == nxt_mu && st.omega == nxt_om));
         const unsigned long long okm = __ballot(ok), exm = __ballot(exists), gdm = __ballot(good);
         const int m = ~okm ? __builtin_ctzll(~okm) : 64;         // lanes 0 .. m start from verified states
         const int e = ~exm ? __builtin_ctzll(~exm) : 64;         // first lane whose symbol does not exist
@@ -443,9 +455,9 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         if (e < nv) { nv = e; exhausted = true; }
         RELAY_TICK(3);
         if (pass == 0 && lane < nv) { m1 += fabsf(p0.x); m2 += p0.x * p0.x; }
-        if (lane < nv) {
+        if (lane < nv && apx != 1) {
             const int o = n + lane;
-            if (o < n_out) {
+            if (o < n_out && !apx) {
                 if (softs) softs[o] = p0.x;
                 if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
             }
@@ -503,7 +515,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         RelaySeg st0{};
         st0.s = T0;
         st0.n_done = n;                 // symbols the record holds
-        st0.flags = RELAY_WALKED;
+        st0.flags = apx ? (RELAY_APPROX | (apx == 2 ? RELAY_REC : 0)) : RELAY_WALKED;
         a.start[s] = st0;
         RelaySeg e{};
         e.s = T;

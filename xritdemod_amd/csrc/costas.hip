@@ -53,9 +53,11 @@ __global__ void __launch_bounds__(256) costas_sub_kernel(const float2 *__restric
 // stat[k] = sum z^2 over chain k, from the runs.  RPC32 (chains of 256 samples = 32 runs): a lane takes two runs
 // (one 16-byte load, a wave reads 1 KB in one piece), a row of 16 lanes holds a chain, four row shifts add it up in a
 // fixed order.  Otherwise a thread adds one chain's runs in order.  Deterministic either way.
+// ang[k] = arg stat[k] rides along (the unwrap scan below reads it instead of taking two double-precision atan2 per element in
+// each of its two kernels: 37 us of latency per burst at C2)
 template <bool RPC32>
 __global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restrict__ sub, float2 *__restrict__ stat,
-                                                          long long runs, int rpc, int K)
+                                                          float *__restrict__ ang, long long runs, int rpc, int K)
 {
     if (RPC32) {
         const long long q = (long long)blockIdx.x * 256 + threadIdx.x;     // pair of runs 2 q, 2 q + 1
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restri
         XR_ROW_ADD(0x111) XR_ROW_ADD(0x112) XR_ROW_ADD(0x114) XR_ROW_ADD(0x118)      // row_shr:1, 2, 4, 8
 #undef XR_ROW_ADD
         const long long k = q >> 4;
-        if ((threadIdx.x & 15) == 15 && k < K) stat[k] = make_float2(sr, si);
+        if ((threadIdx.x & 15) == 15 && k < K) { stat[k] = make_float2(sr, si); ang[k] = atan2f(si, sr); }
         return;
     }
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -88,6 +90,7 @@ __global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restri
         sr += v.x; si += v.y;
     }
     stat[k] = make_float2(sr, si);
+    ang[k] = atan2f(si, sr);
 }
 
 // -------------------------------------------------------------------- guess
@@ -99,18 +102,15 @@ __device__ __forceinline__ double wrap_pi_d(double x)
 // prefix sum of wrapped differences of 2*theta -> unwrapped 2*theta per chain
 struct UnwrapF {
     typedef double T;
-    const float2 *stat;
-    double *th2;   // out: unwrapped 2*theta at chain centres
+    const float *ang;   // arg stat[k]
+    double *th2;        // out: unwrapped 2*theta at chain centres
     __device__ T identity() const { return 0.0; }
     __device__ T combine(const T &lo, const T &hi) const { return lo + hi; }
     __device__ double diff(long long k) const
     {
-        float2 a = stat[k];
-        double cur = atan2((double)a.y, (double)a.x);
+        const double cur = (double)ang[k];
         if (k == 0) return cur;
-        float2 b = stat[k - 1];
-        double prev = atan2((double)b.y, (double)b.x);
-        return wrap_pi_d(cur - prev);
+        return wrap_pi_d(cur - (double)ang[k - 1]);
     }
     __device__ T reduce_run(long long i0, int cnt) const
     {
@@ -788,11 +788,11 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
                 sb = sub.as<float2>();
             }
             if (rpc == 32)
-                hipLaunchKernelGGL(costas_stat_kernel<true>, dim3(div_up((size_t)K * 16, 256)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
+                hipLaunchKernelGGL(costas_stat_kernel<true>, dim3(div_up((size_t)K * 16, 256)), dim3(256), 0, s, sb, stat.as<float2>(), dlin.as<float>(), runs, rpc, K);
             else
-                hipLaunchKernelGGL(costas_stat_kernel<false>, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
+                hipLaunchKernelGGL(costas_stat_kernel<false>, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, sb, stat.as<float2>(), dlin.as<float>(), runs, rpc, K);
             const float2 *st = stat.as<float2>();
-            UnwrapF uf{st, th2};
+            UnwrapF uf{dlin.as<float>(), th2};     // (dlin: scratch of the gated solve, which comes later)
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(scan_apply_lookback_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,

@@ -230,7 +230,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;
-        d->clock.exact = cfg->clock_exact;
+        d->clock.exact = cfg->clock_exact == -3 ? 0 : cfg->clock_exact;        // (-3: the default's plan, its first relay passes approximate)
+        d->clock.relay_quick = cfg->clock_exact == -3;
 #ifdef XRIT_EXPERIMENTS
         d->no_defer = getenv("XRIT_NO_DEFER") != nullptr;
 #endif

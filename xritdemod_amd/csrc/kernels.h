@@ -241,6 +241,7 @@ struct ClockStage {
         bool relay_force = false;               // ... although the tiled hand-off never closed (pass budget used up)
         bool no_handoff = false;                // ... straight from the timing guess: no hand-off passes at all
         int relay_budget = 0;                   // relay passes at most (0: until closed)
+        int relay_apx[2] = {0, 0};              // how the relay's first two passes walk (clock_relay_kernel's apx): 0 exactly
         bool relay_long = false;                // the default configuration on segments of >= auto_long_seg symbols: two passes, no watch on the starts
         int write_from = 0x7fffffff;            // hand-off passes from this one on leave the symbols (ClockPassOut)
     } job;
@@ -290,6 +291,8 @@ struct ClockStage {
     bool relay_per_cu_set = false;
     int relay_no_handoff = -1;       // the relay's first pass starts from the timing guess, no hand-off passes: -1: in the default
                                      // configuration (cfg.clock_exact = 0); XRIT_NO_HANDOFF=0 / 1: never / with every relayed call (A/B runs)
+    bool relay_quick = false;          // cfg.clock_exact = -3: the default configuration with its first relay passes walked approximately
+    int relay_apx_cfg[2] = {-1, -1};   // XRIT_RELAY_APX=a,b: the walk of the relay's first two passes (-1: the configuration's choice; A/B runs)
     int relay_waves = 1;        // waves per walker team at most (clock_relay_wide.h; < 2: the one-wave walker of clock_relay.h)
     int relay_teams_per_cu = 1; // segments (teams) per CU the relay plans with the wide walker
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
