@@ -1099,7 +1099,7 @@ void ClockStage::release()
 {
     table.release(); xbuf[0].release(); xbuf[1].release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
-    relay.release(); relay_rec.release(); alt.release(); stage.release();
+    relay.release(); relay_rec.release(); alt.release(); stage.release(); om_work.release();
     if (h_res) (void)hipHostFree(h_res);
     h_res = nullptr;
 }
@@ -1110,9 +1110,30 @@ double2 *ClockStage::om_slot(int nb, int BL)
 {
     if (nb < 1 || om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))) != XRIT_OK) return nullptr;
     om_ext = true;
+    om_scanned = false;
     om_nb = nb;
     om_BL = BL;
     return om.as<double2>();
+}
+
+// The symbol-count curve of the producer's statistic (om_slot), unwrapped on the producer's stream behind the kernel that
+// leaves the statistic.  Counted from the first NEW sample: the curve does not depend on what the previous call carries
+// over (its integer values -- the symbol instants -- are the same whichever sample the phasor counts from, because the line
+// turns once per symbol), so the next burst's curve is ready while this burst's relay still runs; begin() places it
+// `carry` samples into the buffer.
+int ClockStage::om_scan(hipStream_t s)
+{
+    if (!om_ext || om_nb < 1) return XRIT_OK;
+    const int nb = om_nb, nbB = scan_blocks(nb);
+    XR_TRY(om_work.reserve((size_t)(nbB + 2) * sizeof(double)));
+    double2 *X = om.as<double2>();
+    double *cnt = reinterpret_cast<double *>(om.as<char>() + (size_t)nb * sizeof(double2));
+    ClkUnwrapF uf{X, cnt, nb, (double)sps, 0.0, om_BL, 0.0};
+    hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb, om_work.as<double>());
+    hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb, om_work.as<double>());
+    XR_HIP(hipGetLastError());
+    om_scanned = true;
+    return XRIT_OK;
 }
 
 // where the producer writes the n new samples of this call: behind the `carry` samples left unread by the
@@ -1496,7 +1517,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     if (carry)
         hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, s, tail.as<float2>() + 1024 * cur, x, (int)carry);
     const bool ext = om_ext;          // statistic supplied by the producer of the samples (Costas final pass)
+    const bool scanned = ext && om_scanned;       // ... and its count curve too (om_scan)
     om_ext = false;
+    om_scanned = false;
     if (j.ni <= 0) {
         // not enough samples for a single symbol: everything is carried to the next call
         j.short_input = true;
@@ -1578,9 +1601,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     const int K = (int)((double)j.N / (min_omega * NS)) + 3;
     j.K = K;
     const int BL = ext ? om_BL : CLK_OM_BLOCK;
-    // (the producer's statistic: block b covers buffer samples [carry + b BL, ...), its phasor counted from the first new sample)
+    // (the producer's statistic: block b covers buffer samples [carry + b BL, ...), its phasor counted from the first new sample:
+    // the count curve is computed in those coordinates -- same symbol instants, see om_scan -- and placed `carry` samples in)
     const double om_off = ext ? (double)carry : 0.0;
-    const double om_rot = ext ? 2.0 * XR_PI_D * ((double)carry / (double)sps - floor((double)carry / (double)sps)) : 0.0;
     const int nb = ext ? om_nb : (int)((j.N + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
     XR_TRY(S.reserve((size_t)K * sizeof(ClockState)));
     XR_TRY(E.reserve((size_t)K * sizeof(ClockState)));
@@ -1663,11 +1686,13 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
             if (!ext)
                 hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)nb, 4)), dim3(256), 0, s, x, X, j.N, nb,
                                    1.0 / (double)sps);
-            ClkUnwrapF uf{X, cnt, nb, (double)sps, om_off, BL, om_rot};
-            hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
-                               work.as<double>());
-            hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
-                               work.as<double>());
+            if (!scanned) {
+                ClkUnwrapF uf{X, cnt, nb, (double)sps, 0.0, BL, 0.0};
+                hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
+                                   work.as<double>());
+                hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb,
+                                   work.as<double>());
+            }
             hipLaunchKernelGGL(clock_guess_kernel, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, cnt, nb, (double)sps,
                                S.as<ClockState>(), st_in, K, NS, par.omega_mid, x, table.as<float>(), j.ni, om_off, BL, j.dirty,
                                clock_ctl(counters), (max_passes + 5) * 8, j.terminal, j.written);

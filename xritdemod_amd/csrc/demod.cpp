@@ -420,6 +420,7 @@ static int costas_enqueue(xrit_demod *d, const SliceIO &io, hipStream_t s, Profi
     const double inv_sps = 1.0 / (double)d->sps;
     const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
     XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, 0, inv_sps));
+    if (length) XR_TRY(d->clock.om_scan(s));     // the timing guess's count curve, behind the final pass that leaves its statistic
     if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
     *slot_out = slot;
     return XRIT_OK;
@@ -472,6 +473,7 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
         if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
         bool redone = false;
         XR_TRY(d->costas.finish(s, prof, &redone));
+        if (redone) d->clock.om_scanned = false;     // (the final pass ran again: the statistic is new, begin() unwraps it itself)
         costas_done = true;
     }
     float2 *sym = nullptr;
@@ -556,6 +558,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
             if (io.length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
             bool redone = false;
             rc = d->costas.finish(d->stream2, prof, &redone);
+            if (redone) d->clock.om_scanned = false;
             if (rc == XRIT_OK) {
                 XR_HIP(hipEventRecord(d->ev_costas, d->stream2));
                 XR_HIP(hipStreamWaitEvent(s, d->ev_costas, 0));

@@ -203,6 +203,11 @@ struct ClockStage {
     double2 *om_slot(int nb, int BL);
     bool om_ext = false;
     int om_nb = 0, om_BL = 256;
+    // (round 4: ... and the producer's stream also unwraps it into the symbol-count curve, om_scan(): two launches less between
+    // the end of one burst's relay and the start of the next one's)
+    bool om_scanned = false;
+    DevBuf om_work;
+    int om_scan(hipStream_t s);
     // soft (real parts) and/or complex symbols; either may be null
     int run(size_t n, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
     // The last call once more on its sign-flipped input (one capture across GPUs: this rank's Costas loop turned out
