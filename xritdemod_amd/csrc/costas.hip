@@ -50,34 +50,36 @@ __global__ void __launch_bounds__(256) costas_sub_kernel(const float2 *__restric
     if ((threadIdx.x & 7) == 7 && (j >> 3) < runs) sub[j >> 3] = make_float2(sr, si);
 }
 
-// stat[k] = sum z^2 over chain k, from the runs.  RPC32 (chains of 256 samples = 32 runs): a lane takes two runs
-// (one 16-byte load, a wave reads 1 KB in one piece), a row of 16 lanes holds a chain, four row shifts add it up in a
-// fixed order.  Otherwise a thread adds one chain's runs in order.  Deterministic either way.
-// ang[k] = arg stat[k] rides along (the unwrap scan below reads it instead of taking two double-precision atan2 per element in
-// each of its two kernels: 37 us of latency per burst at C2)
+// stat[k] = sum z^2 over chain k, from the runs.  RPC32 (chains of 256 samples = 32 runs): a lane takes two runs per load
+// (16 bytes; a wave reads 1 KB in one piece), a row of 16 lanes holds a chain, four row shifts add it up in a fixed order;
+// four loads in flight per lane.  Otherwise a thread adds one chain's runs in order.  Deterministic either way.
 template <bool RPC32>
 __global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restrict__ sub, float2 *__restrict__ stat,
-                                                          float *__restrict__ ang, long long runs, int rpc, int K)
+                                                          long long runs, int rpc, int K)
 {
     if (RPC32) {
-        const long long q = (long long)blockIdx.x * 256 + threadIdx.x;     // pair of runs 2 q, 2 q + 1
-        float sr = 0.f, si = 0.f;
-        if (2 * q + 1 < runs) {
-            const float4 v = reinterpret_cast<const float4 *>(sub)[q];
-            sr = v.x + v.z;
-            si = v.y + v.w;
-        } else if (2 * q < runs) {
-            const float2 v = sub[2 * q];
-            sr = v.x;
-            si = v.y;
+        // wave w of the launch: chains [16 w, 16 w + 16), load j covers chains 16 w + 4 j .. + 3
+        const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long q = (w * 4 + j) * 64 + lane;                    // pair of runs 2 q, 2 q + 1
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (2 * q + 1 < runs) v[j] = reinterpret_cast<const float4 *>(sub)[q];
+            else if (2 * q < runs) { const float2 a = sub[2 * q]; v[j].x = a.x; v[j].y = a.y; }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sr = v[j].x + v[j].z, si = v[j].y + v[j].w;
 #define XR_ROW_ADD(CTRL)                                                                                          \
-        sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), CTRL, 0xf, 0xf, true));           \
-        si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), CTRL, 0xf, 0xf, true));
-        XR_ROW_ADD(0x111) XR_ROW_ADD(0x112) XR_ROW_ADD(0x114) XR_ROW_ADD(0x118)      // row_shr:1, 2, 4, 8
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), CTRL, 0xf, 0xf, true));       \
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), CTRL, 0xf, 0xf, true));
+            XR_ROW_ADD(0x111) XR_ROW_ADD(0x112) XR_ROW_ADD(0x114) XR_ROW_ADD(0x118)      // row_shr:1, 2, 4, 8
 #undef XR_ROW_ADD
-        const long long k = q >> 4;
-        if ((threadIdx.x & 15) == 15 && k < K) { stat[k] = make_float2(sr, si); ang[k] = atan2f(si, sr); }
+            const long long k = w * 16 + j * 4 + (lane >> 4);
+            if ((lane & 15) == 15 && k < K) stat[k] = make_float2(sr, si);
+        }
         return;
     }
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -90,7 +92,6 @@ __global__ void __launch_bounds__(256) costas_stat_kernel(const float2 *__restri
         sr += v.x; si += v.y;
     }
     stat[k] = make_float2(sr, si);
-    ang[k] = atan2f(si, sr);
 }
 
 // -------------------------------------------------------------------- guess
@@ -102,27 +103,30 @@ __device__ __forceinline__ double wrap_pi_d(double x)
 // prefix sum of wrapped differences of 2*theta -> unwrapped 2*theta per chain
 struct UnwrapF {
     typedef double T;
-    const float *ang;   // arg stat[k]
+    const float2 *stat;
     double *th2;        // out: unwrapped 2*theta at chain centres
     __device__ T identity() const { return 0.0; }
     __device__ T combine(const T &lo, const T &hi) const { return lo + hi; }
-    __device__ double diff(long long k) const
-    {
-        const double cur = (double)ang[k];
-        if (k == 0) return cur;
-        return wrap_pi_d(cur - (double)ang[k - 1]);
-    }
+    __device__ double ang(long long k) const { const float2 a = stat[k]; return (double)atan2f(a.y, a.x); }
+    // (a thread's run takes every angle once -- single precision: 1e-7 rad on a guess that is 2e-2 off --, the differences chain
+    // through `prev`; two double-precision atan2 per element in each of the scan's two kernels cost 37 us of latency per burst)
     __device__ T reduce_run(long long i0, int cnt) const
     {
-        double s = 0;
-        for (int k = 0; k < cnt; ++k) s += diff(i0 + k);
+        double s = 0, prev = i0 > 0 ? ang(i0 - 1) : 0.0;
+        for (int k = 0; k < cnt; ++k) {
+            const double cur = ang(i0 + k);
+            s += (i0 + k == 0) ? cur : wrap_pi_d(cur - prev);
+            prev = cur;
+        }
         return s;
     }
     __device__ void apply_run(long long i0, int cnt, const T &pre) const
     {
-        double s = pre;
+        double s = pre, prev = i0 > 0 ? ang(i0 - 1) : 0.0;
         for (int k = 0; k < cnt; ++k) {
-            s += diff(i0 + k);
+            const double cur = ang(i0 + k);
+            s += (i0 + k == 0) ? cur : wrap_pi_d(cur - prev);
+            prev = cur;
             th2[i0 + k] = s;
         }
     }
@@ -788,11 +792,11 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
                 sb = sub.as<float2>();
             }
             if (rpc == 32)
-                hipLaunchKernelGGL(costas_stat_kernel<true>, dim3(div_up((size_t)K * 16, 256)), dim3(256), 0, s, sb, stat.as<float2>(), dlin.as<float>(), runs, rpc, K);
+                hipLaunchKernelGGL(costas_stat_kernel<true>, dim3(div_up((size_t)K, 64)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
             else
-                hipLaunchKernelGGL(costas_stat_kernel<false>, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, sb, stat.as<float2>(), dlin.as<float>(), runs, rpc, K);
+                hipLaunchKernelGGL(costas_stat_kernel<false>, dim3(div_up((size_t)K, 256)), dim3(256), 0, s, sb, stat.as<float2>(), runs, rpc, K);
             const float2 *st = stat.as<float2>();
-            UnwrapF uf{dlin.as<float>(), th2};     // (dlin: scratch of the gated solve, which comes later)
+            UnwrapF uf{st, th2};
             hipLaunchKernelGGL(scan_reduce_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
                                work.as<double>());
             hipLaunchKernelGGL(scan_apply_lookback_kernel<UnwrapF>, dim3(nbK), dim3(SCAN_BLOCK), 0, s, uf, (long long)K,
