@@ -304,7 +304,6 @@ struct CostasPolicy {
 #define XR_AMP_THR 1.02f
 #endif
 constexpr int COSTAS_CT = 8;
-constexpr int COSTAS_OT = 16 / COSTAS_CT;    // input tiles per output row of 16 samples (one 128-byte line)
 
 template <bool FINAL>
 __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restrict__ z, float2 *__restrict__ y,
@@ -318,8 +317,12 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
 {
     // the hand-off already closed (later passes of the batch are no-ops), or the gated solve has taken over
     if (!FINAL && (ctl[0] || (aggs != nullptr && ctl[NEWTON_CTL_TAKEOVER]))) return;
+    // Two tiles of COSTAS_CT samples per chain at a time (round 4): the pair's samples sit in two LDS areas, a lane walks its
+    // chain through both, and FINAL leaves the de-rotated samples IN PLACE -- the pair then holds 16 outputs per chain, one whole
+    // 128-byte line, written by eight lanes per row.  No output tile of its own: 9 KB of LDS per wave instead of 17.5, so that
+    // all of a burst's 3277 waves are resident at once (13 per CU; nine were, in two generations), and the NEXT pair's samples
+    // are in flight in registers while this one is walked (two tiles ahead instead of one).
     __shared__ float2 tin[2][64][COSTAS_CT + 1];
-    __shared__ float2 tout[FINAL ? 64 : 1][COSTAS_OT * COSTAS_CT + 1];   // one 128-byte row per chain
     const int lane = threadIdx.x;
     const int kbase = blockIdx.x * 64;
     const int k = kbase + lane;
@@ -358,43 +361,39 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     constexpr int RPI = 64 / LPR;                 // rows per wave instruction
     constexpr int NIT = 64 / RPI;
     const int lrow = lane / LPR, lcol = (lane % LPR) * 2;
-    float4 pre[NIT];
+    float4 pre[2][NIT];
     // unconditional, clamped loads (chains past K / samples past n re-read the last pair; their results are
-    // never used; the input buffer has 8 samples of slack): no branches between the loads, so a tile's requests are all in flight together
+    // never used; the input buffer has 8 samples of slack): no branches between the loads, so a pair's requests are all in flight together
     const long long last_pair = (n - 1) & ~1LL;     // an odd n reads one sample of the buffer's slack
-    auto fetch = [&](int tile) {
+    auto fetch = [&](int tile, int h) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = min(it * RPI + lrow, K - 1 - kbase);
             long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
             j = j < last_pair ? j : last_pair;
-            pre[it] = *reinterpret_cast<const float4 *>(z + j);
+            pre[h][it] = *reinterpret_cast<const float4 *>(z + j);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int r, int h) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = it * RPI + lrow;
-            tin[buf][c][lcol] = make_float2(pre[it].x, pre[it].y);
-            tin[buf][c][lcol + 1] = make_float2(pre[it].z, pre[it].w);
+            tin[h][c][lcol] = make_float2(pre[r][it].x, pre[r][it].y);
+            tin[h][c][lcol + 1] = make_float2(pre[r][it].z, pre[r][it].w);
         }
     };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int tile = 0; tile < nt; ++tile) {
-        const int cur = tile & 1;
-        if (tile + 1 < nt) fetch(tile + 1);
+    // one tile of this lane's chain from area h
+    auto walk = [&](int tile, int h) {
         const int i0 = tile * COSTAS_CT;
         if (__all(!mine || i0 + COSTAS_CT <= cnt)) {
             // every chain of the wave has the whole tile: no per-sample guard (idle lanes compute on zeros)
 #pragma unroll
             for (int i = 0; i < COSTAS_CT; ++i) {
                 float yr, yi;
-                float2 v = tin[cur][lane][i];
+                float2 v = tin[h][lane][i];
                 costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
                 if (FINAL) {
-                    tout[lane][(tile % COSTAS_OT) * COSTAS_CT + i] = make_float2(yr, yi);
+                    tin[h][lane][i] = make_float2(yr, yi);
                     const float p = yr * yr + yi * yi;
                     om_r = fmaf(p, om_c, om_r);
                     om_i = fmaf(p, om_s, om_i);
@@ -408,7 +407,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
             for (int i = 0; i < COSTAS_CT; ++i) {
                 float yr = 0.f, yi = 0.f;
                 if (i0 + i < cnt) {
-                    float2 v = tin[cur][lane][i];
+                    float2 v = tin[h][lane][i];
                     costas_step<!FINAL>(v.x, v.y, phase, freq, g, yr, yi, t);
                     if (FINAL) {
                         const float p = yr * yr + yi * yi;
@@ -419,29 +418,59 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                         om_c = nc;
                     }
                 }
-                if (FINAL) tout[lane][(tile % COSTAS_OT) * COSTAS_CT + i] = make_float2(yr, yi);
+                if (FINAL) tin[h][lane][i] = make_float2(yr, yi);
             }
         }
-        if (FINAL && ((tile % COSTAS_OT) == COSTAS_OT - 1 || tile + 1 == nt)) {
-            // 16 samples per chain = one full 128-byte line, 8 lanes per row
+        if (!FINAL) amp = fmaxf(amp, fabsf(t.pp));
+    };
+    if (!FINAL) {
+        // (the passes with the tangent are bound by their arithmetic: one tile at a time, the next one in flight, measured
+        // 0.113 against 0.123 ms per pass for the pairs)
+        fetch(0, 0);
+        stash(0, 0);
+        __syncthreads();
+        for (int tile = 0; tile < nt; ++tile) {
+            const int cur = tile & 1;
+            if (tile + 1 < nt) fetch(tile + 1, 0);
+            walk(tile, cur);
+            if (tile + 1 < nt) stash(0, cur ^ 1);
             __syncthreads();
-            const int ncol = ((tile % COSTAS_OT) + 1) * COSTAS_CT;
-            const int ob = i0 - (tile % COSTAS_OT) * COSTAS_CT;
+        }
+    } else {
+    fetch(0, 0);
+    if (nt > 1) fetch(1, 1);
+    stash(0, 0);
+    if (nt > 1) stash(1, 1);
+    __syncthreads();
+    for (int tile = 0; tile < nt; tile += 2) {
+        const bool two = tile + 1 < nt;
+        if (tile + 2 < nt) fetch(tile + 2, 0);
+        if (tile + 3 < nt) fetch(tile + 3, 1);
+        walk(tile, 0);
+        if (two) walk(tile + 1, 1);
+        if (FINAL) {
+            // 16 samples per chain = one full 128-byte line, 8 lanes per row (the pair's first tile in area 0, its second in area 1)
+            __syncthreads();
+            const int ncol = two ? 2 * COSTAS_CT : COSTAS_CT;
+            const int ob = tile * COSTAS_CT;
             const int orow = lane >> 3, ocol = (lane & 7) * 2;
+            const int oh = ocol >= COSTAS_CT ? 1 : 0, oc = ocol - oh * COSTAS_CT;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int c = it * 8 + orow;
                 const long long j = (long long)(kbase + c) * L + (long long)ob + ocol;
                 if (kbase + c < K && ocol < ncol) {
-                    float2 a = tout[c][ocol], b = tout[c][ocol + 1];
+                    float2 a = tin[oh][c][oc], b = tin[oh][c][oc + 1];
                     if (j + 1 < n) *reinterpret_cast<float4 *>(y + j) = make_float4(a.x, a.y, b.x, b.y);
                     else if (j < n) y[j] = a;
                 }
             }
         }
-        if (!FINAL) amp = fmaxf(amp, fabsf(t.pp));
-        if (tile + 1 < nt) stash(cur ^ 1);
         __syncthreads();
+        if (tile + 2 < nt) stash(0, 0);
+        if (tile + 3 < nt) stash(1, 1);
+        __syncthreads();
+    }
     }
     if (mine) {
     if (FINAL) {
