@@ -1651,7 +1651,9 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
         // 1.92 instead of 2.07 ms per burst, soft symbols 1.15e-4 instead of 5.6e-5 rms from the serial trajectory (which is
         // itself 1.0e-4 from the oracle); only the first pass approximate: 1.95 ms, 7.5e-5.  (Few segments: a call of up to
         // `budget` segments closes exactly within its budget if every pass is exact, and stays that way.)
-        if (relay_quick && j.G > j.relay_budget && j.relay_w == 0) {
+        // (a plan of two passes -- segments of 49 k symbols and more: C1, C3 -- has one pass in front of its last, and walking that
+        // one in two rounds saves nothing: measured 10.2 against 9.4 ms per C3 burst)
+        if (relay_quick && j.relay_budget >= 3 && j.G > j.relay_budget && j.relay_w == 0) {
             for (int p = 0; p < 2 && p < j.relay_budget - 1; ++p) j.relay_apx[p] = p == j.relay_budget - 2 ? 2 : 1;
         }
     }
