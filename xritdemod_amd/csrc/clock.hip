@@ -1268,7 +1268,15 @@ int ClockStage::relay_plan()
 #endif
     // (without hand-off passes: two walkers per CU -- 24.8 k symbols per segment at C2, three passes; measured in the streamed
     // bench against one per CU with two passes and three per CU with four: 2.12 / 2.35 / 2.27 ms per burst)
-    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? 2 : relay_per_cu);
+    // ... and where the call is long enough for MORE walkers whose segments still hold auto_long_seg symbols -- the two-pass plan:
+    // bursts at the circuit rate, 63 M (LRIT) / 100 M (HRIT) symbols per 2^28 samples -- up to four per CU, one per SIMD: the
+    // passes' latency is a segment's length, and a two-pass plan over 62 k / 97 k-symbol segments has the same exact history
+    // as over 123 k / 195 k (C3: 6.5 instead of 9.6 ms per burst, C1: 5.7 instead of 6.2, profiles/r4_relay_shortcuts.txt))
+    int auto_per_cu = 2;
+    if (j.no_handoff && exact == 0)
+        for (int p = 4; p > 2; --p)
+            if ((long long)j.K * NS / ((long long)p * cu_count) >= auto_long_seg) { auto_per_cu = p; break; }
+    const int per_cu = j.relay_w > 0 ? relay_teams_per_cu : (j.no_handoff && !relay_per_cu_set ? auto_per_cu : relay_per_cu);
     int cps = relay_window > 0 ? relay_window : (j.K + per_cu * cu_count - 1) / (per_cu * cu_count);
     // (a call much shorter than the ~1e5 symbols two trajectories need to meet is walked front to back whatever the
     // cut: segments of at least 2048 symbols then cost the fewest passes -- a pass is a launch)
