@@ -1,5 +1,5 @@
 #!/bin/bash
-# session A/B: bench.py of another configuration under environment switches; usage: s4_ab_cfg.sh "<bench args>" "ENV=.." ...
+# A/B on one box: bench.py of another configuration under environment switches; usage: ab_bench_cfg.sh "<bench args>" "ENV=.." ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 ARGS="$1"; shift
 for cfg in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# session A/B: the streamed C2 bench under environment switches (experiments build); one line per configuration
+# A/B on one box: the streamed C2 bench under environment switches (experiments build); one line per configuration
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 for cfg in "$@"; do
   env $cfg python bench.py --steps 20 --warmup 4 --no-cpu --no-exact --no-serial-floor 2>/dev/null | python -c "
