@@ -137,11 +137,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the chain has no CPU path)")
+    # (XRIT_BENCH_SHARE_DEVICE=1, for the 1-GPU test box: the ranks share the devices there are and meet over gloo -- RCCL
+    # refuses two ranks on one device; the driver's runs never set it)
+    share = os.environ.get("XRIT_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = torch.device("cpu") if share else dev          # where the reductions' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     n_burst = 1 << args.burst_log2
     D = args.decimation
@@ -275,10 +284,10 @@ def main():
         prof = [(n, timed[n][0], timed[n][1]) if n in timed else (n, ms, c) for n, ms, c in prof]
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([float(nsym_total)], dtype=torch.float64, device=dev)
+        s = torch.tensor([float(nsym_total)], dtype=torch.float64, device=rdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         nsym_all = float(s.item())
     else:
