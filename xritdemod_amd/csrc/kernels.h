@@ -256,8 +256,10 @@ struct ClockStage {
                             // (5-6 in steady state)
     // ---- exact closure (clock_relay.h, cfg.clock_exact): segments of the call walked exactly, relayed until the
     // serial trajectory is reproduced bit for bit
-    int exact = 0;              // 0 (default): two hand-off passes, auto_passes relay passes, four more at a time while the segment
-                                // starts still move by more than auto_shift (low Es/N0), to closure when the hand-off never closed;
+    int exact = 0;              // 0 (default), by call size (ClockStage::begin): one exact walk / two hand-off passes + auto_passes relay
+                                // passes / no hand-off passes, relayed from the timing guess (bursts that fill the chip); four more passes at
+                                // a time while the segment starts still move by more than auto_shift (low Es/N0), to closure when the
+                                // hand-off never closed (cfg.clock_exact = -3 arrives here as 0 with relay_quick set);
                                 // 1: always until closed; n > 1: n relay passes, nothing else; -2: hand-off passes only (the
                                 // fast configuration: five of them, 2.6e-4 rms from the serial trajectory), relayed to closure
                                 // when they stall above auto_rms or never close (round 2's default); -1: never relayed
