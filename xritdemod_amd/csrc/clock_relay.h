@@ -78,6 +78,10 @@ struct RelayArgs {
     unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
                                   // (null: no records -- every block starts from the nominal rate)
     unsigned *simd_claim;         // [RELAY_CLAIM_WORDS] per CU: the SIMDs that hold a walker (null: roles by wave number)
+    int rec_use, rec_write;       // this pass takes its first guesses from the record of the walk before / leaves its own.  (A walk that
+                                  // started from the timing guess leaves a record that is of no use to the next pass -- the starts move
+                                  // by 4e-2 sample, five interpolator arms: 2.30 guess rounds per step with it and without --, so a plan
+                                  // without hand-off passes neither writes it in pass 0 nor streams it through LDS in pass 1.)
 };
 
 __device__ __forceinline__ bool relay_same_state(const ClockState &a, const ClockState &b)
@@ -254,8 +258,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const cf32 *xs = reinterpret_cast<const cf32 *>(a.x);
     // the record of the walk before (this call's: the flags are cleared when a call's relay starts): prev.n_done symbols,
     // read indices relative to a reference that does not depend on the pass
-    const bool use_rec = RING && a.rec != nullptr &&
-                         __builtin_amdgcn_readfirstlane((int)((prev.flags & (RELAY_WALKED | RELAY_REC)) != 0 && prev.n_done > 0)) != 0;
+    const bool use_rec = RING && a.rec != nullptr && a.rec_use &&
+                         __builtin_amdgcn_readfirstlane((int)((prev.flags & RELAY_REC) != 0 && prev.n_done > 0)) != 0;
     const int n_rec = __builtin_amdgcn_readfirstlane(prev.n_done);
     const int ref = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii)) -
                     RELAY_REF_MARGIN;
@@ -461,7 +465,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 if (softs) softs[o] = p0.x;
                 if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
             }
-            if (RING && recs) {
+            if (RING && recs && a.rec_write) {
                 const unsigned rel = (unsigned)(cii - ref);
                 recs[o] = rel < (1u << 24) ? (rel << 8) | (unsigned)carm : RELAY_NOGUESS;
             }
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         RelaySeg st0{};
         st0.s = T0;
         st0.n_done = n;                 // symbols the record holds
-        st0.flags = apx ? (RELAY_APPROX | (apx == 2 ? RELAY_REC : 0)) : RELAY_WALKED;
+        st0.flags = apx ? (RELAY_APPROX | (apx == 2 && a.rec_write ? RELAY_REC : 0)) : (RELAY_WALKED | (a.rec_write ? RELAY_REC : 0));
         a.start[s] = st0;
         RelaySeg e{};
         e.s = T;
