@@ -2,7 +2,7 @@
 # A/B on one box: the streamed C2 bench under environment switches (experiments build); one line per configuration
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 for cfg in "$@"; do
-  env $cfg python bench.py --steps 20 --warmup 4 --no-cpu --no-exact --no-serial-floor 2>/dev/null | python -c "
+  env $cfg python bench.py $XARGS --steps 20 --warmup 5 --no-cpu --no-exact --no-serial-floor 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['kernels']
