@@ -1353,6 +1353,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
         ProfScope ps(prof, "clock_relay", s);
         for (int q = 0; q < count && j.relay_enq < limit; ++q, ++j.relay_enq) {
             const int apx = j.relay_enq < 2 ? j.relay_apx[j.relay_enq] : 0;      // (the LDS-staged one-wave walker only)
+            a.sym_skip = j.no_handoff && j.relay_enq == 0 && limit >= 2 && !apx;
             a.rec_write = !(j.no_handoff && j.relay_enq == 0);
             a.rec_use = !(j.no_handoff && j.relay_enq == 1);
 #ifdef XRIT_EXPERIMENTS

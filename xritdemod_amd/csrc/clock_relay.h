@@ -78,6 +78,8 @@ struct RelayArgs {
     unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
                                   // (null: no records -- every block starts from the nominal rate)
     unsigned *simd_claim;         // [RELAY_CLAIM_WORDS] per CU: the SIMDs that hold a walker (null: roles by wave number)
+    int sym_skip;                 // this pass's walks from a GUESS (every segment but the first of a plan without hand-off passes, in its
+                                  // first pass) store no symbols and do not count as walked: the next pass walks them again whatever its starts
     int rec_use, rec_write;       // this pass takes its first guesses from the record of the walk before / leaves its own.  (A walk that
                                   // started from the timing guess leaves a record that is of no use to the next pass -- the starts move
                                   // by 4e-2 sample, five interpolator arms: 2.30 guess rounds per step with it and without --, so a plan
@@ -326,6 +328,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             atomicAdd(&a.changed[RELAY_STAT * pass + 6], 1u);
         }
     }
+    const bool quiet = a.sym_skip != 0 && s > 0;
     const ClockState T0 = T;
     // (the integer model is a guess generator, not the arithmetic: the gains folded into one factor each, the lattice
     // steps -- powers of two, float32 spacings -- as shifts)
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         if (pass == 0 && lane < nv) { m1 += fabsf(p0.x); m2 += p0.x * p0.x; }
         if (lane < nv && apx != 1) {
             const int o = n + lane;
-            if (o < n_out && !apx) {
+            if (o < n_out && !apx && !quiet) {
                 if (softs) softs[o] = p0.x;
                 if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
             }
@@ -519,7 +522,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         RelaySeg st0{};
         st0.s = T0;
         st0.n_done = n;                 // symbols the record holds
-        st0.flags = apx ? (RELAY_APPROX | (apx == 2 && a.rec_write ? RELAY_REC : 0)) : (RELAY_WALKED | (a.rec_write ? RELAY_REC : 0));
+        st0.flags = (apx || quiet) ? (RELAY_APPROX | (apx == 2 && a.rec_write ? RELAY_REC : 0)) : (RELAY_WALKED | (a.rec_write ? RELAY_REC : 0));
         a.start[s] = st0;
         RelaySeg e{};
         e.s = T;
