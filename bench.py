@@ -215,7 +215,14 @@ def main():
         return dem.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
 
     soft1 = None
+    # (the warm-up steps are fed like the timed ones -- the next warm-up burst registered ahead -- so that both sets of the
+    # handle's buffers exist before the clock starts; the last warm-up step has nothing registered behind it: the timed region
+    # begins on an empty pipeline)
+    if not args.no_prefetch and W > 0:
+        dem.prefetch_device(bursts[0].data_ptr(), n_burst, stream=stream.cuda_stream)
     for b in range(W):
+        if not args.no_prefetch and b + 1 < W:
+            dem.prefetch_device(bursts[(b + 1) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
         ns = step(b)
         if b == 0:
             soft0 = soft[:ns].clone()

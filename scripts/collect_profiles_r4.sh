@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_c2.json 2> $OUT/bench_c2.err      # (the driver's command)
 python bench.py --no-prefetch --no-cpu --no-exact > $OUT/bench_c2_noprefetch.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 # kernel statistics over 20 streamed steps (beside), and one burst at a time (alone)
