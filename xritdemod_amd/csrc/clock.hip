@@ -1373,9 +1373,10 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
             else if (j.sym) hipLaunchKernelGGL((clock_relay_kernel<true, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span, apx);
             else hipLaunchKernelGGL((clock_relay_kernel<false, false>), dim3(j.G), dim3(64), 0, s, a, j.relay_enq, span, apx);
         }
-        // (256 threads: a block of 1024 needs sixteen free wave slots on one CU and, with the next burst's front end filling
-        // the chip behind the relay, waited ~90 us for them)
-        hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(256), 0, s, a.ends[0], a.ends[1], changed,
+        // (ONE wave: a block of 1024 needs sixteen free wave slots on one CU and, with the next burst's front end filling
+        // the chip behind the relay, waited ~90 us for them; four waves still waited 75 us behind the 2.4 ms matched filter
+        // of a burst at the circuit rate, profiles/r4_c1_kernel_stats.csv)
+        hipLaunchKernelGGL(clock_relay_finalize_kernel, dim3(1), dim3(64), 0, s, a.ends[0], a.ends[1], changed,
                            j.relay_enq, j.G, j.cps * NS, st.as<ClockState>() + cur, st.as<ClockState>() + (cur ^ 1),
                            clock_res(counters), a.x, tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), j.relay_force ? 1 : 0,
                            a.moments);
@@ -1629,7 +1630,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     XR_TRY(work.reserve((size_t)(3 * nbN + 8) * sizeof(AffMap)));
     {
         const size_t nw = div_up((size_t)K, 64);
-        XR_TRY(wsolve.reserve((nw + 2) * sizeof(AffMap) + (nw / 16 + 2) * sizeof(NewtonStat) + 64));
+        XR_TRY(wsolve.reserve(newton_waves_bytes(nw)));
         j.gated = force_gated;
         j.mean_j = jmean_valid && jmean_ns == NS && K >= 256 && !force_gated && !no_meanj;
     }

@@ -802,7 +802,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     XR_TRY(work.reserve(agg_bytes + (size_t)K * sizeof(double)));
     {
         const size_t nw = div_up((size_t)K, 64);
-        XR_TRY(wsolve.reserve((nw + 2) * sizeof(AffMap) + (nw / 16 + 2) * sizeof(NewtonStat) + 64));
+        XR_TRY(wsolve.reserve(newton_waves_bytes(nw)));
         job.gated = force_gated;
     }
     double *th2 = reinterpret_cast<double *>(work.as<char>() + agg_bytes);

@@ -449,9 +449,39 @@ __device__ __forceinline__ void newton_wave_aggregate(AffMap e, int w, AffMap *a
     if ((threadIdx.x & 63) == 0) aggs[w] = e;
 }
 
+// Calls of more than NEWTON_WAVES_TWO_LEVEL wave aggregates (bursts at the circuit rate: 16 k of them) take the composition
+// in front of every workgroup from ONE scan (this kernel) instead of every workgroup scanning all aggregates in front of it
+// -- that is quadratic in the call's length: 0.12 - 0.33 ms per solve at C1 / C3 (profiles/r4_c3_kernel_stats.csv).
+constexpr int NEWTON_WAVES_TWO_LEVEL = 4096;
+template <int UNUSED = 0>       // (a template: the header is included by two translation units)
+__global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_wave_prefix_kernel(const AffMap *__restrict__ aggs, int nw,
+                                                                               AffMap *__restrict__ wgpre, const int *ctl)
+{
+    __shared__ AffMap buf[NEWTON_WAVES_BLOCK];
+    __shared__ int skip;
+    if (threadIdx.x == 0) skip = ctl[0] || ctl[NEWTON_CTL_TAKEOVER];
+    __syncthreads();
+    if (skip) return;
+    const int run = (nw + NEWTON_WAVES_BLOCK - 1) / NEWTON_WAVES_BLOCK;
+    {
+        const int b0 = (int)threadIdx.x * run, b1 = min(nw, b0 + run);
+        AffMap v = aff_identity();
+        for (int b = b0; b < b1; ++b) v = aff_combine(v, aggs[b]);
+        aff_block_scan<NEWTON_WAVES_BLOCK>(v, buf);              // buf[t] = aggregates [0, (t + 1) run)
+    }
+    const int nwg = (nw + NEWTON_WAVES_PER_BLOCK - 1) / NEWTON_WAVES_PER_BLOCK;
+    for (int g = (int)threadIdx.x; g < nwg; g += NEWTON_WAVES_BLOCK) {
+        const int w0 = g * NEWTON_WAVES_PER_BLOCK, t0 = w0 / run;
+        AffMap pre = t0 > 0 ? buf[t0 - 1] : aff_identity();
+        for (int b = t0 * run; b < w0; ++b) pre = aff_combine(pre, aggs[b]);
+        wgpre[g] = pre;                                         // aggregates [0, first wave of workgroup g)
+    }
+}
+
 template <typename P>
 __global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(P p, long long n, const AffMap *aggs,
-                                                                               int *ctl, NewtonStat *slots)
+                                                                               int *ctl, NewtonStat *slots,
+                                                                               const AffMap *wgpre)
 {
     __shared__ AffMap buf[NEWTON_WAVES_BLOCK];
     __shared__ NewtonStat wst[NEWTON_WAVES_PER_BLOCK];
@@ -474,7 +504,7 @@ __global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(
     const int nw = (int)((n + 63) / 64);
     const int need = min(nw, w0 + NEWTON_WAVES_PER_BLOCK);      // aggregates [0, need) are looked at
     const int run = (need + NEWTON_WAVES_BLOCK - 1) / NEWTON_WAVES_BLOCK;
-    {
+    if (wgpre == nullptr) {
         const int b0 = (int)threadIdx.x * run, b1 = min(need, b0 + run);
         AffMap v = aff_identity();
         for (int b = b0; b < b1; ++b) v = aff_combine(v, aggs[b]);
@@ -482,9 +512,16 @@ __global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(
     }
     NewtonStat st{0u, 0u, 0u, 0.f, 0ull};
     if ((long long)w * 64 < n) {
-        const int t0 = w / run;                                 // run that holds aggregate w
-        AffMap pre = t0 > 0 ? buf[t0 - 1] : aff_identity();
-        for (int b = t0 * run; b < w; ++b) pre = aff_combine(pre, aggs[b]);
+        AffMap pre;
+        if (wgpre != nullptr) {
+            // (long calls: what is in front of the workgroup comes from newton_wave_prefix_kernel)
+            pre = wgpre[blockIdx.x];
+            for (int b = w0; b < w; ++b) pre = aff_combine(pre, aggs[b]);
+        } else {
+            const int t0 = w / run;                             // run that holds aggregate w
+            pre = t0 > 0 ? buf[t0 - 1] : aff_identity();
+            for (int b = t0 * run; b < w; ++b) pre = aff_combine(pre, aggs[b]);
+        }
         const AffMap e = k < n ? newton_element(p, el, false) : aff_identity();
         const AffMap inc = aff_wave_scan(e);
         AffMap ex = aff_shfl_up(inc, 1);
@@ -555,6 +592,11 @@ __global__ void __launch_bounds__(NEWTON_WAVES_BLOCK) newton_apply_waves_kernel(
 }
 
 static inline int newton_waves(long long n) { return (int)((n + 63) / 64); }
+// storage of the wave-aligned solve for nw wave aggregates: the aggregates, the statistics slots, the workgroup prefixes
+static inline size_t newton_waves_bytes(size_t nw)
+{
+    return (nw + 2) * sizeof(AffMap) + (nw / 16 + 4) * sizeof(NewtonStat) + (nw / 16 + 4) * sizeof(AffMap) + 64;
+}
 // storage: newton_waves(n) AffMaps (aggregates) and newton_waves(n) / 16 + 1 NewtonStat slots
 template <typename P>
 static inline void newton_apply_waves(const P &p, long long n, const AffMap *aggs, int *ctl, NewtonStat *slots,
@@ -562,8 +604,15 @@ static inline void newton_apply_waves(const P &p, long long n, const AffMap *agg
 {
     if (n <= 0) return;
     const int nw = newton_waves(n);
-    hipLaunchKernelGGL(newton_apply_waves_kernel<P>, dim3((nw + NEWTON_WAVES_PER_BLOCK - 1) / NEWTON_WAVES_PER_BLOCK),
-                       dim3(NEWTON_WAVES_BLOCK), 0, s, p, n, aggs, ctl, slots);
+    const int nwg = (nw + NEWTON_WAVES_PER_BLOCK - 1) / NEWTON_WAVES_PER_BLOCK;
+    const AffMap *wgpre = nullptr;
+    if (nw > NEWTON_WAVES_TWO_LEVEL) {
+        // (behind the statistics slots: newton_waves_bytes() holds room for it)
+        AffMap *wp = reinterpret_cast<AffMap *>(slots + nwg + 2);
+        hipLaunchKernelGGL(newton_wave_prefix_kernel<0>, dim3(1), dim3(NEWTON_WAVES_BLOCK), 0, s, aggs, nw, wp, (const int *)ctl);
+        wgpre = wp;
+    }
+    hipLaunchKernelGGL(newton_apply_waves_kernel<P>, dim3(nwg), dim3(NEWTON_WAVES_BLOCK), 0, s, p, n, aggs, ctl, slots, wgpre);
 }
 
 static inline int newton_blocks(long long n) { return (int)((n + NEWTON_TILE - 1) / NEWTON_TILE); }
