@@ -215,32 +215,44 @@ __global__ void __launch_bounds__(256) agc_apply_runs_kernel(const float2 *__res
 
 // Without a decimator in front nobody hands the run maps over: one read-only sweep composes them (a wave per
 // run of 64 * PL samples), the matched filter then applies the gains in its window fill as in the fused path.
+// (a wave takes AGC_RUNS_PER_WAVE consecutive runs, all their loads in flight before the first map is composed: one run per
+// wave was a launch of 1.4 M waves of ~110 instructions each at the circuit rate -- 0.66 ms for 2.1 GB, 3.2 TB/s)
+constexpr int AGC_RUNS_PER_WAVE = 4;
 template <int PL>
 __global__ void __launch_bounds__(256) agc_run_maps_kernel(const float2 *__restrict__ x, AgcMap *__restrict__ maps,
                                                            float *__restrict__ state_out, float rate, float ref,
                                                            float maxg, long long n)
 {
     const int lane = threadIdx.x & 63;
-    const long long run = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long i0 = run * (64 * PL) + (long long)lane * PL;
-    int cnt = 0;
-    if (i0 < n) cnt = (int)((n - i0) < PL ? (n - i0) : PL);
-    float2 v[PL];
+    const long long run0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * AGC_RUNS_PER_WAVE;
+    float2 v[AGC_RUNS_PER_WAVE][PL];
 #pragma unroll
-    for (int k = 0; k < PL; ++k) v[k] = x[min(i0 + k, n - 1)];
-    AgcMap m = agc_identity();
+    for (int r = 0; r < AGC_RUNS_PER_WAVE; ++r) {
+        const long long i0 = (run0 + r) * (64 * PL) + (long long)lane * PL;
+#pragma unroll
+        for (int k = 0; k < PL; ++k) v[r][k] = x[min(i0 + k, n - 1)];
+    }
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < PL; ++k) {
-        if (k < cnt) {
-            const AgcMap e = agc_sample_map(v[k].x, v[k].y, rate, ref, maxg);
-            bad |= !(e.a >= 0.0f);
-            m = agc_compose(m, e);
+    for (int r = 0; r < AGC_RUNS_PER_WAVE; ++r) {
+        const long long run = run0 + r;
+        if (run * (64 * PL) >= n) break;                       // wave-uniform
+        const long long i0 = run * (64 * PL) + (long long)lane * PL;
+        int cnt = 0;
+        if (i0 < n) cnt = (int)((n - i0) < PL ? (n - i0) : PL);
+        AgcMap m = agc_identity();
+#pragma unroll
+        for (int k = 0; k < PL; ++k) {
+            if (k < cnt) {
+                const AgcMap e = agc_sample_map(v[r][k].x, v[r][k].y, rate, ref, maxg);
+                bad |= !(e.a >= 0.0f);
+                m = agc_compose(m, e);
+            }
         }
+        m = agc_wave_total(m);
+        if (lane == 0) maps[run] = m;
     }
     if (bad) state_out[1] = 1.0f;
-    m = agc_wave_total(m);
-    if (lane == 0 && run * (64 * PL) < n) maps[run] = m;
 }
 
 int AgcStage::fused_reduce(const float2 *in, size_t n, int per_lane, hipStream_t s, Profiler *prof)
@@ -252,7 +264,7 @@ int AgcStage::fused_reduce(const float2 *in, size_t n, int per_lane, hipStream_t
     const size_t rl = (size_t)64 * per_lane;
     const unsigned nr = div_up(n, rl);
     ProfScope ps(prof, "agc_reduce", s);
-    hipLaunchKernelGGL(agc_run_maps_kernel<3>, dim3(div_up((size_t)nr, 4)), dim3(256), 0, s, in, epi.maps, epi.state_out,
+    hipLaunchKernelGGL(agc_run_maps_kernel<3>, dim3(div_up((size_t)nr, 4 * AGC_RUNS_PER_WAVE)), dim3(256), 0, s, in, epi.maps, epi.state_out,
                        rate, ref, maxg, (long long)n);
     XR_HIP(hipGetLastError());
     return XRIT_OK;
