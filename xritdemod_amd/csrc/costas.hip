@@ -838,7 +838,8 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
                 hipLaunchKernelGGL(costas_head_kernel, dim3(1), dim3(1), 0, s, st, S.as<float2>(), st_in, K, L, gains,
                                    COSTAS_HEAD);
         }
-        if (model_step && !job.gated && K > 2 && (rpc & 1) == 0 && rpc <= 120) {
+        // (64 rows of rpc + 1 pairs: within the 48 KB of dynamic LDS a launch gets without asking)
+        if (model_step && !job.gated && K > 2 && (rpc & 1) == 0 && rpc <= 92) {
             // one Newton step on the sub-block model of the loop (costas_model_pass_kernel)
             ProfScope ps(prof, "costas_model", s);
             CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), costas_cnt(counters, max_passes),
