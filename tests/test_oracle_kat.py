@@ -597,3 +597,44 @@ def test_oracle_built_with_fma_contraction_is_another_1e_4_away(oracle_mod, tmp_
     assert np.array_equal(np.sign(fma[big]), np.sign(base[big]))
     r = rms(fma - base)
     assert 1e-6 < r < 4e-4, r
+
+
+def test_costas_sub_block_model_follows_the_loop(oracle_mod):
+    """The model behind csrc/costas.hip's costas_model_pass_kernel, restated in numpy against the
+    oracle's own loop: over a run of R = 8 samples the loop's summed detector is 1/2 Im(sum z^2 e^{-2j phi_mid}) and the R
+    per-sample updates collapse to  f += beta e,  phi += R f + (alpha + beta (R + 1) / 2) e.  Run serially over the stream
+    from a chain in lock, the recurrence must stay within 1e-3 rad rms (measured 4e-4) of the loop's phase at the chain
+    boundaries -- an order of magnitude closer than the block averages (2e-2) the device's Newton iteration used to start from."""
+    o = oracle_mod
+    fs, D, L, R = 6.25e6, 5, 256, 8
+    x = synth_signal(1 << 21, fs_in=fs)
+    dem = o.Demod(o.config("lrit", fs, D))
+    dem.process(x)
+    z = dem.stage("rrc").astype(np.complex128)
+    y = dem.stage("costas").astype(np.complex128)
+    phi = np.angle(z * np.conj(y))                       # the loop's phase at every sample (mod 2 pi)
+    K = len(z) // L
+    lb = 0.0037
+    den = 1 + 2 * (np.sqrt(2) / 2) * lb + lb * lb
+    alpha, beta = 4 * (np.sqrt(2) / 2) * lb / den, 4 * lb * lb / den
+    z2 = z * z
+
+    def wrap(v):
+        return (v + np.pi / 2) % np.pi - np.pi / 2       # the loop is pi-periodic in phase
+
+    th2 = np.unwrap(np.angle(z2[:K * L].reshape(K, L).sum(1)))
+    k0 = 60                                              # in lock
+    guess = 0.25 * (th2[k0 - 1] + th2[k0])
+    s = z2[:(len(z) // R) * R].reshape(-1, R).sum(1)
+    p, f = guess, 0.5 * (th2[k0 + 1] - th2[k0 - 2]) / (3 * L)
+    err_model, err_avg = [], []
+    for k in range(k0, K):
+        if k >= k0 + 40:                                 # the model has forgotten the guess it started from
+            err_model.append(wrap(p - phi[k * L]))
+            err_avg.append(wrap(0.25 * (th2[k - 1] + th2[k]) - phi[k * L]))
+        for b in range(k * L // R, (k + 1) * L // R):
+            e = 0.5 * np.imag(s[b] * np.exp(-2j * (p + f * (R - 1) * 0.5)))
+            p, f = p + R * f + (alpha + beta * (R + 1) * 0.5) * e, f + beta * e
+    r_model, r_avg = float(np.sqrt(np.mean(np.square(err_model)))), float(np.sqrt(np.mean(np.square(err_avg))))
+    assert len(err_model) > 1000
+    assert r_model <= 1e-3 and r_avg >= 10 * r_model, (r_model, r_avg)
