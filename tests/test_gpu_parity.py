@@ -1579,6 +1579,32 @@ def test_noisy_hrit_calls_of_a_few_hundred_chains_close(xa, oracle_mod, D, n, se
     check_symbols(np.concatenate(got), np.concatenate(want), rms_tol=1e-4)
 
 
+def test_tracking_costas_loop_closes_in_one_pass(xa, oracle_mod):
+    """Round 4: a Newton step on the model of the loop over runs of 8 samples (costas_model_pass_kernel) refines the block-average
+    guesses, and a TRACKING loop -- the call before closed in the minimum number of passes -- is then one pass over the samples
+    and the final pass (accepted on prediction, verified behind the final pass).  The de-rotated stream of those calls is as
+    close to the oracle's as that of the two-pass calls; a chain length with an odd number of runs has no model step and
+    keeps its two passes."""
+    fs, D, n = 6.25e6, 5, 400000
+    x = synth.generate(synth.SynthParams(fs_in=fs), 6 * n)
+    for L, want_passes in ((0, 1), (200, 2)):
+        od = oracle_mod.Demod(oracle_mod.config("lrit", fs, D))
+        gd = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, costas_chain_len=L))
+        gd.keep_stages(True)
+        passes = []
+        for i in range(6):
+            w, g = od.process(x[i * n:(i + 1) * n]), gd.process(x[i * n:(i + 1) * n])
+            st = gd.stats()
+            passes.append(st.costas_passes)
+            assert st.costas_unconverged == 0
+            a, b = od.stage("costas"), gd.stage("costas")
+            assert len(a) == len(b) and rms(a - b) <= 2e-6 and np.abs(a - b).max() <= 5e-5, (L, i, rms(a - b))
+            # (calls of 19 k symbols are ONE exact walk: what they show against the oracle is the float32 M&M's own floor on a
+            # short call, 0.6e-4 .. 2e-4 from call to call)
+            check_symbols(g, w, rms_tol=5e-4 if i == 0 else 3.2e-4)
+        assert passes[0] >= 2 and all(p == want_passes for p in passes[2:]), (L, passes)
+
+
 def test_mid_stream_jump_after_the_spare_pass_was_dropped(xa, oracle_mod):
     """After two calls that closed inside their batch with the same count the Costas stage stops enqueueing its spare
     pass.  A carrier / phase / timing jump in a later call then needs more passes than are queued: the call goes on
