@@ -408,7 +408,7 @@ def main():
         "fp32_flops_per_sample": round(flops_per_sample, 1),
         "read_bw_measured_gbs": None if read_bw is None else round(read_bw, 1),
         "loop_passes": {"costas": st.costas_passes, "clock": st.clock_passes, "clock_relay": st.clock_relay_passes,
-                        "clock_relay_closed": st.clock_relay_closed,
+                        "clock_relay_closed": st.clock_relay_closed, "clock_relay_segments": int(st.clock_relay_segments),
                         "costas_unconverged": st.costas_unconverged, "clock_open_large": st.clock_open_large,
                         "clock_boundaries_at_the_floor": st.clock_unconverged},
     }
