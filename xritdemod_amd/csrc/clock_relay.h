@@ -167,6 +167,7 @@ constexpr int RELAY_XMIR = 8;        // the ring's first samples again behind it
 constexpr int RELAY_GR = 1024;       // ring of first guesses (symbols), refilled RELAY_GCH at a time
 constexpr int RELAY_GCH = 256;
 constexpr unsigned RELAY_NOGUESS = 0xffffffffu;
+constexpr unsigned RELAY_NOPOS = 0x80000000u;     // record of the one-wave walker: no position
 constexpr int RELAY_REF_MARGIN = 1 << 20;     // a segment's reference index sits this far in front of its nominal start
 
 // RING: two waves per workgroup, samples through the LDS ring (span = samples a block of 64 symbols can cover
@@ -263,8 +264,9 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const bool use_rec = RING && a.rec != nullptr && a.rec_use &&
                          __builtin_amdgcn_readfirstlane((int)((prev.flags & RELAY_REC) != 0 && prev.n_done > 0)) != 0;
     const int n_rec = __builtin_amdgcn_readfirstlane(prev.n_done);
-    const int ref = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii)) -
-                    RELAY_REF_MARGIN;
+    // (the segment's nominal start: does not depend on the pass)
+    const int base = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii));
+    const int w20 = (int)rintf(a.par.omega_mid * 1048576.0f);
     unsigned *recs = a.rec ? a.rec + obase : nullptr;
 
     if (RING && role == 1) {
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
 #pragma unroll
                 for (int q = 0; q < RELAY_GCH / 64; ++q) {
                     const int m = g_hi + lane + 64 * q;
-                    vg[q] = m < n_rec ? recs[m] : RELAY_NOGUESS;
+                    vg[q] = m < n_rec ? recs[m] : RELAY_NOPOS;
                 }
 #pragma unroll
                 for (int q = 0; q < RELAY_GCH / 64; ++q) gr[(g_hi + lane + 64 * q) & (RELAY_GR - 1)] = vg[q];
@@ -389,10 +391,25 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         if (lane == 0) cmu = T.mu;
         carm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
         if (use_rec) {
+            // The record holds where the walk before had symbol n + lane: its position in units of 2^-20 sample, as the
+            // difference from the nominal one (symbol number x omega_mid behind the segment's nominal start) -- 32 bits.  This
+            // walk's trajectory runs beside that one at a distance that changes slowly (they are merging): the distance at
+            // lane 0, where this walk's state is known exactly, is added to every lane's recorded position.  (Round 4, late:
+            // with (index, arm) records a walk whose start had moved by half an arm re-interpolated every block of its
+            // segment -- 2.0 guess rounds per step where the others took 1.1, and the pass waits for its slowest walker.)
             const unsigned g = gr[(n + lane) & (RELAY_GR - 1)];
-            if (g != RELAY_NOGUESS && lane != 0) {
-                cii = ref + (int)(g >> 8);
-                carm = min((int)(g & 0xffu), XR_MM_NSTEPS);
+            const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+            if (g0 != RELAY_NOPOS) {
+                const long long prec = (long long)(int)g + (long long)(n + lane) * (long long)w20;
+                const int plo = __builtin_amdgcn_readfirstlane((int)(unsigned)(prec & 0xffffffffLL));
+                const int phi = __builtin_amdgcn_readfirstlane((int)(prec >> 32));
+                const long long prec0 = ((long long)phi << 32) | (long long)(unsigned)plo;
+                const long long pnow0 = ((long long)(ii0 - base) << 20) + (long long)(int)(T.mu * 1048576.0f);
+                const long long pg = prec + (pnow0 - prec0);
+                if (g != RELAY_NOPOS && lane != 0) {
+                    cii = base + (int)(pg >> 20);
+                    carm = ((int)(pg & 0xfffffLL) + 4096) >> 13;
+                }
             }
         }
         RELAY_TICK(1);
@@ -469,8 +486,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
             }
             if (RING && recs && a.rec_write) {
-                const unsigned rel = (unsigned)(cii - ref);
-                recs[o] = rel < (1u << 24) ? (rel << 8) | (unsigned)carm : RELAY_NOGUESS;
+                const long long pw = ((long long)(cii - base) << 20) + (long long)(int)(cmu * 1048576.0f) - (long long)o * (long long)w20;
+                recs[o] = (pw > -(1LL << 30) && pw < (1LL << 30)) ? (unsigned)(int)pw : RELAY_NOPOS;
             }
         }
         if (nv > 0) {
