@@ -80,10 +80,7 @@ struct RelayArgs {
     unsigned *simd_claim;         // [RELAY_CLAIM_WORDS] per CU: the SIMDs that hold a walker (null: roles by wave number)
     int sym_skip;                 // this pass's walks from a GUESS (every segment but the first of a plan without hand-off passes, in its
                                   // first pass) store no symbols and do not count as walked: the next pass walks them again whatever its starts
-    int rec_use, rec_write;       // this pass takes its first guesses from the record of the walk before / leaves its own.  (A walk that
-                                  // started from the timing guess leaves a record that is of no use to the next pass -- the starts move
-                                  // by 4e-2 sample, five interpolator arms: 2.30 guess rounds per step with it and without --, so a plan
-                                  // without hand-off passes neither writes it in pass 0 nor streams it through LDS in pass 1.)
+    int rec_use, rec_write;       // this pass takes its first guesses from the record of the walk before / leaves its own
 };
 
 __device__ __forceinline__ bool relay_same_state(const ClockState &a, const ClockState &b)
@@ -264,9 +261,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const bool use_rec = RING && a.rec != nullptr && a.rec_use &&
                          __builtin_amdgcn_readfirstlane((int)((prev.flags & RELAY_REC) != 0 && prev.n_done > 0)) != 0;
     const int n_rec = __builtin_amdgcn_readfirstlane(prev.n_done);
-    // (the segment's nominal start: does not depend on the pass)
-    const int base = __builtin_amdgcn_readfirstlane((int)(s == 0 ? a.first[0].ii : a.S[min(s * a.cps, a.K - 1)].ii));
-    const int w20 = (int)rintf(a.par.omega_mid * 1048576.0f);
+    // (the nominal period the records are relative to: does not depend on the pass)
+    const int wnom = (int)(a.par.omega_mid * 16777216.0f), wint_n = wnom >> 24, wfrac_n = wnom & 0xffffff;
     unsigned *recs = a.rec ? a.rec + obase : nullptr;
 
     if (RING && role == 1) {
@@ -331,6 +327,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         }
     }
     const bool quiet = a.sym_skip != 0 && s > 0;
+    // (kernel arguments used inside the walk are taken once: behind the hand-written LDS traffic the compiler reloads them)
+    const bool rec_write = __builtin_amdgcn_readfirstlane(a.rec_write) != 0;
     const ClockState T0 = T;
     // (the integer model is a guess generator, not the arithmetic: the gains folded into one factor each, the lattice
     // steps -- powers of two, float32 spacings -- as shifts)
@@ -346,6 +344,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     unsigned steps = 0, rounds_total = 0;
     bool exhausted = false, stuck = false;
     int x_hi = x_lo, g_hi = 0;           // what the rings are known to hold (asked again only when that is not enough)
+    float rec_slope = 0.0f;              // how much further than the recorded walk this one advanced per symbol over the block before (2^-24 sample)
     float m1 = 0.f, m2 = 0.f;            // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -390,26 +389,30 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         cmu = (float)(fr0 & 0xffffff) * (1.0f / 16777216.0f);
         if (lane == 0) cmu = T.mu;
         carm = (int)rintf(cmu * (float)XR_MM_NSTEPS);
+        int rinc = 0;                  // recorded advances summed up to and including this lane (blocks that guess from the record)
+        bool rec_block = false;
         if (use_rec) {
-            // The record holds where the walk before had symbol n + lane: its position in units of 2^-20 sample, as the
-            // difference from the nominal one (symbol number x omega_mid behind the segment's nominal start) -- 32 bits.  This
-            // walk's trajectory runs beside that one at a distance that changes slowly (they are merging): the distance at
-            // lane 0, where this walk's state is known exactly, is added to every lane's recorded position.  (Round 4, late:
-            // with (index, arm) records a walk whose start had moved by half an arm re-interpolated every block of its
-            // segment -- 2.0 guess rounds per step where the others took 1.1, and the pass waits for its slowest walker.)
+            // The record holds, per symbol, how far the walk before ADVANCED behind it (omega + gain_mu mm, as the difference
+            // from the nominal period, units of 2^-24 sample: 32 bits).  Summed over the lanes in front (one more prefix sum)
+            // and anchored at this walk's own state at lane 0, that is where the symbols sat relative to one another -- this
+            // walk's trajectory runs beside that one at a distance that changes slowly (they are merging: a damped
+            // oscillation, smooth over 64 symbols), so the rate at which the distance changed over the block before is added
+            // as a slope.  (Round 4, late.  With (index, arm) records a walk whose start had moved by half an arm
+            // re-interpolated every block of its segment, 2.0 guess rounds per step where the others took 1.1 -- and a pass
+            // waits for its slowest walker; and the record of a walk from the timing guess, five arms away, was of no use at
+            // all: 2.30 rounds per step in the second pass, now 1.3.)
             const unsigned g = gr[(n + lane) & (RELAY_GR - 1)];
-            const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-            if (g0 != RELAY_NOPOS) {
-                const long long prec = (long long)(int)g + (long long)(n + lane) * (long long)w20;
-                const int plo = __builtin_amdgcn_readfirstlane((int)(unsigned)(prec & 0xffffffffLL));
-                const int phi = __builtin_amdgcn_readfirstlane((int)(prec >> 32));
-                const long long prec0 = ((long long)phi << 32) | (long long)(unsigned)plo;
-                const long long pnow0 = ((long long)(ii0 - base) << 20) + (long long)(int)(T.mu * 1048576.0f);
-                const long long pg = prec + (pnow0 - prec0);
-                if (g != RELAY_NOPOS && lane != 0) {
-                    cii = base + (int)(pg >> 20);
-                    carm = ((int)(pg & 0xfffffLL) + 4096) >> 13;
+            rec_block = !__any(g == RELAY_NOPOS);
+            if (rec_block) {
+                rinc = relay_scan((int)g, lane);
+                const int rex = rinc - (int)g;
+                const int frg = mu0u + lane * wfrac_n + rex + (int)rintf(rec_slope * (float)lane);
+                if (lane != 0) {
+                    cii = ii0 + lane * wint_n + (frg >> 24);
+                    carm = ((frg & 0xffffff) + (1 << 16)) >> 17;
                 }
+            } else {
+                rec_slope = 0.0f;
             }
         }
         RELAY_TICK(1);
@@ -485,9 +488,10 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
                 if (softs) softs[o] = p0.x;
                 if (SYM && syms) syms[o] = make_float2(p0.x, p0.y);
             }
-            if (RING && recs && a.rec_write) {
-                const long long pw = ((long long)(cii - base) << 20) + (long long)(int)(cmu * 1048576.0f) - (long long)o * (long long)w20;
-                recs[o] = (pw > -(1LL << 30) && pw < (1LL << 30)) ? (unsigned)(int)pw : RELAY_NOPOS;
+            if (RING && recs && rec_write) {
+                // (this symbol's advance: the lane's own literal step, already verified)
+                const int dev = (((int)st.ii - cii - wint_n) << 24) + ((int)(st.mu * 16777216.0f) - (int)(cmu * 16777216.0f)) - wfrac_n;
+                recs[o] = (unsigned)dev != RELAY_NOPOS ? (unsigned)dev : 0u;
             }
         }
         if (nv > 0) {
@@ -500,6 +504,12 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             nt.p1 = cf32{relay_lane(st.p1.x, src), relay_lane(st.p1.y, src)};
             nt.c0 = cf32{relay_lane(st.c0.x, src), relay_lane(st.c0.y, src)};
             nt.c1 = cf32{relay_lane(st.c1.x, src), relay_lane(st.c1.y, src)};
+            if (rec_block) {
+                // (what this walk advanced over the block beyond what the record said, per symbol: the next block's slope)
+                const int act = (((int)nt.ii - ii0 - nv * wint_n) << 24) + ((int)(nt.mu * 16777216.0f) - mu0u) - nv * wfrac_n;
+                const float over = (float)(act - __builtin_amdgcn_readlane(rinc, src));
+                rec_slope = nv == 64 ? over * (1.0f / 64.0f) : over / (float)nv;
+            }
             T = nt;
             n += nv;
             if (RING && lane == 0) { relay_st(&sh_pos_ii, (int)T.ii); relay_st(&sh_pos_n, n); }
@@ -539,7 +549,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
         RelaySeg st0{};
         st0.s = T0;
         st0.n_done = n;                 // symbols the record holds
-        st0.flags = (apx || quiet) ? (RELAY_APPROX | (apx == 2 && a.rec_write ? RELAY_REC : 0)) : (RELAY_WALKED | (a.rec_write ? RELAY_REC : 0));
+        st0.flags = (apx || quiet) ? (RELAY_APPROX | ((apx == 2 || !apx) && rec_write ? RELAY_REC : 0)) : (RELAY_WALKED | (rec_write ? RELAY_REC : 0));
         a.start[s] = st0;
         RelaySeg e{};
         e.s = T;

@@ -298,6 +298,7 @@ struct ClockStage {
     bool relay_per_cu_set = false;
     int relay_no_handoff = -1;       // the relay's first pass starts from the timing guess, no hand-off passes: -1: in the default
                                      // configuration (cfg.clock_exact = 0); XRIT_NO_HANDOFF=0 / 1: never / with every relayed call (A/B runs)
+    bool relay_rec01 = true;           // a plan from the timing guess records its first pass and guesses from that in its second (XRIT_RELAY_REC01=0: not; A/B runs)
     bool relay_quick = false;          // cfg.clock_exact = -3: the default configuration with its first relay passes walked approximately
     int relay_apx_cfg[2] = {-1, -1};   // XRIT_RELAY_APX=a,b: the walk of the relay's first two passes (-1: the configuration's choice; A/B runs)
     int relay_waves = 1;        // waves per walker team at most (clock_relay_wide.h; < 2: the one-wave walker of clock_relay.h)
