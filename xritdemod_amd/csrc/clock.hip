@@ -1359,7 +1359,7 @@ int ClockStage::enqueue_relay(int count, bool restart, hipStream_t s, Profiler *
             // them at its own state, with the slope of the block before, even the record of a walk from the timing guess -- 4e-2
             // sample away -- saves the next pass a guess round per step: 1.28 instead of 2.30)
             a.rec_write = relay_rec01 || !(j.no_handoff && j.relay_enq == 0);
-            a.rec_use = relay_rec01 || !(j.no_handoff && j.relay_enq == 1);
+            a.rec_use = (relay_rec01 || !(j.no_handoff && j.relay_enq == 1)) ? 3 : 0;      // (bit 1: the next block's record is read ahead)
 #ifdef XRIT_EXPERIMENTS
 #define XR_RELAY_WIDE(WV)                                                                                             \
     do {                                                                                                              \

@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     const bool quiet = a.sym_skip != 0 && s > 0;
     // (kernel arguments used inside the walk are taken once: behind the hand-written LDS traffic the compiler reloads them)
     const bool rec_write = __builtin_amdgcn_readfirstlane(a.rec_write) != 0;
+    const bool g_ahead = (__builtin_amdgcn_readfirstlane(a.rec_use) & 2) != 0;
     const ClockState T0 = T;
     // (the integer model is a guess generator, not the arithmetic: the gains folded into one factor each, the lattice
     // steps -- powers of two, float32 spacings -- as shifts)
@@ -344,6 +345,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
     unsigned steps = 0, rounds_total = 0;
     bool exhausted = false, stuck = false;
     int x_hi = x_lo, g_hi = 0;           // what the rings are known to hold (asked again only when that is not enough)
+    unsigned g_next = 0u;                // the record of the next block, read ahead
+    bool g_have = false;
     float rec_slope = 0.0f;              // how much further than the recorded walk this one advanced per symbol over the block before (2^-24 sample)
     float m1 = 0.f, m2 = 0.f;            // per lane: sum |s|, sum s^2 of the symbols it committed (first pass only)
 #ifdef XRIT_RELAY_TIMING
@@ -401,7 +404,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             // re-interpolated every block of its segment, 2.0 guess rounds per step where the others took 1.1 -- and a pass
             // waits for its slowest walker; and the record of a walk from the timing guess, five arms away, was of no use at
             // all: 2.30 rounds per step in the second pass, now 1.3.)
-            const unsigned g = gr[(n + lane) & (RELAY_GR - 1)];
+            // (taken at the end of the step before where the ring already held it: the LDS latency is behind the loop head)
+            const unsigned g = g_have ? g_next : gr[(n + lane) & (RELAY_GR - 1)];
             rec_block = !__any(g == RELAY_NOPOS);
             if (rec_block) {
                 rinc = relay_scan((int)g, lane);
@@ -512,6 +516,8 @@ __global__ void __launch_bounds__(RING ? 128 : 64) clock_relay_kernel(RelayArgs 
             }
             T = nt;
             n += nv;
+            g_have = use_rec && g_ahead && g_hi >= (n + 64 < Lseg ? n + 64 : Lseg);
+            if (g_have) g_next = gr[(n + lane) & (RELAY_GR - 1)];
             if (RING && lane == 0) { relay_st(&sh_pos_ii, (int)T.ii); relay_st(&sh_pos_n, n); }
         }
         RELAY_TICK(4);
