@@ -28,10 +28,12 @@
 //    next block starts from the literal result.  Lane 0 always starts from the walker's own state.
 //  * The samples are streamed into an LDS ring by a second wave of the workgroup that runs ahead of the walker
 //    (the walker itself reads LDS only and issues stores nobody waits for).
-//  * A segment that is walked again (its start moved by a few lattice units) meets the same arms and read indices
-//    as the walk before in all but ~1 % of its symbols: every walk leaves (index, arm) per symbol, the prefetching
-//    wave streams the record of the walk before into a second LDS ring, and the lanes take THAT as their first
-//    guess -- one round settles most blocks instead of two or three.
+//  * A segment that is walked again meets nearly the same timing errors as the walk before: every walk leaves, per symbol,
+//    how far it ADVANCED behind it (difference from the nominal period, 2^-24 sample), the prefetching wave streams the
+//    record of the walk before into a second LDS ring, and the lanes take their first guess from it -- the advances summed
+//    over the lanes in front, anchored at the walker's own state at lane 0, plus the rate at which this walk closed in on
+//    the recorded one over the block before.  One round settles all but a few per cent of the blocks, even behind a walk
+//    that started 4e-2 sample away (round 4; rounds 3-4 kept (index, arm), which is only right within a fraction of an arm).
 #pragma once
 
 #include "kernels.h"
@@ -75,7 +77,8 @@ struct RelayArgs {
     const int *ctl;               // clock control block: ctl[0] != 0 once the tiled hand-off has closed (null: do not ask)
     unsigned long long *moments;  // [2] sum |s| and sum s^2 over the soft symbols of the first relay pass, units of 2^-20 (the
                                   // default configuration's look at the signal-to-noise ratio: ClockStage::finish)
-    unsigned *rec;                // [G * cps * NS] (read index - segment reference) << 8 | arm of every symbol as last walked
+    unsigned *rec;                // [G * cps * NS] the advance behind every symbol as last walked (one-wave walker: difference from the
+                                  // nominal period, 2^-24 sample; walker teams: (read index - segment reference) << 8 | arm)
                                   // (null: no records -- every block starts from the nominal rate)
     unsigned *simd_claim;         // [RELAY_CLAIM_WORDS] per CU: the SIMDs that hold a walker (null: roles by wave number)
     int sym_skip;                 // this pass's walks from a GUESS (every segment but the first of a plan without hand-off passes, in its
