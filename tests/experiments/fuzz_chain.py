@@ -72,6 +72,12 @@ for c in range(cases):
                 float(np.sqrt(np.mean((g - ser) ** 2))), int(np.sum(np.sign(g[big]) != np.sign(ser[big]))))
         else:
             ser_msg = " | serial-device COUNT %d" % len(ser)
+    if os.environ.get("FUZZ_STAGES") and keep and ok and len(w):
+        # (kept stages: how far the last call's Costas output is from the oracle's -- tells a front-end difference from the M&M's own floor)
+        a_, b_ = od.stage("costas"), gd.stage("costas")
+        if len(a_) == len(b_) and len(a_):
+            e_ = np.abs(a_ - b_)
+            ser_msg += " | costas stage (last call) rms %.2e max %.2e at %d of %d" % (float(np.sqrt(np.mean(e_ ** 2))), float(e_.max()), int(np.argmax(e_)), len(e_))
     if os.environ.get("FUZZ_DUMP") and only:
         np.save(f"/tmp/fuzz_case{c}.npy", xi)
         print("   exact parameters", repr(extra))
