@@ -73,6 +73,9 @@ struct xrit_demod {
     int pf_count = 0;           // at most the one after it
     RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
+    // what the Costas loop of the CURRENT call reported when it was finished: taken there, because with a registered next input the
+    // stage begins the next burst's loop (and resets its counters) before this call returns
+    struct CostasSeen { int passes = 0; unsigned unconverged = 0; float max_residual = 0; bool walked = false; } costas_seen;
     bool no_defer = false;      // XRIT_NO_DEFER: registered front ends start at once also with the exact closure on (A/B runs)
     bool keep_stages = false;   // every stage's output is copied (diagnostics, tests): no fusion across stages
     bool keep_symbols = false;  // only the complex symbols of the clock recovery are kept (constellation tap)
@@ -455,6 +458,14 @@ static void set_relay_hook(xrit_demod *d, hipStream_t s)
 
 // clock recovery (:156, SymbolManager.cpp:104) of a slice whose Costas loop has been enqueued on s (costas_done: has been
 // finished ahead of this call, on stream2)
+static void costas_note(xrit_demod *d)
+{
+    d->costas_seen.passes = d->costas.passes;
+    d->costas_seen.unconverged = d->costas.unconverged;
+    d->costas_seen.max_residual = d->costas.max_residual;
+    d->costas_seen.walked = d->costas.job.rescued && d->costas.walked;
+}
+
 static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, size_t *nsym, hipStream_t s, Profiler *prof,
                  bool costas_done = false, float2 *slot_done = nullptr)
 {
@@ -473,6 +484,7 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
         if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
         bool redone = false;
         XR_TRY(d->costas.finish(s, prof, &redone));
+        costas_note(d);
         if (redone) d->clock.om_scanned = false;     // (the final pass ran again: the statistic is new, begin() unwraps it itself)
         costas_done = true;
     }
@@ -492,6 +504,7 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
         if (length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
         bool redone = false;
         XR_TRY(d->costas.finish(s, prof, &redone));
+        costas_note(d);
         if (redone) {
             // the Costas output was rewritten after more passes: the clock recovery starts over on it
             const int L = d->costas.L;
@@ -562,6 +575,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
             if (io.length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
             bool redone = false;
             rc = d->costas.finish(d->stream2, prof, &redone);
+            costas_note(d);
             if (redone) d->clock.om_scanned = false;
             if (rc == XRIT_OK) rc = loops(d, io, d_soft, cap, &total_sym, s, prof, true, f.slot);
             costas_ahead = true;
@@ -584,9 +598,9 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         return rc;
     }
     total_len = io.length;
-    const int worst_cp = d->costas.passes, worst_kp = d->clock.passes;
-    const unsigned unc_c = d->costas.unconverged, unc_k = d->clock.unconverged, large_k = d->clock.large_open;
-    const float res_c = d->costas.max_residual, res_k = d->clock.max_residual;
+    const int worst_cp = d->costas_seen.passes, worst_kp = d->clock.passes;
+    const unsigned unc_c = d->costas_seen.unconverged, unc_k = d->clock.unconverged, large_k = d->clock.large_open;
+    const float res_c = d->costas_seen.max_residual, res_k = d->clock.max_residual;
     if (prof) d->prof.collect();
     d->stage_n[4] = total_sym;
     d->stats.samples_in = n;
@@ -600,7 +614,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
     d->stats.clock_max_residual = res_k;
     d->stats.agc_serial_fallback = d->agc_fallback_seen;
     d->stats.clock_open_large = large_k;
-    d->stats.costas_serial_walk = d->costas.job.rescued && d->costas.walked ? 1 : 0;
+    d->stats.costas_serial_walk = d->costas_seen.walked ? 1 : 0;
     d->stats.clock_relay_passes = d->clock.relay_passes;
     d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
     d->stats.clock_relay_segments = d->clock.job.relay ? d->clock.relay_segments : 0;
