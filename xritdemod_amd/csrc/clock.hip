@@ -1090,6 +1090,8 @@ int ClockStage::reset(hipStream_t s)
     cur = 0;
     carry = 0;
     x_pending = -1;         // (samples a producer has put in place for a call that will not come)
+    om_ext = false;         // (... and its timing statistic and count curve)
+    om_scanned = false;
     in_flight = false;
     redo_ok = false;        // (nothing of an earlier call is left to run again, nor a flipped loop's state to start it from)
     alt_valid = false;
