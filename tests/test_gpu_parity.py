@@ -796,6 +796,14 @@ def test_prefetched_front_ends_give_the_same_symbols(xa, exact):
     dem2.reset()
     k = dem2.process_device(xt[0].data_ptr(), n, soft.data_ptr(), cap)
     assert np.array_equal(soft[:k].cpu().numpy(), plain[0])
+    # ... and one reset while the NEXT burst's front end and Costas loop are at work on the second stream (started beside the
+    # relay of the call before): the stream is left, the handle starts over
+    dem2.prefetch_device(xt[1].data_ptr(), n)
+    dem2.prefetch_device(xt[2].data_ptr(), n)
+    k = dem2.process_device(xt[1].data_ptr(), n, soft.data_ptr(), cap)
+    dem2.reset()
+    k = dem2.process_device(xt[0].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy(), plain[0])
     dem2.prefetch_device(xt[1].data_ptr(), n)
     del dem2
 

@@ -1093,6 +1093,15 @@ int ClockStage::reset(hipStream_t s)
     om_ext = false;         // (... and its timing statistic and count curve)
     om_scanned = false;
     in_flight = false;
+    // what the stage has learnt from the stream it is leaving: as on a new handle (a reset handle gives a new handle's words)
+    passes = 0;
+    last_passes = -1;
+    batch = 7;
+    relay_batch = 96;
+    jmean_valid = false;
+    last_symbols = 0;
+    prev_carry = 0;
+    prev_n = 0;
     redo_ok = false;        // (nothing of an earlier call is left to run again, nor a flipped loop's state to start it from)
     alt_valid = false;
     return XRIT_OK;

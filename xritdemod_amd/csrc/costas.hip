@@ -629,6 +629,7 @@ int CostasStage::reset(hipStream_t s)
     unconverged = 0;
     stable = 0;
     last_passes = -1;
+    batch = 4;              // (as on a new handle)
     return XRIT_OK;
 }
 
