@@ -790,6 +790,19 @@ def test_prefetched_front_ends_give_the_same_symbols(xa, exact):
     dem.prefetch_device(xt[0].data_ptr(), n)
     with pytest.raises(xa.XritError):                     # inputs are taken in the order they were prefetched
         dem.process_device(xt[1].data_ptr(), n, soft.data_ptr(), cap)
+    # a call refused for its capacity consumes nothing: the burst's front end and Costas loop, which ran ahead beside the relay of
+    # the call before, stay queued for the retry
+    dem3 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D, clock_exact=exact))
+    dem3.prefetch_device(xt[0].data_ptr(), n)
+    dem3.prefetch_device(xt[1].data_ptr(), n)
+    k = dem3.process_device(xt[0].data_ptr(), n, soft.data_ptr(), cap)
+    with pytest.raises(xa.XritError):
+        dem3.process_device(xt[1].data_ptr(), n, soft.data_ptr(), 1000)
+    k = dem3.process_device(xt[1].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy(), plain[1])
+    k = dem3.process_device(xt[2].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy(), plain[2])
+    del dem3
     # a handle that is reset or destroyed with a registered input it never started
     dem2 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, D, clock_exact=exact))
     dem2.prefetch_device(xt[0].data_ptr(), n)
