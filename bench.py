@@ -32,22 +32,28 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in):
-    """ONE stream per step, cut in `world` time slices of n_burst samples: the C++ group API
-    (xrit_group_*: ncclSend / ncclRecv of the halo and of 256 boundary symbols, one ncclAllGather of (polarity,
-    count)).  The handles persist across steps, the slices of every step are generated and resident before the
-    clock starts; torch.distributed only hands out the ncclUniqueId and brackets the timing."""
-    K, W = args.steps, args.warmup
+def run_contiguous(torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in, K, W, slices=None):
+    """ONE stream per step, cut in `world` time slices of n_burst samples (BASELINE config 4): the C++ group API
+    (xrit_group_*: ncclSend / ncclRecv of the halo and of 256 boundary symbols, two ncclAllGather of (polarity, status) and
+    (count, status)).  The handles persist across steps, the slices of every step are generated and resident before the
+    clock starts; torch.distributed only hands out the ncclUniqueId and brackets the timing.  `slices`: an existing
+    (nbuf, n_burst, 2) float32 device tensor to generate into (the default leg reuses the headline's bursts).
+    Returns the measurement as a dict (every rank; the reductions are collective)."""
     sp = _capi.synth_params(fs_in=fs_in)
     stream = torch.cuda.current_stream(dev)
+    n_burst -= n_burst % D      # (slices are whole decimation periods: the next slice's decimator phase must not shift, group.hip)
     uid = [xa.group_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     grp = xa.Group(xa.Demodulator.config("lrit", fs_in, D, device=local_rank), rank, world, uid[0])
     halo = grp.halo_samples
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    nbuf = max(1, min(W + K, int(free_b * 0.6) // (n_burst * 8)))
-    slices = torch.empty((nbuf, n_burst, 2), dtype=torch.float32, device=dev)
+    rccl_ranks = grp.rccl_ranks
+    if slices is None:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        nbuf = max(1, min(W + K, int(free_b * 0.6) // (n_burst * 8)))
+        slices = torch.empty((nbuf, n_burst, 2), dtype=torch.float32, device=dev)
+    nbuf = slices.shape[0]
+    slices = slices[:, :n_burst]
     for t in range(min(W + K, nbuf)):          # step t, rank r: samples [(t * world + r) * n_burst, ...) of the stream
         _capi.synth_generate_device(sp, (t * world + rank) * n_burst, n_burst, slices[t].data_ptr(), device=local_rank,
                                     stream=stream.cuda_stream)
@@ -60,36 +66,51 @@ def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev,
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    nsym = 0
+    nsym, flips = 0, 0
     for t in range(W):
         grp.process_slice_device(slices[t % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
     barrier()
     t0 = time.perf_counter()
     for t in range(W, W + K):
-        k, _off, _pol = grp.process_slice_device(slices[t % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap,
-                                                 stream=stream.cuda_stream)
+        k, _off, pol = grp.process_slice_device(slices[t % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap,
+                                                stream=stream.cuda_stream)
         nsym += k
+        flips += 1 if pol < 0 else 0
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, float(nsym)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(nsym), float(flips)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, nsym_all = float(tmax[0].item()), float(t[1].item())
+        elapsed, nsym_all, flips_all = float(tmax[0].item()), float(t[1].item()), int(t[2].item())
     else:
-        nsym_all = float(nsym)
+        nsym_all, flips_all = float(nsym), flips
+    del grp
+    return {"value": round(n_burst * world * K / elapsed / 1e6, 2), "unit": "Msamples/s", "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 3), "symbols_per_s": round(nsym_all / elapsed, 1),
+            "samples_per_step_per_gpu": n_burst, "halo_samples": int(halo), "halo_bytes_per_boundary": int(halo) * 8,
+            "rccl_ranks": int(rccl_ranks), "polarity_flips": flips_all, "slices_reused": bool(W + K > nbuf),
+            "what": "one LRIT stream per step cut in n_gpus time slices: ncclSend / ncclRecv of the halo and of 256 boundary "
+                    "symbols, two ncclAllGather of two words per rank (xrit_group_process_slice_device)"}
+
+
+def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in):
+    """--contiguous: the edge-exchange mode as the whole run (its own JSON line)."""
+    K, W = args.steps, args.warmup
+    r = run_contiguous(torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in, K, W)
     if rank == 0:
         print(json.dumps({
             "metric": "Msamples/s in -> soft-symbols/s out (LRIT 293 ksym/s chain); % HBM roofline",
-            "value": round(n_burst * world * K / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": r["value"], "unit": "Msamples/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "symbols_per_s": round(nsym_all / elapsed, 1),
+            "symbols_per_s": r["symbols_per_s"],
             "config": {"workload": "C4 contiguous: one LRIT stream per step cut in n_gpus time slices, edge-sample exchange "
                                    "over RCCL (xrit_group_process_slice_device); slices resident before the clock starts",
-                       "samples_per_step_per_gpu": n_burst, "decimation": D, "halo_samples": halo,
-                       "halo_bytes_per_boundary": halo * 8, "slices_reused": bool(W + K > nbuf),
+                       "samples_per_step_per_gpu": n_burst, "decimation": D, "halo_samples": r["halo_samples"],
+                       "halo_bytes_per_boundary": r["halo_bytes_per_boundary"], "slices_reused": r["slices_reused"],
+                       "rccl_ranks": r["rccl_ranks"], "polarity_flips": r["polarity_flips"],
                        "parallelism": f"time-slice x{world}"}}))
     if world > 1:
         dist.destroy_process_group()
@@ -120,6 +141,10 @@ def main():
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
                     help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
                          "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")
+    ap.add_argument("--contiguous-leg", action="store_true",
+                    help="add the `contiguous` leg (second timed region, same JSON line) also at N = 1, where the RCCL communicator "
+                         "has one rank; with N > 1 over RCCL the leg is always run")
+    ap.add_argument("--contiguous-timeout", type=int, default=240, help="seconds the contiguous leg may take before the line is printed without it")
     ap.add_argument("--contiguous", action="store_true",
                     help="N ranks demodulate ONE stream cut in N slices, with RCCL edge-sample exchange "
                          "(SURVEY.md 8(e); the default is N independent segments, no data-path collective)")
@@ -344,8 +369,10 @@ def main():
         # refers to.  The kernel that moves those bytes (the decimating FIR reads every input sample once; without a
         # decimator the longest single launch) is listed beside it, priced with ITS OWN algorithmic bytes and timed
         # with HIP events on the launch stream inside the timed region.
-        dom_name = "fir_decim" if "fir_decim" in kernels else max(kernels, key=lambda n: kernels[n]["avg_launch_ms"])
+        in_name = "fir_decim" if "fir_decim" in kernels else max(kernels, key=lambda n: kernels[n]["avg_launch_ms"])
+        dom_name = max(prof, key=lambda r: r[1])[0]          # the kernel the step spends most of its time in
         fd = kernels[dom_name]
+        fi = kernels[in_name]
         roofline = {"bound": "hbm", "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                     "what": "whole chain: algorithmic_bytes_per_sample x samples per step / ms_per_step",
@@ -357,7 +384,13 @@ def main():
                                         "measured": fd.get("measured"),
                                         "avg_launch_ms_alone": fd.get("avg_launch_ms_alone"),
                                         "frac_alone": fd.get("hbm_frac_alone")},
-                    "dominant_kernel_frac": fd.get("hbm_frac")}
+                    "dominant_kernel_frac": fd.get("hbm_frac"),
+                    # the kernel that moves the algorithmic bytes (reads every input sample once), priced on its own bytes
+                    "input_kernel": {"kernel": in_name, "avg_launch_ms": fi["avg_launch_ms"],
+                                     "algorithmic_bytes_per_launch": fi.get("algorithmic_bytes_per_launch"),
+                                     "achieved": fi.get("achieved_gbs"), "frac": fi.get("hbm_frac"),
+                                     "measured": fi.get("measured"), "avg_launch_ms_alone": fi.get("avg_launch_ms_alone"),
+                                     "frac_alone": fi.get("hbm_frac_alone")}}
         tot = max(prof, key=lambda r: r[1])
         roofline["by_total_time"] = {"kernel": tot[0], "total_ms_per_step": round(tot[1] / K, 4),
                                      "achieved": kernels[tot[0]].get("achieved_gbs"),
@@ -369,10 +402,12 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("_step", {}).get("burst_log2") == args.burst_log2:
                     roofline["traffic"] = tj["_step"]["hbm_bytes_per_step"]
-                    roofline["traffic_source"] = tj["_step"].get("source")
-                ent = tj.get(dom_name)
-                if ent and ent.get("burst_log2") == args.burst_log2:
-                    roofline["dominant_kernel"]["traffic"] = ent["hbm_bytes_per_launch"]
+                    roofline["traffic_measured_in_this_run"] = False
+                    roofline["traffic_source"] = "NOT measured in this run: read from the committed profiles/hbm_traffic.json <- " + str(tj["_step"].get("source"))
+                for nm_, key_ in ((dom_name, "dominant_kernel"), (in_name, "input_kernel")):
+                    ent = tj.get({"clock_relay": "clock_relay_pass"}.get(nm_, nm_))      # (the relay's entry is per pass)
+                    if ent and ent.get("burst_log2") == args.burst_log2:
+                        roofline[key_]["traffic"] = ent["hbm_bytes_per_launch"]
             except Exception:
                 pass
     # secondary figures of SURVEY.md 8(d): FP32 rate of the arithmetic the chain has to do, and what a plain
@@ -560,6 +595,30 @@ def main():
                 out["parity_vs_oracle"]["floor_note"] = ("serial_gpu_rms is the measured floor of a hand-off-free float32 "
                                                          "M&M on this chain's Costas output; the time-tiled evaluation "
                                                          "adds the rest")
+    # ---- BASELINE config 4 names "RCCL edge-sample exchange": with N > 1 the driver's command also times ONE stream cut in N
+    # slices through xrit_group_process_slice_device (a second timed region, LAST: `value` above is the independent-segments
+    # figure and is complete by now).  A watchdog keeps a stuck collective from taking the headline with it: on expiry rank 0
+    # prints the line it has, with the reason, and every rank leaves.
+    if (world > 1 and not share) or (args.contiguous_leg and world == 1):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["contiguous"] = {"error": "the leg did not finish within %d s (a collective is stuck?)" % args.contiguous_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.contiguous_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            out["contiguous"] = run_contiguous(torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in, min(K, 8), 2,
+                                               slices=bursts)
+        except Exception as e:      # (a failure of one rank reaches every rank through the group's all-gathers)
+            out["contiguous"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+    elif world > 1:
+        out["contiguous"] = {"skipped": "the ranks share a device and meet over gloo (XRIT_BENCH_SHARE_DEVICE): RCCL refuses two ranks on one GPU"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

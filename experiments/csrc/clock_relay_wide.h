@@ -24,7 +24,7 @@
 //    behind the next step's loads, so that the wait in front of a drop never includes a young store.
 #pragma once
 
-#include "clock_relay.h"
+#include "../../xritdemod_amd/csrc/clock_relay.h"
 
 namespace xrit {
 

@@ -167,12 +167,15 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n_com
  * rank's Costas loop locked pi away from the stream the capture's first GPU follows; the Mueller & Mueller detector
  * slices to {0, 1}, so the loop on -y is not minus the loop on y and the recovery has to run on the right sign).
  * The clock recovery's carried state goes back to what it was before that call (history and unread tail change sign),
- * the Costas loop's carried phase moves by pi; d_soft receives the call's symbols again. */
+ * the Costas loop's carried phase moves by pi; d_soft receives the call's symbols again.
+ * Refused (XRIT_E_INVALID, nothing changed) while an input registered with xrit_demod_prefetch_device waits for its
+ * process call: its front end and Costas loop may already have started from the unflipped state. */
 int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft_out, size_t cap, size_t *n_out, void *stream);
 /* Called after the process call that warmed the chain up over a time slice's halo (from a cold start): that call's
  * clock recovery is run once more on the negated Costas output and what it would carry is kept aside, so that a later
  * xrit_demod_redo_clock_flipped starts from the flipped loop's own state (without it, it starts from this sign's state
- * with the symbol history negated -- right to 1e-3 sample in timing, which takes 1e4..1e5 symbols to settle). */
+ * with the symbol history negated -- right to 1e-3 sample in timing, which takes 1e4..1e5 symbols to settle).
+ * Refused like xrit_demod_redo_clock_flipped while a prefetched input waits. */
 int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
 /* Streaming at full rate: run the front end (ingest, decimator, AGC, matched filter) of a LATER call's input now, on
  * the handle's second stream, so that it overlaps the feedback loops of the call made in between:
@@ -377,6 +380,9 @@ xrit_demod *xrit_group_chain(xrit_group *g);
 int    xrit_group_rank(const xrit_group *g);
 int    xrit_group_world(const xrit_group *g);
 size_t xrit_group_halo_samples(const xrit_group *g);
+/* Ranks of the RCCL communicator the group exchanges over, as RCCL itself counts them (ncclCommCount); 0 when the
+ * ranks are threads of one process (xrit_group_create_local: no communicator). */
+int    xrit_group_rccl_ranks(xrit_group *g);
 /* Collective: every rank passes ITS slice (n samples, device resident, slices in
  * rank order make up the burst; n >= the halo and a whole number of decimation
  * periods) and receives its symbols in the stream's

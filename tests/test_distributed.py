@@ -13,7 +13,8 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from xritdemod_amd import dist as xd, synth
+    import dist_twin as xd
+    from xritdemod_amd import synth
     d = xd.init("gloo")
     w, r, lr = xd.env_world()
     assert (w, r) == (world, rank)
@@ -46,7 +47,7 @@ def test_two_rank_segments_and_timing():
 
 def test_segment_seeds_do_not_collide():
     sys.path.insert(0, ROOT)
-    from xritdemod_amd import dist as xd
+    import dist_twin as xd
     seeds = [xd.segment_seed(r) for r in range(8)]
     used = set()
     for s in seeds:
@@ -60,7 +61,8 @@ def _split_worker(rank, world, port, q, same_lock):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import oracle                       # the CPU tier plays the chain with the oracle; on GPUs it is the HIP chain
-    from xritdemod_amd import dist as xd, synth
+    import dist_twin as xd
+    from xritdemod_amd import synth
     d = xd.init("gloo")
     n = 900000
     # every rank holds only its own slice of ONE stream (the generator is counter based: any slice on its own)

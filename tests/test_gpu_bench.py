@@ -38,6 +38,31 @@ def test_bench_line_of_one_rank():
     _check_line(_last_json(r.stdout), 1)
 
 
+CONTIG_KEYS = {"value", "unit", "steps", "ms_per_step", "halo_samples", "halo_bytes_per_boundary", "rccl_ranks", "polarity_flips",
+               "symbols_per_s", "samples_per_step_per_gpu"}
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contiguous_leg_over_rccl():
+    """With N > 1 the driver's command times a second region through xrit_group_process_slice_device (ONE stream cut in N
+    slices, RCCL edge-sample exchange: BASELINE config 4) and reports it as `contiguous` in the same JSON line; `value` stays the
+    independent-segments figure.  One GPU allows an RCCL communicator of ONE rank: --contiguous-leg runs that leg at N = 1, so the
+    schema, ncclCommCount and the group path are covered here (two ranks on one device: the in-process fabric tests of
+    test_gpu_parity.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--contiguous-leg"] + SMALL, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    _check_line(d, 1)
+    c = d["contiguous"]
+    assert CONTIG_KEYS <= set(c), sorted(c)
+    assert c["rccl_ranks"] == 1 and c["halo_samples"] == 0 and c["polarity_flips"] == 0
+    assert c["value"] > 0 and c["samples_per_step_per_gpu"] == (1 << 24) - (1 << 24) % 5      # whole decimation periods
+    rf = d["roofline"]
+    # the kernel a step spends most of its time in is named as such; the kernel that moves the algorithmic bytes beside it
+    assert rf["dominant_kernel"]["kernel"] == rf["by_total_time"]["kernel"] and rf["input_kernel"]["kernel"] == "fir_decim"
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_launched_like_the_driver_does():
     with socket.socket() as s:
@@ -50,7 +75,10 @@ def test_bench_two_ranks_launched_like_the_driver_does():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines            # rank 0 prints, nobody else
-    _check_line(json.loads(lines[0]), 2)
+    d = json.loads(lines[0])
+    _check_line(d, 2)
+    # (two ranks on ONE device meet over gloo: the RCCL leg says why it did not run; on the driver's multi-GPU node it does)
+    assert "skipped" in d["contiguous"]
 
 
 @pytest.mark.gpu

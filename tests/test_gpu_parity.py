@@ -4,7 +4,13 @@ Tolerances (float32 path, stated per check):
   * FIR / AGC / RRC / Costas outputs: max |err| <= 2e-5, rms <= 2e-6 relative to signals of amplitude ~0.5
     (different summation order, scan instead of serial gain recurrence, hand-off tolerance 1e-5 rad).
   * recovered symbols: count identical, hard-decision sign identical wherever |oracle| > 1e-3 (Es/N0 >= 6 dB; below,
-    see test_randomised_chains), rms <= 1.5e-4 on every call of the default configuration (check_symbols; round 4 --
+    see test_randomised_chains).  BASELINE.json's tolerance is 1e-4 rms (NORTH_STAR_RMS): asserted PLAINLY -- no floor
+    clause -- for C1, C2 and C5 on their test bursts (test_chain_parity, test_soft_symbol_target_of_1e_4,
+    test_default_configuration_is_within_reach_of_the_floor, test_north_star_1e_4_on_the_test_bursts); where the chain is
+    KNOWN to miss it -- C3 on every burst, C2 / C5 / C1 on steady-state bursts of the BASELINE size -- the same assertion runs
+    as a strict expected failure that reports the measured value and the serial floor in the warnings summary
+    (test_north_star_1e_4_on_the_test_bursts[C3], test_north_star_1e_4_in_steady_state): the miss is in the pytest tail, not
+    inside a tolerance.  Every other call of the default configuration: rms <= 1.5e-4 (check_symbols; round 4 --
     3.2e-4 until then, which is kept for the hand-off passes alone, cfg.clock_exact = -2 / -1: 2.0e-4 .. 2.5e-4 on every
     configuration and burst size).  BASELINE.json asks for 1e-4.  Why the hand-off passes miss it, measured (DESIGN.md
     section 6): the M&M recurrence lives on a lattice -- mu and omega move in steps of 2^-21 sample (float32 near 4.25),
@@ -266,6 +272,24 @@ CASES = {
 }
 
 
+NORTH_STAR_RMS = 1.0e-4        # BASELINE.json north_star: "soft-symbol output within 1e-4 RMS of reference"
+# Where the default configuration is KNOWN to sit above it on the test burst (any float32 M&M on a Costas
+# output that is not bit-identical to the oracle's has a floor of 1.14e-4 on HRIT's 2.7 samples per symbol):
+NORTH_STAR_MISS = {"C3"}
+
+
+def north_star_tol(case):
+    """1e-4 where the configuration meets BASELINE.json's tolerance on its test burst; for the known miss the old bound, so that
+    the other assertions of a test still guard it (the miss itself is asserted by test_north_star_1e_4_on_the_test_bursts)."""
+    return 1.5e-4 if case in NORTH_STAR_MISS else NORTH_STAR_RMS
+
+
+def report_parity(what, **values):
+    """Measured parity figures into the warnings summary of the run (visible with -q)."""
+    import warnings
+    warnings.warn(what + ": " + ", ".join(f"{k} = {v:.3e}" if isinstance(v, float) else f"{k} = {v}" for k, v in values.items()))
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_chain_parity(xa, oracle_mod, case):
     o = oracle_mod
@@ -283,7 +307,7 @@ def test_chain_parity(xa, oracle_mod, case):
         assert len(a) == len(b), st
         assert rms(a - b) <= 2e-6, (st, rms(a - b))
         assert np.abs(a - b).max() <= 5e-5, (st, np.abs(a - b).max())
-    check_symbols(got, want)
+    check_symbols(got, want, rms_tol=north_star_tol(case))
     s4 = dem.stage("clock")
     assert len(s4) == len(want) and np.array_equal(s4.real, got)
     # what the decoder receives (SymbolManager.cpp:43-46)
@@ -316,7 +340,10 @@ def test_soft_symbol_target_of_1e_4(xa, oracle_mod, case):
     r, floor = rms(got - want), rms(ser - want)
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert r <= max(1e-4, 1.1 * floor) and r <= 1.45e-4, (case, r, floor)
+    if case in NORTH_STAR_MISS:
+        assert r <= 1.1 * floor and r <= 1.45e-4, (case, r, floor)      # (the known miss: held to its floor)
+    else:
+        assert r <= NORTH_STAR_RMS, (case, r, floor)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -348,7 +375,93 @@ def test_default_configuration_is_within_reach_of_the_floor(xa, oracle_mod, case
     for g in (got, g3):
         r = rms(g - want)
         assert np.array_equal(np.sign(g[big]), np.sign(want[big]))
-        assert r <= max(1e-4, 1.2 * floor) and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
+        if case in NORTH_STAR_MISS:
+            assert r <= 1.2 * floor and r <= 1.5e-4 and r <= rf + 1e-6, (case, r, floor, rf)
+        else:
+            assert r <= NORTH_STAR_RMS and r <= rf + 1e-6, (case, r, floor, rf)
+
+
+class BeyondTheKnownMiss(Exception):
+    """Raised (not asserted) inside the expected-failure cases: only the 1e-4 assertion itself is expected to fail there."""
+
+
+def _must(cond, *what):
+    if not cond:
+        raise BeyondTheKnownMiss(what)
+
+
+def _north_star_params(cases, miss, why):
+    return [pytest.param(c, marks=pytest.mark.xfail(strict=True, raises=AssertionError, reason=why)) if c in miss else c for c in cases]
+
+
+@pytest.mark.parametrize("case", _north_star_params(CASES, NORTH_STAR_MISS,
+                         "known miss: HRIT's float32 M&M floor is 1.14e-4 for any front end not bit-identical to the oracle's"))
+def test_north_star_1e_4_on_the_test_bursts(xa, oracle_mod, case):
+    """BASELINE.json's tolerance, as written: the DEFAULT configuration's soft symbols within 1e-4 rms of the oracle's, hard
+    decisions equal.  No floor clause.  C3 is a strict expected failure (if it ever passes, this list must change); the
+    measured value and the serial floor of the same samples go to the warnings summary either way."""
+    mode, fs, D, kw, n = CASES[case]
+    x = synth_signal(n, **kw)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    got = xa.Demodulator(xa.Demodulator.config(mode, fs, D)).process(x)
+    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
+    _must(len(got) == len(want) == len(ser), "symbol count")
+    big = np.abs(want) > 1e-3
+    _must(np.array_equal(np.sign(got[big]), np.sign(want[big])), "hard decisions")
+    r, floor = rms(got - want), rms(ser - want)
+    _must(r <= 1.5e-4, "beyond the known miss", r, floor)
+    report_parity(f"north star 1e-4, test burst, {case}", rms_vs_oracle=r, serial_floor=floor, met=bool(r <= NORTH_STAR_RMS))
+    assert r <= NORTH_STAR_RMS, (case, r, floor)
+
+
+# (case, samples per burst, bursts): bursts of the BASELINE size where the oracle finishes in seconds per burst
+STEADY = {
+    "C1": ("lrit", 1.25e6, 1, dict(fs_in=1.25e6), 1 << 26, 3),
+    "C2": ("lrit", 6.25e6, 5, dict(fs_in=6.25e6), 1 << 28, 3),
+    "C3": ("hrit", 2.5e6, 1, dict(fs_in=2.5e6, symbol_rate=927000.0, alpha=0.3), 1 << 26, 3),
+    "C5": ("lrit", 40e6, 32, dict(fs_in=40e6), 1 << 28, 3),
+}
+# steady-state bursts of the default configuration, measured (profiles/r4_steady_parity.json, r4_bench_c{1,3,5}.json): C2 1.05e-4
+# (the serial trajectory itself: 1.01e-4), C5 1.03e-4, C3 1.31e-4, C1 9.65e-5
+STEADY_MISS = {"C2", "C3", "C5"}
+
+
+@pytest.mark.parametrize("case", _north_star_params(STEADY, STEADY_MISS,
+                         "known miss: on steady-state bursts the serial float32 trajectory itself is 1.0e-4 (LRIT) / 1.3e-4 (HRIT) from the oracle"))
+def test_north_star_1e_4_in_steady_state(xa, oracle_mod, case):
+    """The same assertion on the bursts the throughput is quoted on: consecutive bursts of one stream at the BASELINE burst size
+    (C2, C5: 2^28 samples; C1, C3: 2^26), the cold-started first one left out.  C2, C3 and C5 are strict expected failures --
+    the serial floor of these bursts is at or above 1e-4 -- and say by how much in the warnings summary."""
+    import torch
+    from xritdemod_amd import _capi
+    mode, fs, D, kw, n, bursts = STEADY[case]
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    sp = _capi.synth_params(**kw)
+    dflt = xa.Demodulator(xa.Demodulator.config(mode, fs, D))
+    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1))
+    ref = oracle_mod.Demod(oracle_mod.config(mode, fs, D))
+    se = sf = sd = 0.0
+    cnt = 0
+    for b in range(bursts):
+        _capi.synth_generate_device(sp, b * n, n, buf.data_ptr(), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        x = buf.cpu().numpy().view(np.complex64).reshape(-1)
+        got, flo, want = dflt.process(x), ser.process(x), ref.process(x)
+        _must(len(got) == len(flo) == len(want), "symbol count", b)
+        big = np.abs(want) > 1e-3
+        _must(np.array_equal(np.sign(got[big]), np.sign(want[big])), "hard decisions", b)
+        if b == 0:
+            continue
+        se += float(np.sum((got - want).astype(np.float64) ** 2))
+        sf += float(np.sum((flo - want).astype(np.float64) ** 2))
+        sd += float(np.sum((got - flo).astype(np.float64) ** 2))
+        cnt += len(want)
+    r, floor, rs = (se / cnt) ** 0.5, (sf / cnt) ** 0.5, (sd / cnt) ** 0.5
+    report_parity(f"north star 1e-4, steady state, {case} ({bursts - 1} bursts of {n} samples)", rms_vs_oracle=r, serial_floor=floor,
+                  rms_vs_serial=rs, met=bool(r <= NORTH_STAR_RMS))
+    _must(r <= 1.5e-4 and rs <= 1.0e-4, "beyond the known miss", r, floor, rs)
+    assert r <= NORTH_STAR_RMS, (case, r, floor, rs)
 
 
 def test_bursts_that_fill_the_chip_are_relayed_from_the_timing_guess(xa, oracle_mod):
@@ -974,6 +1087,39 @@ def test_host_program_streams_int8_symbols_to_a_tcp_decoder(xa, oracle_mod, tmp_
     assert np.array_equal(np.sign(gq[np.abs(wq) > 2]), np.sign(wq[np.abs(wq) > 2]))
 
 
+def test_host_program_fifo_chunking_is_the_reference_rule(xa, oracle_mod, tmp_path):
+    """--fifo (demodulator.cpp:108-119): the source delivers blocks of 65535 samples (CFileFrontend's BUFFERSIZE) into a FIFO of
+    512 Ki complex samples and the DSP loop, when it looks (here after every 3 blocks), takes EVERYTHING the FIFO holds if that is
+    at least 32 Ki complex samples -- chunks of 3 x 65535 samples, of which :137 drops `length mod decimation` (here 196605 mod 32
+    = 29 per chunk) -- and at the end of the file what is left below the threshold stays in the FIFO.  The oracle is fed the same
+    chunks; a lag of 9 blocks overflows the FIFO (9 x 65535 > 524288) and loses the excess like the reference."""
+    import subprocess
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    fs, D, P, lag = 40e6, 32, 65535, 3
+    n = 9 * P * lag + 20000                  # nine chunks and a rest below the threshold
+    x = synth_signal(n, fs_in=fs)
+    f, out = tmp_path / "capture.cf32", tmp_path / "sym.s8"
+    x.tofile(f)
+    r = subprocess.run([host_bin, "--input", str(f), "--sample-rate", str(fs), "--decimation", str(D), "--sink", f"file:{out}",
+                        "--fifo", "--fifo-lag", str(lag), "--stats"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"fifo: 9 chunks of {lag * P} .. {lag * P} samples" in r.stderr and "0 samples lost to overflow" in r.stderr, r.stderr
+    od = oracle_mod.Demod(oracle_mod.config("lrit", fs, D))
+    want = np.concatenate([od.process(x[i * lag * P:(i + 1) * lag * P]) for i in range(9)])      # (the rest is never processed)
+    wq, gq = oracle_mod.quantize_i8(want), np.fromfile(out, np.int8)
+    assert len(gq) == len(wq)
+    d = np.abs(gq.astype(np.int16) - wq.astype(np.int16))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.99
+    # the same file through fixed blocks of the same size is ANOTHER sample stream at decimation 32 only through the dropped
+    # remainders, which this mode reproduces: a whole-file call drops 9 x 29 samples fewer and ends up with more symbols
+    whole = oracle_mod.Demod(oracle_mod.config("lrit", fs, D)).process(x[:9 * lag * P])
+    assert len(whole) >= len(want)
+    r = subprocess.run([host_bin, "--input", str(f), "--sample-rate", str(fs), "--decimation", str(D), "--sink", "null",
+                        "--fifo", "--fifo-lag", "9", "--stats"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Input Samples Fifo is overflowing!" in r.stderr, r.stderr
+    assert f"chunks of {512 * 1024} .. {512 * 1024} samples" in r.stderr and f"{3 * (9 * P - 512 * 1024)} samples lost to overflow" in r.stderr, r.stderr
+
+
 def test_host_program_symbol_manager_loss_semantics(xa, oracle_mod, tmp_path):
     """--drop: SymbolManager's queue between the DSP thread and the sender thread, with the reference's two ways of
     losing symbols (SymbolManager.cpp:78-83: everything queued is dropped while no decoder is connected; :97-101: a
@@ -1095,7 +1241,7 @@ def test_host_program_output_locks_in_the_decoder(xa, tmp_path):
 
 class _ThreadComm:
     """Two 'ranks' as two threads of this process sharing the one GPU: the send / recv / all_gather calls of
-    xritdemod_amd.dist with queues in place of RCCL (a 1-GPU box cannot host two nccl ranks)."""
+    tests/dist_twin.py with queues in place of RCCL (a 1-GPU box cannot host two nccl ranks)."""
 
     def __init__(self, world):
         import queue
@@ -1135,7 +1281,8 @@ def test_contiguous_split_on_device(xa, same_lock):
     symbols.  Checked against the uninterrupted HIP chain on the same stream."""
     import threading
     import torch
-    from xritdemod_amd import _capi, dist as xd
+    import dist_twin as xd
+    from xritdemod_amd import _capi
     n, D, fs = 6000000, 5, 6.25e6
     sp = _capi.synth_params(fs_in=fs)
     whole = torch.empty((2 * n, 2), dtype=torch.float32, device="cuda:0")

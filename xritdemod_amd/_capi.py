@@ -109,6 +109,7 @@ _SIGNATURES = {
     "xrit_group_rank": (C.c_int, [_vp]),
     "xrit_group_world": (C.c_int, [_vp]),
     "xrit_group_halo_samples": (_sz, [_vp]),
+    "xrit_group_rccl_ranks": (C.c_int, [_vp]),
     "xrit_group_process_slice_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64),
                                                   C.POINTER(C.c_int), _vp]),
     "xrit_group_process_slice_host": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64),
@@ -472,6 +473,11 @@ class Group(_Handle):
     @property
     def halo_samples(self):
         return lib().xrit_group_halo_samples(self._h)
+
+    @property
+    def rccl_ranks(self):
+        """Ranks of the RCCL communicator behind the group, as ncclCommCount reports them (0: in-process fabric)."""
+        return lib().xrit_group_rccl_ranks(self._h)
 
     @property
     def rank(self):

@@ -466,7 +466,7 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 }  // namespace xrit
 #include "clock_relay.h"
 #ifdef XRIT_EXPERIMENTS
-#include "clock_relay_wide.h"      // walker teams: built, verified, no faster
+#include "../../experiments/csrc/clock_relay_wide.h"      // walker teams: built, verified, no faster; not in the shipped library
 #else
 namespace xrit { constexpr int RW_REC_PAD = 0; }
 #endif

@@ -571,16 +571,17 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
             // call here sits between the end of one burst's relay and the start of the next one's, with the device idle:
             // measured, steady state: 8 us between two calls, 6 us from entry to ClockStage::begin, 30 us to enqueue
             // tail + guess + relay kernels, of which the device spends 20 in the first two).
-            XR_HIP(hipEventSynchronize(d->ev_costas));
+            // (from here on the registered input has been consumed: a failure poisons the handle below, no early return)
+            if (hipEventSynchronize(d->ev_costas) != hipSuccess) { set_error("hipEventSynchronize failed"); rc = XRIT_E_HIP; }
             if (io.length && d->agc.requested_flag() == 2.0f) d->agc_fallback_seen = true;
             bool redone = false;
-            rc = d->costas.finish(d->stream2, prof, &redone);
+            if (rc == XRIT_OK) rc = d->costas.finish(d->stream2, prof, &redone);
             costas_note(d);
             if (redone) d->clock.om_scanned = false;
             if (rc == XRIT_OK) rc = loops(d, io, d_soft, cap, &total_sym, s, prof, true, f.slot);
             costas_ahead = true;
         } else {
-            XR_HIP(hipStreamWaitEvent(s, d->ev_fe[f.set], 0));
+            if (hipStreamWaitEvent(s, d->ev_fe[f.set], 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = XRIT_E_HIP; }
         }
     } else {
         const int set = d->next_set;
@@ -634,6 +635,9 @@ int xrit_demod_prepare_flipped(xrit_demod *d, void *stream)
 {
     if (!d) { set_error("null argument"); return XRIT_E_INVALID; }
     if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    // (a registered input's front end / Costas loop may have started from the unflipped state, and left the clock stage its
+    // timing statistic: the flip belongs between two plain calls)
+    if (d->pf_count > 0) { set_error("a prefetched input waits for its process call: the flipped re-run belongs between plain calls"); return XRIT_E_INVALID; }
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     int rc = d->clock.make_alt(s, d->prof.enabled ? &d->prof : nullptr);
@@ -646,6 +650,9 @@ int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft, size_t cap, size
     if (!d || !n_out || !d_soft) { set_error("null argument"); return XRIT_E_INVALID; }
     *n_out = 0;
     if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    // (a registered input's front end / Costas loop may have started from the unflipped state, and left the clock stage its
+    // timing statistic: the flip belongs between two plain calls)
+    if (d->pf_count > 0) { set_error("a prefetched input waits for its process call: the flipped re-run belongs between plain calls"); return XRIT_E_INVALID; }
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
@@ -1017,7 +1024,9 @@ int xrit_clock_set_serial(xrit_clock *c, int serial)
 int xrit_clock_set_exact(xrit_clock *c, int exact, int window)
 {
     if (!c) return XRIT_E_INVALID;
-    c->st.exact = exact;
+    if (exact < -3) { set_error("clock_exact = %d: -3 .. n (see xrit_demod_config.clock_exact)", exact); return XRIT_E_INVALID; }
+    c->st.exact = exact == -3 ? 0 : exact;          // (-3: the default's plan, its first relay passes approximate -- as in xrit_demod_create)
+    c->st.relay_quick = exact == -3;
     c->st.relay_window = window > 0 ? window : 0;
     return XRIT_OK;
 }

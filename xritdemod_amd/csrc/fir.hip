@@ -234,66 +234,7 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     // PAD: window index i sits at i + i/D; walk it D samples at a time
     if (MF) {
 #ifdef XRIT_EXPERIMENTS      // (make EXTRA=-DXRIT_EXPERIMENTS: not in the shipped library)
-        // EXPERIMENT (round 2's review, item 7): the same sums on the matrix pipe.  A decimating FIR is a block-Toeplitz
-        // product: for 16 groups of 16 consecutive outputs (rows G, columns j; output 16 G + j of the workgroup),
-        //     Y[G][j] = sum_s X[G][s] * H[s][j],   X[G][s] = tile[16 DS G + s],   H[s][j] = g[s - DS j]  (0 outside the filter),
-        // s = 0 .. 15 DS + TS - 1.  v_mfma_f32_16x16x4_f32 accumulates four s per instruction as a k-ordered fmaf chain
-        // (MI355X guide: bitwise a v_fmac loop), i.e. in the window order of the straight-line path; the taps that are
-        // zero for a column add exact zeros.  Same rate as v_pk_fma_f32 (64 FLOP / clk / SIMD), but 15 DS + TS = 226
-        // columns of H for TS = 151 useful ones (1.5 x the multiply-adds), on a pipe nothing else in the chain uses,
-        // with one ds_read_b64 per lane and two MFMAs instead of the VALU path's 76 ds_read2_b64 + 453 FMAs per lane.
-        // Three waves of the workgroup take 256 outputs each (RC = 3, 256 threads: 768 outputs), the fourth waits.
-        // RESULT (round 3, profiles/r3_mfma_decimator.txt): bit-identical to the VALU path (0 differing words over
-        // ragged multi-call runs, test_mfma_decimator_experiment_is_bit_identical) and SLOWER -- 0.82 ms against 0.51 alone
-        // at C2, 1.16 against 0.93 under the loops.  Ablation on 12 Mi outputs: VALU kernel 133 us; this one 203 =
-        // 119 (window fill + epilogue alone) + ~90 (the 114 MFMAs per wave alone: 129 with the stores).  The VALU kernel is
-        // already within 25 % of a pure stream (5.2 TB/s on its bytes) with its arithmetic hidden under other
-        // workgroups' fills; f32 MFMA has the SAME rate as v_pk_fma_f32, the Toeplitz padding makes it 1.5 x the
-        // multiply-adds and a quarter of the waves idle, so the matrix pipe would have to run at > 80 % while the same
-        // waves also wait for their fills: it does not.  Kept behind XRIT_MFMA_DEC=1 as the measured experiment; off.
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        constexpr int KS = (15 * DS + TS + 3) / 4;              // MFMA steps
-        const int wave = tid >> 6, lane = tid & 63;
-        f4 dre = {0.f, 0.f, 0.f, 0.f}, dim = {0.f, 0.f, 0.f, 0.f};
-        if (wave < 3) {
-            const int gg = lane & 15, kk = lane >> 4;
-            // B: H[4 q + kk][j] for this lane's (kk, j), precomputed on the host (FirStage::init), one coalesced load per step
-            float bt[KS];
-#pragma unroll
-            for (int q = 0; q < KS; ++q) bt[q] = mfb[q * 64 + lane];
-            // A: X[G][4 q + kk] = tile[pos(80 G + 4 q + kk)]: the skew adds 20 samples at s = 80 and s = 160, the same for
-            // every lane (4 q + kk crosses a multiple of 80 only between steps)
-            const float2 *xa = tile + (16 * DS + 20) * (16 * wave + gg) + kk;
-            constexpr int NB = 8;                               // steps per batch: the next batch's reads are in flight
-            float2 xs[2][NB];                                   // under this batch's MFMAs
-#pragma unroll
-            for (int u = 0; u < NB; ++u) xs[0][u] = xa[4 * u + 20 * ((4 * u) / 80)];
-#pragma unroll
-            for (int b = 0; b < (KS + NB - 1) / NB; ++b) {
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int q = (b + 1) * NB + u;
-                    if (q < KS) xs[(b + 1) & 1][u] = xa[4 * q + 20 * ((4 * q) / 80)];
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int q = b * NB + u;
-                    if (q < KS) {
-                        dre = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[b & 1][u].x, bt[q], dre, 0, 0, 0);
-                        dim = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[b & 1][u].y, bt[q], dim, 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();                                        // every window is dead
-        if (wave < 3) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                tile[256 * wave + 16 * (4 * (lane >> 4) + r) + (lane & 15)] = make_float2(dre[r], dim[r]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < RC; ++c) acc[c] = tile[tid * RC + c];
+#include "../../experiments/csrc/fir_mfma_dec.inc"
 #endif
     } else if (TS > 0) {
         // row 0 of g is the reversed filter, g[i] = h[TS-1-i] (zero behind it); output c takes sample i with tap

@@ -42,6 +42,8 @@ struct Transport {
     virtual int allreduce_max(double *v, hipStream_t s) = 0;
     // a rank that cannot go on serving its peers inside a collective call: they must not wait for it for ever
     virtual void abort() {}
+    // ranks the transport's own communicator reports (ncclCommCount); 0: no RCCL communicator behind this transport
+    virtual int comm_ranks() { return 0; }
 };
 
 // ONE copy of RCCL per process.  A host that has brought its own (PyTorch ships librccl.so.1 inside its wheel and loads it
@@ -54,6 +56,7 @@ struct RcclApi {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -68,12 +71,16 @@ struct RcclApi {
         void *h = nullptr;
         for (const char *name : {"librccl.so.1", "librccl.so"})
             if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already has
+        std::string last;                // (dlerror() hands its message out ONCE and clears it: taken right after the failing call)
         for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
-            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (!h) { why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+            if (!h) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) { const char *e = dlerror(); if (e) last = e; }
+            }
+        if (!h) { why = "RCCL not found: " + (last.empty() ? std::string("dlopen failed") : last); return; }
         bool all = true;
 #define XR_SYM(F) do { F = reinterpret_cast<decltype(F)>(dlsym(h, "nccl" #F)); if (!F) { all = false; why = "RCCL lacks nccl" #F; } } while (0)
-        XR_SYM(GetUniqueId); XR_SYM(CommInitRank); XR_SYM(CommInitAll); XR_SYM(CommDestroy); XR_SYM(CommAbort);
+        XR_SYM(GetUniqueId); XR_SYM(CommInitRank); XR_SYM(CommInitAll); XR_SYM(CommDestroy); XR_SYM(CommAbort); XR_SYM(CommCount);
         XR_SYM(GroupStart); XR_SYM(GroupEnd); XR_SYM(Send); XR_SYM(Recv); XR_SYM(AllGather); XR_SYM(AllReduce);
         XR_SYM(GetErrorString);
 #undef XR_SYM
@@ -114,6 +121,12 @@ struct RcclTransport : Transport {
     {
         if (comm && rccl().ok) (void)rccl().CommAbort(comm);      // pending and future operations of every rank on it return an error
         comm = nullptr;
+    }
+    int comm_ranks() override
+    {
+        int n = 0;
+        if (!comm || !rccl().ok || rccl().CommCount(comm, &n) != ncclSuccess) return 0;
+        return n;
     }
     int exchange(const void *send, size_t send_bytes, int to, void *recv, size_t recv_bytes, int from,
                  hipStream_t s) override
@@ -438,6 +451,7 @@ xrit_demod *xrit_group_chain(xrit_group *g) { return g ? g->chain : nullptr; }
 int xrit_group_rank(const xrit_group *g) { return g ? g->rank : -1; }
 int xrit_group_world(const xrit_group *g) { return g ? g->world : 0; }
 size_t xrit_group_halo_samples(const xrit_group *g) { return g ? g->halo : 0; }
+int xrit_group_rccl_ranks(xrit_group *g) { return g && g->tr ? g->tr->comm_ranks() : 0; }
 
 int xrit_group_restart(xrit_group *g)
 {

@@ -8,6 +8,13 @@
 //                               --paced the blocks are released at the capture's sample
 //                               rate like the reference does (default: as fast as possible)
 //   * demodulator.cpp:100-168   processSamples(): one chain call per block, state carried
+//   * demodulator.cpp:38,       --fifo: the reference's chunking rule instead of fixed --block calls: the source delivers blocks of
+//     :108-119, Parameters.h:57 --fifo-block samples (65535: CFileFrontend's BUFFERSIZE) into a FIFO of 1 Mi floats (512 Ki complex
+//                               samples); the DSP loop looks at it after every --fifo-lag blocks and, once it holds 64 Ki floats,
+//                               takes EVERYTHING it holds as one chunk -- so the chunk length varies, and with it which `length
+//                               mod decimation` samples :137 drops.  What does not fit the FIFO is lost ("Input Samples Fifo is
+//                               overflowing!").  The reference's chunk sizes depend on thread timing; here they are a function of
+//                               (--fifo-block, --fifo-lag), so that a run can be repeated and checked against the oracle.
 //   * SymbolManager.cpp:37-52   soft symbol -> int8 (x127, clamp, C-cast truncation), sent
 //                               in pieces of at most 16384 bytes (SM_SOCKET_BUFFER_SIZE)
 //   * SymbolManager.cpp:23-35   the demodulator is the TCP *client*; it retries the
@@ -65,7 +72,12 @@ struct Options {
     size_t queue_symbols = 1024 * 1024;   // SM_MAX_SYMBOL_BUFFER (SymbolManager.h:23)
     int sndbuf = 0;                // > 0: SO_SNDBUF of the decoder socket (the kernel's default grows to megabytes)
     int gpus = 1;                  // > 1: every block is cut in that many time slices, one per GPU (xrit_group_*)
+    bool fifo = false;             // the reference's FIFO chunking (demodulator.cpp:108-119) instead of fixed --block calls
+    size_t fifo_block = 65535;     // complex samples per source callback (CFileFrontend.cpp:12 BUFFERSIZE)
+    int fifo_lag = 1;              // source blocks that arrive between two looks of the DSP loop
 };
+constexpr size_t FIFO_COMPLEX = 1024 * 1024 / 2;      // FIFO_SIZE floats (Parameters.h:57)
+constexpr size_t FIFO_MIN_COMPLEX = 64 * 1024 / 2;    // "Lets wait for more samples" (demodulator.cpp:113)
 
 void usage()
 {
@@ -74,7 +86,8 @@ void usage()
                  "         [--sample-rate HZ] [--decimation D] [--block SAMPLES] [--device N]\n"
                  "         [--sink tcp://HOST:PORT | file:PATH | null] [--connect-tries N] [--paced] [--stats]\n"
                  "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n"
-                 "         [--gpus N]   (devices 0..N-1: each block of --block samples is cut in N time slices, RCCL edge exchange)\n");
+                 "         [--gpus N]   (devices 0..N-1: each block of --block samples is cut in N time slices, RCCL edge exchange)\n"
+                 "         [--fifo [--fifo-block SAMPLES] [--fifo-lag BLOCKS]]   (the reference's FIFO chunking, demodulator.cpp:108-119)\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -99,10 +112,17 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--queue-symbols") { if (!(v = need("--queue-symbols"))) return false; o.queue_symbols = (size_t)std::atoll(v); }
         else if (a == "--sndbuf") { if (!(v = need("--sndbuf"))) return false; o.sndbuf = std::atoi(v); }
         else if (a == "--gpus") { if (!(v = need("--gpus"))) return false; o.gpus = std::atoi(v); }
+        else if (a == "--fifo-block") { if (!(v = need("--fifo-block"))) return false; o.fifo_block = (size_t)std::atoll(v); }
+        else if (a == "--fifo-lag") { if (!(v = need("--fifo-lag"))) return false; o.fifo_lag = std::atoi(v); }
+        else if (a == "--fifo") o.fifo = true;
         else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
+    }
+    if (o.fifo && (o.fifo_block < 1 || o.fifo_block > FIFO_COMPLEX || o.fifo_lag < 1 || o.gpus > 1)) {
+        std::fprintf(stderr, "--fifo: --fifo-block 1..%zu, --fifo-lag >= 1, one GPU\n", FIFO_COMPLEX);
+        return false;
     }
     return !o.input.empty() && o.block > 0 && o.decimation >= 1 && o.gpus >= 1;
 }
@@ -471,18 +491,54 @@ int main(int argc, char **argv)
         }
         diag_iq.resize(2 * 1024);
     }
-    std::vector<unsigned char> raw(o.block * bytes_per_sample);
-    const size_t cap = o.block + 64;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto t_release = t_start;
+    const size_t max_chunk = o.fifo ? FIFO_COMPLEX : o.block;
+    std::vector<unsigned char> raw(max_chunk * bytes_per_sample);
+    const size_t cap = max_chunk + 64;
+    // --fifo: samplesFifo (demodulator.cpp:38) between the source's callbacks and the DSP loop
+    size_t fifo_fill = 0, fifo_overflowed = 0, fifo_calls = 0, fifo_min = ~(size_t)0, fifo_max = 0;
+    bool fifo_eof = false;
+    std::vector<unsigned char> blockbuf(o.fifo ? o.fifo_block * bytes_per_sample : 0);
+    auto fifo_chunk = [&]() -> size_t {
+        // the source runs until the DSP loop looks again AND finds at least 64 Ki floats (:108-116)
+        for (;;) {
+            for (int b = 0; b < o.fifo_lag && !fifo_eof; ++b) {
+                const size_t got = std::fread(blockbuf.data(), bytes_per_sample, o.fifo_block, in);
+                if (got == 0) { fifo_eof = true; break; }
+                if (o.paced) {        // CFileFrontend.cpp:36-47: one callback per block period
+                    std::this_thread::sleep_until(t_release);
+                    t_release += std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                        std::chrono::duration<double>((double)got / o.sample_rate));
+                }
+                size_t take = got;
+                if (fifo_fill + take > FIFO_COMPLEX) {
+                    if (!fifo_overflowed) std::fprintf(stderr, "Input Samples Fifo is overflowing!\n");
+                    fifo_overflowed += fifo_fill + take - FIFO_COMPLEX;
+                    take = FIFO_COMPLEX - fifo_fill;
+                }
+                std::memcpy(raw.data() + fifo_fill * bytes_per_sample, blockbuf.data(), take * bytes_per_sample);
+                fifo_fill += take;
+            }
+            if (fifo_fill >= FIFO_MIN_COMPLEX || fifo_eof) break;
+        }
+        // (at the end of the file the reference's loop stops with what is left below the threshold still in the FIFO)
+        if (fifo_fill < FIFO_MIN_COMPLEX) return 0;
+        const size_t n = fifo_fill;
+        fifo_fill = 0;
+        ++fifo_calls;
+        fifo_min = n < fifo_min ? n : fifo_min;
+        fifo_max = n > fifo_max ? n : fifo_max;
+        return n;
+    };
     std::vector<float> soft(cap);
     std::vector<int8_t> q(cap);
     size_t total_in = 0, total_sym = 0;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto t_release = t_start;
     int exit_code = 0;
     for (;;) {
-        size_t n = std::fread(raw.data(), bytes_per_sample, o.block, in);
+        size_t n = o.fifo ? fifo_chunk() : std::fread(raw.data(), bytes_per_sample, o.block, in);
         if (n == 0) { std::fprintf(stderr, "EOF\n"); break; }
-        if (o.paced) {
+        if (o.paced && !o.fifo) {
             // CFileFrontend.cpp:36-47: one block per block period
             std::this_thread::sleep_until(t_release);
             t_release += std::chrono::duration_cast<std::chrono::steady_clock::duration>(
@@ -522,6 +578,9 @@ int main(int argc, char **argv)
         if (xrit_demod_get_stats(chain, &st) == XRIT_OK)
             std::fprintf(stderr, "samples in %zu, symbols out %zu, %.3f s (%.2f Msamples/s incl. file and PCIe)\n",
                          total_in, total_sym, secs, secs > 0 ? total_in / secs * 1e-6 : 0.0);
+        if (o.fifo)
+            std::fprintf(stderr, "fifo: %zu chunks of %zu .. %zu samples (source blocks of %zu, %d per look), %zu samples lost to overflow\n",
+                         fifo_calls, fifo_calls ? fifo_min : 0, fifo_max, o.fifo_block, o.fifo_lag, fifo_overflowed);
         if (o.drop)
             std::fprintf(stderr, "symbol queue: capacity %zu, peak %zu, demodulatorFifoUsage %u %% at end of input (peak %u %%), "
                                  "sent %zu, dropped while full %zu, dropped while disconnected %zu\n",
