@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="one burst at a time: do not run the front end of the next burst (xrit_demod_prefetch_device, second "
                          "stream) under the feedback loops of the current one")
+    ap.add_argument("--prefetch-depth", type=int, default=2,
+                    help="inputs registered behind the call in progress (xrit_demod_prefetch_device): 2 (round 5: the walkers of "
+                         "bursts b and b + 1 beside the front end and Costas loop of burst b + 2) or 1 (round 4)")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode, fast-mode and quick-mode legs (cfg.clock_exact = 1, -2, -3)")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
@@ -243,11 +246,13 @@ def main():
     # (the warm-up steps are fed like the timed ones -- the next warm-up burst registered ahead -- so that both sets of the
     # handle's buffers exist before the clock starts; the last warm-up step has nothing registered behind it: the timed region
     # begins on an empty pipeline)
-    if not args.no_prefetch and W > 0:
-        dem.prefetch_device(bursts[0].data_ptr(), n_burst, stream=stream.cuda_stream)
+    depth = max(1, min(2, args.prefetch_depth))       # inputs registered behind the call in progress
+    if not args.no_prefetch:
+        for q in range(min(depth, W)):
+            dem.prefetch_device(bursts[q % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
     for b in range(W):
-        if not args.no_prefetch and b + 1 < W:
-            dem.prefetch_device(bursts[(b + 1) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+        if not args.no_prefetch and b + depth < W:
+            dem.prefetch_device(bursts[(b + depth) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
         ns = step(b)
         if b == 0:
             soft0 = soft[:ns].clone()
@@ -263,9 +268,10 @@ def main():
 
     if not args.no_profile:
         dem.profile(2)       # events around the decimating FIR only: an event record is a queue barrier
-    # Streaming: the front end (decimator, AGC, matched filter) and the Costas loop of burst b + 1 run on the handle's second
-    # stream beside the relay kernels of burst b -- every timed step still pays one front end and one set of loops, all
-    # inside the timed region (nothing is prefetched before the clock starts).
+    # Streaming (round 5): the inputs of bursts b + 1 and b + 2 are registered while burst b is processed; front end, Costas loop
+    # and the clock recovery's walkers of those bursts run ahead on the handle's own streams (the walkers of a burst wait for no
+    # other burst: csrc/clock_overlap.h) -- every timed step still pays one front end and one set of loops, all inside the timed
+    # region (nothing is registered before the clock starts: the first timed steps fill the pipeline).
     prefetch = not args.no_prefetch
 
     def ahead(b):
@@ -275,10 +281,11 @@ def main():
     t0 = time.perf_counter()
     nsym_total = 0
     if prefetch:
-        ahead(W)
+        for q in range(min(depth, K)):
+            ahead(W + q)
     for b in range(W, W + K):
-        if prefetch and b + 1 < W + K:
-            ahead(b + 1)
+        if prefetch and b + depth < W + K:
+            ahead(b + depth)
         nsym_total += step(b)
     barrier()
     t1 = time.perf_counter()
@@ -305,7 +312,7 @@ def main():
             b += chunk
         torch.cuda.synchronize(dev)
         prof = dem.profile_read()
-        for nm in ("fir_decim", "fir_rrc", "clock_pass", "costas_pass"):
+        for nm in ("fir_decim", "fir_rrc", "clock_pass", "costas_pass", "clock_overlap", "clock_relay"):
             v = sorted(dem.profile_samples(nm))
             if v:
                 dec_samples[nm] = {"min_ms": round(v[0], 4), "median_ms": round(v[len(v) // 2], 4), "max_ms": round(v[-1], 4),
@@ -341,6 +348,9 @@ def main():
         # (one launch bracket = the call's relay passes, three by default: each reads the stream and leaves a soft symbol and
         # a record word per symbol)
         "clock_relay": 3 * (c8 + 8.0 / (D * sps)),
+        # (round 5: ONE launch of overlapping exactly walked blocks: algorithmically one read of the stream and one soft symbol
+        # per symbol; the walkers read every sample 1 + history / range times)
+        "clock_overlap": c8 + 4.0 / (D * sps),
     }
     roofline = None
     kernels = {}
@@ -433,9 +443,12 @@ def main():
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
                    "segments": world, "bursts_reused": bool(W + K > nbuf),
-                   "clock_recovery": "cfg.clock_exact = 0 (default): no hand-off passes; %d relay passes over %d exactly walked segments, the first from the timing guess (last step: %d hand-off passes)" % (int(st.clock_relay_passes), int(st.clock_relay_segments), int(st.clock_passes)),
+                   "clock_recovery": ("cfg.clock_exact = 0 (default): %d overlapping exactly walked blocks, every walker started from the timing guess one history in front of its range (csrc/clock_overlap.h)" % int(st.clock_relay_segments))
+                                     if int(st.clock_relay_passes) == 1 and int(st.clock_passes) == 0 else
+                                     ("cfg.clock_exact = 0 (default): %d relay passes over %d exactly walked segments (last step: %d hand-off passes)" % (int(st.clock_relay_passes), int(st.clock_relay_segments), int(st.clock_passes))),
                    "front_end_of_next_burst_overlaps_loops": bool(prefetch),
-                   "next_burst_under_the_relay": "decimator, AGC, matched filter and Costas loop" if prefetch else "nothing", "costas_chain_len": args.costas_chain or 256,
+                   "inputs_registered_ahead": (depth if prefetch else 0),
+                   "ahead_of_a_call": "front end, Costas loop and clock-recovery walkers of the next two bursts" if prefetch and depth >= 2 else ("front end and Costas loop of the next burst" if prefetch else "nothing"), "costas_chain_len": args.costas_chain or 256,
                    "clock_chain_syms": args.clock_chain or "auto: whole generations of resident waves (112 at C2), 64..256"},
         "soft_symbols_per_s": round(nsym_all / elapsed, 1),
         "algorithmic_bytes_per_sample": round(b_alg, 4),
@@ -473,10 +486,11 @@ def main():
             x0 = time.perf_counter()
             # (streamed like the headline: the front end of burst b + 1 under the loops of burst b)
             if prefetch:
-                xd.prefetch_device(bursts[Wx % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+                for q in range(min(depth, Kx)):
+                    xd.prefetch_device(bursts[(Wx + q) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
             for b in range(Wx, Wx + Kx):
-                if prefetch and b + 1 < Wx + Kx:
-                    xd.prefetch_device(bursts[(b + 1) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+                if prefetch and b + depth < Wx + Kx:
+                    xd.prefetch_device(bursts[(b + depth) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
                 xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
                 sx = xd.stats()
                 closed = closed and bool(sx.clock_relay_closed)

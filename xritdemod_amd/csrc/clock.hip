@@ -465,6 +465,11 @@ __device__ __forceinline__ void clock_table_to_lds(float *dst, const float *__re
 
 }  // namespace xrit
 #include "clock_relay.h"
+namespace xrit {
+struct ClockResult;
+__device__ __forceinline__ double clk_count_at(const double *cnt, int nb, double sps, double t, double off, int BL);
+}
+#include "clock_overlap.h"
 #ifdef XRIT_EXPERIMENTS
 #include "../../experiments/csrc/clock_relay_wide.h"      // walker teams: built, verified, no faster; not in the shipped library
 #else
@@ -1013,6 +1018,8 @@ __global__ void __launch_bounds__(256) clock_jmean_kernel(const float4 *__restri
     }
 }
 
+static int relay_span(const ClockPar &par, int symbols);
+
 int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit, int chain_syms,
                      int max_passes_)
 {
@@ -1051,6 +1058,26 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     }
     cur = 0;
     carry = 0;
+    ov_enabled = getenv("XRIT_NO_OVERLAP") == nullptr;
+    if (const char *e = getenv("XRIT_OV_HIST")) { const int v = atoi(e); if (v >= 1024) ov_hist = v; }
+    if (const char *e = getenv("XRIT_OV_MIN")) { const long long v = atoll(e); if (v > 0) ov_min = v; }
+    if (const char *e = getenv("XRIT_OV_LRATIO")) { const double v = atof(e); if (v >= 0.125 && v <= 16.0) ov_lratio = v; }
+    {
+        // history a warm walker 0 needs in front of the new samples: its warm-up, the symbols it stages in front of the carried
+        // position, the two symbols of history its start state interpolates
+        const double wmax = (double)par.omega_mid + (double)par.omega_lim + 0.004;
+        ov_pad_need = (int)ceil((double)ov_hist * wmax) + XR_MM_NTAPS + XR_MM_FUDGE + 6 * (int)ceil(wmax) + 64;
+        ov_pad_need = (ov_pad_need + 15) & ~15;
+        // (only where the LDS-staged walker applies; else the pad stays what the carried tail needs)
+        const bool ring_ok = relay_span(par, 64) + 8 <= RELAY_RX - RELAY_XCH - 72;
+        xpad = 1024;
+        if (ov_enabled && ring_ok && (size_t)ov_pad_need > xpad) xpad = (size_t)ov_pad_need;
+        XR_TRY(ov_claim.reserve(RELAY_CLAIM_WORDS * sizeof(unsigned)));
+        XR_HIP(hipMemset(ov_claim.p, 0, RELAY_CLAIM_WORDS * sizeof(unsigned)));
+        for (auto &j : ov)
+            if (hipEventCreateWithFlags(&j.ev_walk, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&j.ev_guess, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return XRIT_E_HIP; }
+    }
     // diagnostics, read once, here (a host that calls setenv races with getenv on a launch path): the fallback paths of the
     // shipped configuration
     force_gated = getenv("XRIT_GATED_SOLVE") != nullptr;
@@ -1090,6 +1117,10 @@ int ClockStage::reset(hipStream_t s)
     cur = 0;
     carry = 0;
     x_pending = -1;         // (samples a producer has put in place for a call that will not come)
+    for (auto &j : ov) j.state = 0;     // (the caller has waited for whatever walked ahead: xrit_demod_reset synchronises its streams)
+    ov_job = -1;
+    hist_xb = -1; hist_len = 0; hist_job = -1;
+    if (ov_claim.p) (void)hipMemsetAsync(ov_claim.p, 0, RELAY_CLAIM_WORDS * sizeof(unsigned), s);
     om_ext = false;         // (... and its timing statistic and count curve)
     om_scanned = false;
     in_flight = false;
@@ -1109,7 +1140,15 @@ int ClockStage::reset(hipStream_t s)
 
 void ClockStage::release()
 {
-    table.release(); xbuf[0].release(); xbuf[1].release(); st.release(); S.release(); E.release(); J.release(); om.release();
+    for (auto &b : xbuf) b.release();
+    for (auto &j : ov) {
+        j.om.release(); j.om_work.release(); j.segs.release(); j.S.release(); j.stage.release(); j.aux.release();
+        if (j.ev_walk) (void)hipEventDestroy(j.ev_walk);
+        if (j.ev_guess) (void)hipEventDestroy(j.ev_guess);
+        j.ev_walk = nullptr; j.ev_guess = nullptr;
+    }
+    ov_claim.release();
+    table.release(); st.release(); S.release(); E.release(); J.release(); om.release();
     work.release(); counters.release(); sym.release(); dlin.release(); flags.release(); tail.release(); wsolve.release(); jmean.release();
     relay.release(); relay_rec.release(); alt.release(); stage.release(); om_work.release();
     if (h_res) (void)hipHostFree(h_res);
@@ -1120,6 +1159,13 @@ void ClockStage::release()
 // block b covering buffer samples [offset + b*BL, ...).  Returns where to write it (double2 per block).
 double2 *ClockStage::om_slot(int nb, int BL)
 {
+    if (ov_job >= 0 && ov[ov_job].state == 1) {
+        // (an overlap job keeps its own statistic and curve: the walkers of the job behind it read them for their first ranges)
+        OvJob &j = ov[ov_job];
+        if (nb < 1 || j.om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))) != XRIT_OK) return nullptr;
+        j.om_ext = true; j.om_scanned = false; j.nb = nb; j.BL = BL;
+        return j.om.as<double2>();
+    }
     if (nb < 1 || om.reserve((size_t)nb * (sizeof(double2) + sizeof(double))) != XRIT_OK) return nullptr;
     om_ext = true;
     om_scanned = false;
@@ -1135,6 +1181,20 @@ double2 *ClockStage::om_slot(int nb, int BL)
 // `carry` samples into the buffer.
 int ClockStage::om_scan(hipStream_t s)
 {
+    if (ov_job >= 0 && ov[ov_job].state == 1) {
+        OvJob &j = ov[ov_job];
+        if (!j.om_ext || j.nb < 1) return XRIT_OK;
+        const int nb = j.nb, nbB = scan_blocks(nb);
+        XR_TRY(j.om_work.reserve((size_t)(nbB + 2) * sizeof(double)));
+        double2 *X = j.om.as<double2>();
+        double *cnt = reinterpret_cast<double *>(j.om.as<char>() + (size_t)nb * sizeof(double2));
+        ClkUnwrapF uf{X, cnt, nb, (double)sps, 0.0, j.BL, 0.0};
+        hipLaunchKernelGGL(scan_reduce_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb, j.om_work.as<double>());
+        hipLaunchKernelGGL(scan_apply_lookback_kernel<ClkUnwrapF>, dim3(nbB), dim3(SCAN_BLOCK), 0, s, uf, (long long)nb, j.om_work.as<double>());
+        XR_HIP(hipGetLastError());
+        j.om_scanned = true;
+        return XRIT_OK;
+    }
     if (!om_ext || om_nb < 1) return XRIT_OK;
     const int nb = om_nb, nbB = scan_blocks(nb);
     XR_TRY(om_work.reserve((size_t)(nbB + 2) * sizeof(double)));
@@ -1152,12 +1212,32 @@ int ClockStage::om_scan(hipStream_t s)
 // previous call (those are copied in from the tail buffer when the call begins)
 int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
-    (void)s;
-    // (while a call is between begin() and finish() its walkers read xbuf[xb]: the next call's samples go to the other one)
-    const int b = in_flight ? xb ^ 1 : xb;
-    XR_TRY(xbuf[b].reserve((XPAD + n + 64 + 16) * sizeof(float2)));
+    // A buffer nobody reads: not the one of the call in flight, not one whose walkers are at work (overlap jobs), and not the
+    // one that holds the stream's last samples -- the history the next overlap call's first walkers warm up over.
+    bool busy[NXB] = {false, false, false};
+    if (in_flight) busy[xb] = true;
+    for (int q = 0; q < NXB; ++q) if (ov[q].state != 0) busy[q] = true;
+    int b = -1;
+    // (the call that follows the stream's last samples may not overwrite them -- unless nothing else is free)
+    for (int q = 0; q < NXB && b < 0; ++q) { const int c = (xb + 1 + q) % NXB; if (!busy[c] && c != hist_xb) b = c; }
+    for (int q = 0; q < NXB && b < 0; ++q) { const int c = (xb + q) % NXB; if (!busy[c]) b = c; }
+    if (b < 0) { set_error("clock recovery: no free sample buffer (three calls are already in flight)"); return XRIT_E_INVALID; }
+    // (a job whose first walkers warm up over what this buffer holds must have read it: its pad copy and start states)
+    for (int q = 0; q < NXB; ++q)
+        if (ov[q].state >= 2 && ov[q].hist_src == b) XR_HIP(hipStreamWaitEvent(s, ov[q].ev_guess, 0));
+    if (b == hist_xb) { hist_xb = -1; hist_len = 0; hist_job = -1; }
+    XR_TRY(xbuf[b].reserve((xpad + n + 64 + 16) * sizeof(float2)));
     x_pending = b;
-    *slot = xbuf[b].as<float2>() + XPAD;
+    *slot = xbuf[b].as<float2>() + xpad;
+    ov_job = -1;
+    if (ov_eligible(n)) {
+        OvJob &j = ov[b];
+        j.state = 1;
+        j.n = n;
+        j.om_ext = false; j.om_scanned = false; j.nb = 0;
+        j.serial = ++ov_serial;
+        ov_job = b;
+    }
     return XRIT_OK;
 }
 
@@ -1517,6 +1597,241 @@ int ClockStage::enqueue_output(hipStream_t s, Profiler *prof, bool again)
 }
 
 // Everything of one call is put on the stream without waiting: the carried tail, the timing guess, a batch of
+// ---- overlapping exactly walked blocks: host side (clock_overlap.h) -------------------------------------------------
+bool ClockStage::ov_eligible(size_t n) const
+{
+    if (!ov_enabled || !ov_allow || exact != 0 || relay_quick || serial || relay_global || xbase_fixed) return false;
+    if (relay_no_handoff == 0 || auto_passes <= 0) return false;          // (A/B switches that ask for round 3's / round 2's plans)
+    if ((size_t)ov_pad_need > xpad) return false;                          // (no LDS-staged walker at this symbol rate)
+    if (n >= ((size_t)1 << 31) - xpad - 4096) return false;
+    return (double)n / (double)par.omega_mid >= (double)ov_min;
+}
+
+// the job's ranges.  `ahead`: the call in front has not finished -- its carry is not known; such a job needs the history.
+int ClockStage::ov_plan(OvJob &j, bool ahead)
+{
+    const double wmax = (double)par.omega_mid + (double)par.omega_lim + 0.004, wmin = (double)par.omega_mid - (double)par.omega_lim;
+    const int cw = (int)ceil(wmax);
+    j.hist = (int)ceil((double)ov_hist * (double)par.omega_mid);
+    j.early = (int)ceil(1.5 * wmax) + 2;
+    // history: the samples the call in front left at the end of its buffer, and the timing curve that covers them
+    const bool have_hist = hist_xb >= 0 && hist_len >= (size_t)ov_pad_need && hist_job >= 0 && ov[hist_job].om_scanned;
+    if (ahead && !have_hist) { set_error("clock recovery: an overlap job cannot start ahead without the history of the call in front"); return XRIT_E_INVALID; }
+    j.ahead = ahead;
+    if (have_hist) {
+        j.padN = ov_pad_need;
+        j.w0_carried = false;
+        j.w0_ii = ahead ? 0 : j.padN - (int)carry;          // (ahead: the scan kernel is told at the call, ov_finalize)
+        // the carried state reads its next symbol 19 .. 24 + a period samples in front of the new ones (the walk in front stops at
+        // the first read index within 8 + 16 samples of its end): staging starts a period in front of that
+        j.store0 = j.padN - (XR_MM_NTAPS + XR_MM_FUDGE) - cw - 2;
+    } else {
+        if (carry > 1024) { set_error("clock recovery: carry of %zu samples exceeds the hand-over buffer", carry); return XRIT_E_INVALID; }
+        j.padN = (int)carry;
+        j.w0_carried = true;
+        j.w0_ii = 0;
+        j.store0 = 0;
+    }
+    j.N = (long long)j.padN + (long long)j.n;
+    j.ni = j.N - XR_MM_NTAPS - XR_MM_FUDGE;
+    // walkers: ranges about as long as the history in front of them (every symbol is walked twice), at least 240 of them where
+    // the call is long enough for ranges of 8192 symbols (few walkers: their latency is the call's), at most four per CU
+    const double nsym = (double)j.n / (double)par.omega_mid;
+    double gt = nsym / ((double)ov_hist * ov_lratio);
+    if (gt < 240.0) gt = 240.0;
+    if (nsym / gt < 8192.0) gt = nsym / 8192.0;
+    if (gt > 4.0 * cu_count - 2.0) gt = 4.0 * cu_count - 2.0;
+    if (gt < 1.0) gt = 1.0;
+    long long Ls = (long long)ceil((double)j.n / gt);
+    Ls = (Ls + 63) & ~63LL;
+    if (Ls < 4096) Ls = 4096;
+    j.Ls = (int)Ls;
+    // range 0 ends where walker 1 has its whole history behind it
+    const long long w0_start = j.w0_carried ? 0 : (long long)j.store0 - j.hist;
+    long long fb = w0_start + j.hist + Ls;
+    if (fb < (long long)j.padN + Ls) fb = (long long)j.padN + Ls;
+    j.first_bound = (int)fb;
+    // (the last range is not shorter than a quarter of the others)
+    const long long lim = j.N - Ls / 4;
+    j.G = fb <= lim ? 2 + (int)((lim - fb) / Ls) : 1;
+    const long long last_start = j.G >= 2 ? fb + (long long)(j.G - 2) * Ls : (long long)j.store0;
+    long long longest = fb - j.store0;
+    if (j.G >= 2 && Ls + j.early > longest) longest = Ls + j.early;
+    if (j.N - last_start + j.early > longest) longest = j.N - last_start + j.early;
+    if (j.G == 1) longest = j.N - j.store0;
+    long long stride = (long long)ceil((double)longest / wmin) + 64;
+    stride = (stride + 63) & ~63LL;
+    if (stride * j.G >= (1LL << 31)) { set_error("clock recovery: call too long for the overlap plan"); return XRIT_E_INVALID; }
+    j.stride = (int)stride;
+    XR_TRY(j.segs.reserve((size_t)j.G * sizeof(OverlapSeg)));
+    XR_TRY(j.S.reserve((size_t)j.G * sizeof(ClockState)));
+    XR_TRY(j.stage.reserve((size_t)j.G * (size_t)j.stride * sizeof(float) + 256));
+    // aux: [0, 8) counters, [8, 12) moments (two 64-bit words), then j0[G] and offs[G] (64-bit, 8-byte aligned)
+    XR_TRY(j.aux.reserve(64 + (size_t)j.G * sizeof(int) + 8 + (size_t)j.G * sizeof(unsigned long long)));
+    return XRIT_OK;
+}
+
+bool ClockStage::ov_can_launch_ahead(int job) const
+{
+    if (job < 0 || job >= NXB || ov[job].state != 1 || !ov[job].om_scanned) return false;
+    // the job in front must be an overlap job whose samples and timing curve are in place (its walkers may still be at work)
+    for (int q = 0; q < NXB; ++q)
+        if (q != job && ov[q].state >= 1 && ov[q].serial + 1 == ov[job].serial)
+            return ov[q].om_scanned && (size_t)ov[q].padN + ov[q].n >= (size_t)ov_pad_need && ov[q].state >= 2;
+    return false;
+}
+
+static inline unsigned *ov_stat(ClockStage::OvJob &j) { return j.aux.as<unsigned>(); }
+static inline unsigned long long *ov_moments(ClockStage::OvJob &j) { return reinterpret_cast<unsigned long long *>(j.aux.as<unsigned>() + 8); }
+static inline unsigned long long *ov_offs(ClockStage::OvJob &j) { return reinterpret_cast<unsigned long long *>(j.aux.as<char>() + 64); }
+static inline int *ov_j0(ClockStage::OvJob &j) { return reinterpret_cast<int *>(j.aux.as<char>() + 64 + (size_t)j.G * sizeof(unsigned long long)); }
+
+int ClockStage::ov_launch(int job, hipStream_t sw, bool ahead, Profiler *prof)
+{
+    OvJob &j = ov[job];
+    // the history: the job in front when launched ahead (it has not finished: hist_* still describe the call before it)
+    int h_xb = hist_xb, h_job = hist_job;
+    size_t h_len = hist_len;
+    size_t h_n = 0;
+    if (ahead) {
+        int front = -1;
+        for (int q = 0; q < NXB; ++q) if (q != job && ov[q].state >= 1 && ov[q].serial + 1 == j.serial) front = q;
+        if (front < 0) { set_error("clock recovery: no job in front of a job launched ahead"); return XRIT_E_INVALID; }
+        h_xb = front; h_job = front; h_len = (size_t)ov[front].padN + ov[front].n;
+        // (the plan looks at hist_*: described for the duration of the plan)
+        const int k_xb = hist_xb, k_job = hist_job; const size_t k_len = hist_len;
+        hist_xb = h_xb; hist_job = h_job; hist_len = h_len;
+        const int rc = ov_plan(j, true);
+        hist_xb = k_xb; hist_job = k_job; hist_len = k_len;
+        XR_TRY(rc);
+    } else {
+        XR_TRY(ov_plan(j, false));
+    }
+    float2 *data = xbuf[job].as<float2>() + xpad;
+    float2 *base = data - j.padN;
+    if (!j.w0_carried) {
+        // the last padN samples of the stream in front of the new ones
+        if (!(h_job >= 0 && h_xb == h_job) || h_len < (size_t)j.padN) { set_error("clock recovery: history without its job"); return XRIT_E_INVALID; }
+        h_n = ov[h_job].n;
+        const float2 *hend = xbuf[h_xb].as<float2>() + xpad + h_n;
+        XR_HIP(hipMemcpyAsync(base, hend - j.padN, (size_t)j.padN * sizeof(float2), hipMemcpyDeviceToDevice, sw));
+        j.hist_src = h_xb;
+    } else if (j.padN > 0) {
+        hipLaunchKernelGGL(clock_tail_kernel, dim3(1), dim3(1024), 0, sw, tail.as<float2>() + 1024 * cur, base, j.padN);
+    }
+    // the timing curve: the producer's (Costas final pass + om_scan), else computed here
+    const int BL = j.om_ext ? j.BL : CLK_OM_BLOCK;
+    if (!j.om_ext) {
+        j.nb = (int)((j.n + CLK_OM_BLOCK - 1) / CLK_OM_BLOCK);
+        j.BL = CLK_OM_BLOCK;
+        XR_TRY(j.om.reserve((size_t)j.nb * (sizeof(double2) + sizeof(double))));
+        hipLaunchKernelGGL(clock_om_kernel, dim3(div_up((size_t)j.nb, 4)), dim3(256), 0, sw, data, j.om.as<double2>(), (long long)j.n, j.nb,
+                           1.0 / (double)sps);
+        j.om_ext = true;
+    }
+    if (!j.om_scanned) {
+        const int k_job = ov_job;
+        const int k_state = j.state;
+        ov_job = job; j.state = 1;
+        const int rc = om_scan(sw);
+        ov_job = k_job; j.state = k_state;
+        XR_TRY(rc);
+    }
+    const double *cnt = reinterpret_cast<const double *>(j.om.as<char>() + (size_t)j.nb * sizeof(double2));
+    const double *cnt_prev = nullptr;
+    int nb_prev = 0;
+    if (!j.w0_carried && h_job >= 0) {
+        OvJob &p = ov[h_job];
+        cnt_prev = reinterpret_cast<const double *>(p.om.as<char>() + (size_t)p.nb * sizeof(double2));
+        nb_prev = p.nb;
+        if (p.BL != BL) { set_error("clock recovery: timing curves of consecutive calls differ in their block length"); return XRIT_E_INVALID; }
+    }
+    OverlapArgs a{};
+    a.x = base; a.table = table.as<float>(); a.N = j.N; a.ni = j.ni;
+    a.start = j.S.as<ClockState>(); a.G = j.G; a.store0 = j.store0; a.first_bound = j.first_bound; a.Ls = j.Ls; a.early = j.early;
+    a.stride = j.stride; a.stage = j.stage.as<float>(); a.segs = j.segs.as<OverlapSeg>(); a.par = par;
+    {
+        const float om = par.omega_mid, su = par.omega_mid + 0.5f;
+        const double u = 1.0 / 16777216.0;
+        a.q_om = (int)((double)(nextafterf(om, INFINITY) - om) / u);
+        a.q_mu = (int)((double)(nextafterf(su, INFINITY) - su) / u);
+        if (a.q_om < 1) a.q_om = 1;
+        if (a.q_mu < 1) a.q_mu = 1;
+    }
+    a.stat = ov_stat(j); a.moments = ov_moments(j); a.simd_claim = relay_no_claim ? nullptr : ov_claim.as<unsigned>();
+    const int span = relay_span(par, 64);
+    j.hist_src = j.w0_carried ? -1 : j.hist_src;
+    {
+        ProfScope ps(prof, "clock_guess", sw);
+        hipLaunchKernelGGL(clock_overlap_guess_kernel, dim3(div_up((size_t)j.G, 256)), dim3(256), 0, sw, cnt, j.nb, cnt_prev, nb_prev,
+                           (long long)h_n, BL, (double)sps, par.omega_mid, base, table.as<float>(), j.ni, j.padN, j.hist, j.G, j.store0,
+                           j.first_bound, j.Ls, st.as<ClockState>() + cur, j.w0_carried ? 1 : 0, j.w0_ii, 0, j.S.as<ClockState>(),
+                           a.stat, a.moments);
+    }
+    XR_HIP(hipEventRecord(j.ev_guess, sw));       // (from here on the history this job was started from may be overwritten)
+    {
+        ProfScope ps(prof, "clock_overlap", sw);
+        hipLaunchKernelGGL(clock_overlap_kernel, dim3(j.G), dim3(128), 0, sw, a, span);
+    }
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipEventRecord(j.ev_walk, sw));
+    j.state = 2;
+    return XRIT_OK;
+}
+
+int ClockStage::ov_restart(int job, hipStream_t s)
+{
+    (void)s;
+    if (job < 0 || job >= NXB) return XRIT_OK;
+    OvJob &j = ov[job];
+    if (j.state == 2) XR_HIP(hipEventSynchronize(j.ev_walk));
+    if (j.state >= 1) { j.state = 1; j.om_scanned = false; }
+    return XRIT_OK;
+}
+
+// a call that began as an overlap job and whose result is not taken (low Es/N0: the default walks such calls to closure; a joint
+// that did not fit: a timing guess off by a symbol): the relay of clock_relay.h, to closure, on the same samples
+int ClockStage::ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof)
+{
+    const int job = ov_cur;
+    OvJob &j = ov[job];
+    ov_cur = -1;
+    j.state = 0;
+    const int k_exact = exact;
+    exact = 1;
+    xb = job;
+    xbase_fixed = xbuf[job].as<float2>() + xpad - carry;        // (the call's samples lie where they were produced; the tail goes in front)
+    const int rc = run(j.n, ov_soft, nullptr, ov_cap, n_out, s, prof);
+    xbase_fixed = nullptr;
+    exact = k_exact;
+    if (rc == XRIT_OK) { hist_xb = job; hist_len = (size_t)j.padN + j.n; hist_job = job; }
+    ov_fell_back = true;
+    return rc;
+}
+
+// the joints, the output and the call's result, on the call's stream behind the walkers
+int ClockStage::ov_finalize(int job, float *soft_out, size_t cap, hipStream_t s, Profiler *prof)
+{
+    OvJob &j = ov[job];
+    XR_HIP(hipStreamWaitEvent(s, j.ev_walk, 0));
+    if (j.ahead) j.w0_ii = j.padN - (int)carry;        // (known now: the call in front has finished)
+    {
+        ProfScope ps(prof, "clock_joints", s);
+        hipLaunchKernelGGL(clock_reset_kernel, dim3(1), dim3(256), 0, s, counters.as<unsigned>(), CLK_CTL_WORDS, (int *)nullptr);
+        hipLaunchKernelGGL(clock_overlap_scan_kernel, dim3(1), dim3(256), 0, s, j.segs.as<OverlapSeg>(), j.G, j.stride,
+                           st.as<ClockState>() + cur, j.w0_ii, j.w0_carried ? 1 : 0, par.omega_mid, ov_j0(j), ov_offs(j),
+                           st.as<ClockState>() + (cur ^ 1), clock_res(counters), xbuf[job].as<float2>() + xpad - j.padN,
+                           tail.as<float2>() + 1024 * (cur ^ 1), j.N, clock_ctl(counters), ov_moments(j), (unsigned long long)cap);
+        if (soft_out)
+            hipLaunchKernelGGL(clock_overlap_copy_kernel, dim3(div_up((size_t)j.stride, 1024), j.G), dim3(256), 0, s, j.stage.as<float>(),
+                               j.segs.as<OverlapSeg>(), ov_j0(j), ov_offs(j), j.stride, soft_out, (unsigned long long)cap, clock_res(counters));
+    }
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(h_res, counters.p, CLK_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    j.state = 3;
+    return XRIT_OK;
+}
+
 // hand-off passes (no-ops once the device-side test has declared the hand-off closed), the output pass and the
 // copy of the control block.  finish() runs after the caller has synchronised the stream.
 int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hipStream_t s, Profiler *prof)
@@ -1528,6 +1843,31 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     prev_carry = carry;
     prev_n = n;
     redo_ok = false;
+    ov_fell_back = false;
+    // this call's overlap job, if its samples were produced into one (input_slot): the oldest job that waits for its call
+    ov_cur = -1;
+    if (!xbase_fixed) {
+        unsigned long long first = ~0ull;
+        for (int q = 0; q < NXB; ++q)
+            if ((ov[q].state == 1 || ov[q].state == 2) && ov[q].serial < first) { first = ov[q].serial; ov_cur = q; }
+        if (ov_cur >= 0 && (ov[ov_cur].n != n || sym_out != nullptr)) {
+            set_error("clock recovery: the call does not match the overlap job its samples were produced for");
+            return XRIT_E_INVALID;
+        }
+    }
+    if (ov_cur >= 0) {
+        job = Job{};
+        job.n = n; job.soft = soft_out; job.cap = cap;
+        xb = ov_cur;
+        x_pending = -1;
+        ov_job = -1;
+        in_flight = true;
+        om_ext = false; om_scanned = false;
+        ov_soft = soft_out; ov_cap = cap;
+        carry_before_fallback = carry;
+        if (ov[ov_cur].state == 1) XR_TRY(ov_launch(ov_cur, s, false, prof));
+        return ov_finalize(ov_cur, soft_out, cap, s, prof);
+    }
     job = Job{};
     Job &j = job;
     j.n = n; j.soft = soft_out; j.sym = sym_out; j.cap = cap;
@@ -1537,7 +1877,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     if (!xbase_fixed) {
         if (x_pending >= 0) xb = x_pending;
         x_pending = -1;
-        XR_TRY(xbuf[xb].reserve((size_t)(XPAD + n + 64 + 16) * sizeof(float2)));
+        XR_TRY(xbuf[xb].reserve((size_t)(xpad + n + 64 + 16) * sizeof(float2)));
     }
     in_flight = true;
     float2 *x = xbase();
@@ -1758,6 +2098,55 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
 {
     *n_out = 0;
     in_flight = false;      // (the caller has synchronised: whatever finish() still enqueues it waits for itself)
+    if (ov_cur >= 0) {
+        OvJob &oj = ov[ov_cur];
+        const int *hc = reinterpret_cast<const int *>(h_res);
+        ClockResult r;
+        memcpy(&r, reinterpret_cast<const unsigned *>(h_res) + CLK_RES_WORD, sizeof r);
+        float snr2, far_;
+        memcpy(&snr2, &hc[14], sizeof snr2);
+        memcpy(&far_, &hc[18], sizeof far_);
+        snr_estimate = snr2;
+        ov_walkers = oj.G;
+        ov_joint_max = far_;
+        relay_passes = 1;
+        relay_closed = false;
+        relay_auto = false;
+        relay_segments = oj.G;
+        relay_seg_chains = 0;
+        passes = 0;
+        if (trace_env) {
+            unsigned hs[8];
+            XR_HIP(hipMemcpy(hs, oj.aux.p, sizeof hs, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[xrit] overlap: %d walkers over ranges of %d samples behind %d samples of history (%s), %u steps, %.2f guess rounds per step; "
+                            "joints: %d do not fit, largest distance %.3e sample; 2 Es/N0 = %.1f; %llu symbols%s\n",
+                    oj.G, oj.Ls, oj.hist, oj.w0_carried ? "walker 0 from the carried state" : "walker 0 warms up in the burst before", hs[0],
+                    hs[0] ? (double)hs[1] / hs[0] : 0.0, hc[17], (double)far_, (double)snr2, (unsigned long long)r.n_symbols, r.ok ? "" : " -- NOT taken");
+        }
+        if (hc[15]) { set_error("clock recovery: a walker gave up waiting for its sample ring (watchdog)"); oj.state = 0; ov_cur = -1; return XRIT_E_HIP; }
+        // The default configuration's two looks at such a call (ClockStage::finish below has them for the relay): Es/N0 below 7 dB
+        // -- walked to closure, the serial trajectory whatever the noise --, and a joint whose two trajectories do not meet within a
+        // quarter symbol -- the timing guess and the loop disagree about a symbol count.
+        const bool signal = snr2 >= auto_snr_floor;
+        if ((signal && !(snr2 >= auto_snr)) || hc[17] > 0 || (!r.ok && r.n_symbols <= oj.stride * (unsigned long long)oj.G && (size_t)r.n_symbols <= ov_cap && hc[17] > 0))
+            return ov_fallback(n_out, s, prof);
+        oj.state = 0;
+        const int jb = ov_cur;
+        ov_cur = -1;
+        if (!r.ok) {
+            if ((size_t)r.n_symbols > ov_cap) { set_error("clock recovery produced %zu symbols, capacity %zu", (size_t)r.n_symbols, ov_cap); return XRIT_E_CAPACITY; }
+            set_error("clock recovery: the walkers did not reach the end of the input");
+            return XRIT_E_INVALID;
+        }
+        cur ^= 1;
+        carry = (size_t)(oj.N - r.ii_final);
+        if (carry > 1024) { set_error("clock recovery: carry of %zu samples exceeds the hand-over buffer", carry); return XRIT_E_INVALID; }
+        last_symbols = (size_t)r.n_symbols;
+        *n_out = last_symbols;
+        hist_xb = jb; hist_len = (size_t)oj.padN + oj.n; hist_job = jb;
+        redo_ok = true;
+        return XRIT_OK;
+    }
     if (job.short_input) {
         carry = (size_t)job.N;
         last_symbols = 0;
@@ -1975,6 +2364,8 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         return XRIT_E_CAPACITY;
     }
     redo_ok = true;
+    // (what this call left in its buffer is history for an overlap call behind it only together with a timing curve: none here)
+    hist_xb = xbase_fixed ? hist_xb : xb; hist_len = xbase_fixed ? hist_len : prev_carry + prev_n; hist_job = xbase_fixed ? hist_job : -1;
     return XRIT_OK;
 }
 
@@ -2028,7 +2419,7 @@ int ClockStage::redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_
     }
     if (n) hipLaunchKernelGGL(clock_negate_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, data, n);
     XR_HIP(hipGetLastError());
-    xbase_fixed = data - carry;             // (carry <= 1024 = XPAD: never in front of the buffer)
+    xbase_fixed = data - carry;             // (carry <= 1024 <= xpad: never in front of the buffer)
     const int rc = run(n, soft_out, sym_out, cap, n_out, s, prof);
     xbase_fixed = nullptr;
     return rc;

@@ -4,8 +4,10 @@
 // :436-450 (construction); constants from Parameters.h:16-37.
 #include "kernels.h"
 
+#include <chrono>
 #include <cmath>
 #include <new>
+#include <thread>
 
 namespace xrit {
 
@@ -56,6 +58,9 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
+    hipStream_t stream3[3] = {nullptr, nullptr, nullptr};           // the clock recovery's walkers of bursts started ahead (round 5):
+                                                                    // one stream per job, so that two bursts' walkers run side by side
+    hipEvent_t ev_done = nullptr;                                   // the current call's clock recovery has left its result
     hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
     hipEvent_t ev_relay = nullptr;                                  // the relay kernels of the current call come next
     hipEvent_t ev_costas = nullptr;                                 // the Costas loop started ahead on stream2 has run its batch
@@ -66,11 +71,17 @@ struct xrit_demod {
         size_t length = 0; const float2 *rrc = nullptr; bool stat_ready = false; const float *agc_flag = nullptr;
         bool costas_begun = false;      // the Costas loop of this input has been started too (on stream2, behind its front end)
         float2 *slot = nullptr;         // ... writing here (the clock recovery's next input buffer)
+        // round 5, bursts whose clock recovery walks overlapping blocks (clock_overlap.h): everything up to the walkers runs ahead
+        bool costas_finished = false;   // the host has looked at the loop's stop test (and continued it where it had not closed)
+        int ov_job = -1;                // the clock stage's job of this input
+        bool walk_launched = false;     // its walkers have been enqueued (stream3)
+        bool agc_fallback = false;      // what the AGC's guard and the Costas loop reported for this input
+        int c_passes = 0; unsigned c_unconverged = 0; float c_max_residual = 0; bool c_walked = false;
         bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
                                 // starts the front end of the next burst in front of the relay kernels of the current one,
                                 // which leave most of the chip idle, instead of under the loops that fill it
-    } pf[2];                    // front ends that ran ahead, oldest first: the one of the next process call, and
-    int pf_count = 0;           // at most the one after it
+    } pf[3];                    // inputs registered ahead, oldest first: the one of the next process call and the two behind it
+    int pf_count = 0;
     RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
     // what the Costas loop of the CURRENT call reported when it was finished: taken there, because with a registered next input the
@@ -217,6 +228,9 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if (hipStreamCreate(&d->stream) != hipSuccess ||
             hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
+            hipStreamCreate(&d->stream3[0]) != hipSuccess || hipStreamCreate(&d->stream3[1]) != hipSuccess ||
+            hipStreamCreate(&d->stream3[2]) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess ||
@@ -252,9 +266,12 @@ void xrit_demod_destroy(xrit_demod *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
+    for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
+    for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
     if (d->ev_relay) (void)hipEventDestroy(d->ev_relay);
     if (d->ev_costas) (void)hipEventDestroy(d->ev_costas);
@@ -274,6 +291,12 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
+    for (auto w : d->stream3) XR_HIP(hipStreamSynchronize(w));      // ... and so do walkers
+    if (d->costas.job.n && d->pf_count > 0) {
+        // (a Costas loop begun ahead and never looked at: the stage's bookkeeping is brought to an end before its state is reset)
+        for (int i = 0; i < d->pf_count; ++i)
+            if (d->pf[i].costas_begun && !d->pf[i].costas_finished) { bool redone = false; (void)d->costas.finish(d->stream2, nullptr, &redone); }
+    }
     d->pf_count = 0;
     d->last_fe_set = -1;
     XR_TRY(d->dec.reset(s));
@@ -519,6 +542,157 @@ static int loops(xrit_demod *d, const SliceIO &io, float *d_soft, size_t cap, si
     return rc;
 }
 
+// ---- round 5: bursts whose clock recovery walks overlapping blocks (clock_overlap.h) -----------------------------------------
+// Nothing in such a burst's clock recovery waits for the burst in front of it, so EVERYTHING up to its walkers runs ahead of
+// its process call: front end and Costas loop on stream2 (in the order of the inputs: the stages carry their state from one
+// to the next), the walkers on stream3 behind the Costas loop.  With two inputs registered behind the current call
+// (xrit_demod_prefetch_device) the device holds, at any time, the walkers of bursts b and b + 1 and the front end / Costas loop
+// of burst b + 2; a process call enqueues what the newest registration allows, waits for its own walkers and lays out its
+// symbols (ClockStage::ov_finalize) -- the relay's latency, which bounded a burst in round 4, is hidden.
+static bool ov_call(xrit_demod *d, size_t n)
+{
+    const unsigned D = d->cfg.decimation;
+    d->clock.ov_allow = !(d->keep_stages || d->keep_symbols);
+    return d->clock.ov_eligible(D > 1 ? n / D : n);
+}
+
+// whatever can be enqueued for the registered inputs, oldest first, without waiting for the device.  Returns an error code;
+// *progress: something was enqueued or finished.
+static int ov_service(xrit_demod *d, bool *progress)
+{
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    if (progress) *progress = false;
+    bool costas_busy = false;       // a Costas loop begun and not yet finished: the stage takes the next input behind it
+    for (int i = 0; i < d->pf_count; ++i) {
+        xrit_demod::Prefetched &f = d->pf[i];
+        if (!ov_call(d, f.n)) break;                    // (inputs that take the other path are started by their own calls)
+        // (two sets of front-end buffers: the input two in front used the set this one takes, and its Costas loop reads that set
+        // until the host has seen it close -- a loop that did not close inside its batch goes on from the host)
+        if (!f.launched && (i < 2 || d->pf[i - 2].costas_finished)) {
+            XR_TRY(launch_prefetched(d, f, nullptr));
+            if (progress) *progress = true;
+        }
+        if (!f.launched) break;
+        if (f.costas_begun && !f.costas_finished) {
+            if (hipEventQuery(d->ev_costas) != hipSuccess) { costas_busy = true; continue; }
+            if (f.length && d->agc.requested_flag() == 2.0f) f.agc_fallback = true;
+            bool redone = false;
+            int rc = d->costas.finish(d->stream2, prof, &redone);
+            if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+            f.c_passes = d->costas.passes; f.c_unconverged = d->costas.unconverged; f.c_max_residual = d->costas.max_residual;
+            f.c_walked = d->costas.job.rescued && d->costas.walked;
+            f.costas_finished = true;
+            if (redone && f.ov_job >= 0) {
+                // the loop went on from the host and rewrote its output (and the timing statistic): walkers that were started
+                // behind the first batch have read the old one
+                rc = d->clock.ov_restart(f.ov_job, d->stream2);
+                if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+                f.walk_launched = false;
+            }
+            if (progress) *progress = true;
+        }
+        if (!f.costas_begun && !costas_busy) {
+            SliceIO io;
+            io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+            int rc = costas_enqueue(d, io, d->stream2, prof, &f.slot);
+            if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+            XR_HIP(hipEventRecord(d->ev_costas, d->stream2));
+            f.costas_begun = true;
+            f.ov_job = d->clock.ov_job;
+            costas_busy = true;
+            if (progress) *progress = true;
+        }
+        if (f.costas_begun && f.ov_job >= 0 && !f.walk_launched && d->clock.ov_can_launch_ahead(f.ov_job)) {
+            // (behind the Costas loop's batch and the timing curve: speculative until the host has seen the loop's stop test)
+            hipStream_t sw = d->stream3[f.ov_job % 3];
+            XR_HIP(hipStreamWaitEvent(sw, d->ev_costas, 0));
+            int rc = d->clock.ov_launch(f.ov_job, sw, true, prof);
+            if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+            f.walk_launched = true;
+            if (progress) *progress = true;
+        }
+        if (!f.costas_begun || !f.costas_finished) costas_busy = true;      // (the inputs behind wait for this one's loop)
+    }
+    return XRIT_OK;
+}
+
+static int process_overlap(xrit_demod *d, const void *d_samples, size_t n, int type, float *d_soft, size_t cap, size_t *n_out,
+                           hipStream_t s, Profiler *prof)
+{
+    // the call's own input goes through the same queue: registered now if it was not registered ahead
+    if (d->pf_count > 0) {
+        if (d->pf[0].samples != d_samples || d->pf[0].n != n || d->pf[0].type != type) {
+            set_error("process calls must take the prefetched inputs in the order they were prefetched");
+            d->poisoned = true;
+            return XRIT_E_INVALID;
+        }
+    } else {
+        XR_HIP(hipEventRecord(d->ev_ready, s));
+        xrit_demod::Prefetched &f = d->pf[0];
+        f = xrit_demod::Prefetched{};
+        f.samples = d_samples; f.n = n; f.type = type; f.launched = false;
+        d->pf_count = 1;
+    }
+    auto fail = [&](int rc) { d->poisoned = true; *n_out = 0; return rc; };
+    int rc = ov_service(d, nullptr);
+    if (rc != XRIT_OK) return fail(rc);
+    // this call's Costas loop must have been looked at before its clock recovery is laid out
+    for (int spins = 0; !d->pf[0].costas_finished; ++spins) {
+        if (d->pf[0].costas_begun) { if (hipEventSynchronize(d->ev_costas) != hipSuccess) { set_error("hipEventSynchronize failed"); return fail(XRIT_E_HIP); } }
+        if ((rc = ov_service(d, nullptr)) != XRIT_OK) return fail(rc);
+        if (spins > 8) { set_error("the Costas loop of the call could not be started"); return fail(XRIT_E_INVALID); }
+    }
+    xrit_demod::Prefetched &f0 = d->pf[0];
+    d->agc_fallback_seen = f0.agc_fallback;
+    d->costas_seen.passes = f0.c_passes; d->costas_seen.unconverged = f0.c_unconverged;
+    d->costas_seen.max_residual = f0.c_max_residual; d->costas_seen.walked = f0.c_walked;
+    // joints, output and result behind this call's walkers (started here if they did not run ahead), on the call's stream.
+    // (the host has SEEN the end of everything stream2 did for this input -- the Costas loop's event, a continued loop's
+    // synchronise --, so s needs no event of stream2's; the finalize kernels wait for the walkers' event)
+    rc = d->clock.begin(f0.length, d_soft, nullptr, cap, s, prof);
+    if (rc != XRIT_OK) return fail(rc);
+    if (hipEventRecord(d->ev_done, s) != hipSuccess) { set_error("hipEventRecord failed"); return fail(XRIT_E_HIP); }
+    // while the walkers finish: keep the inputs behind this one moving (the Costas loop of the next one may close meanwhile,
+    // which frees the stage for the one after it)
+    for (;;) {
+        const hipError_t q = hipEventQuery(d->ev_done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return fail(XRIT_E_HIP); }
+        bool progress = false;
+        if ((rc = ov_service(d, &progress)) != XRIT_OK) return fail(rc);
+        if (!progress) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    size_t nsym = 0;
+    rc = d->clock.finish(&nsym, s, prof);
+    const size_t length = f0.length;
+    for (int i = 1; i < d->pf_count; ++i) d->pf[i - 1] = d->pf[i];
+    --d->pf_count;
+    if (rc != XRIT_OK) return fail(rc);
+    if (prof) d->prof.collect();
+    d->stage_n[4] = nsym;
+    d->stats.samples_in = n;
+    d->stats.circuit_samples = length;
+    d->stats.symbols_out = nsym;
+    d->stats.costas_passes = d->costas_seen.passes;
+    d->stats.clock_passes = d->clock.passes;
+    d->stats.costas_unconverged = d->costas_seen.unconverged;
+    d->stats.clock_unconverged = d->clock.unconverged;
+    d->stats.costas_max_residual = d->costas_seen.max_residual;
+    d->stats.clock_max_residual = d->clock.max_residual;
+    d->stats.agc_serial_fallback = d->agc_fallback_seen;
+    d->stats.clock_open_large = d->clock.large_open;
+    d->stats.costas_serial_walk = d->costas_seen.walked ? 1 : 0;
+    d->stats.clock_relay_passes = d->clock.relay_passes;
+    d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
+    d->stats.clock_relay_segments = d->clock.relay_segments;
+    *n_out = nsym;
+    if (d->cfg.strict && d->costas_seen.unconverged) {
+        set_error("Costas hand-off did not close: %u boundaries above tolerance", d->costas_seen.unconverged);
+        return XRIT_E_NOT_CONVERGED;
+    }
+    return XRIT_OK;
+}
+
 int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, int type, float *d_soft, size_t cap,
                               size_t *n_out, void *stream)
 {
@@ -545,6 +719,9 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
             return XRIT_E_CAPACITY;    // end that ran ahead stays queued for the retry with the same (pointer, n, type)
         }
     }
+    // (round 5: bursts of a million symbols and more in the default configuration)
+    if (ov_call(d, n) && !(d->pf_count > 0 && d->pf[0].costas_begun && d->pf[0].ov_job < 0))
+        return process_overlap(d, d_samples, n, type, d_soft, cap, n_out, s, prof);
     size_t total_sym = 0, total_len = 0;
     d->agc_fallback_seen = false;
     SliceIO io;
@@ -560,7 +737,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         // (registered only: the call before had no relay phase to put it in front of)
         if (!d->pf[0].launched) XR_TRY(launch_prefetched(d, d->pf[0], nullptr));
         const xrit_demod::Prefetched f = d->pf[0];
-        d->pf[0] = d->pf[1];
+        for (int i = 1; i < d->pf_count; ++i) d->pf[i - 1] = d->pf[i];
         --d->pf_count;
         io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
         if (f.costas_begun) {
@@ -678,7 +855,7 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     if (!d || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
     if (type < 0 || type > 3) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
     if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
-    if (d->pf_count >= 2) { set_error("two prefetched inputs are already waiting for their process calls"); return XRIT_E_INVALID; }
+    if (d->pf_count >= 3) { set_error("three prefetched inputs are already waiting for their process calls"); return XRIT_E_INVALID; }
     // stage copies and per-kernel event brackets belong to one call at a time: no running ahead then
     if (d->keep_stages || d->keep_symbols || (d->prof.enabled && !d->prof.light)) return XRIT_OK;
     XR_HIP(hipSetDevice(d->device));
@@ -693,7 +870,8 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     // waves per CU: the front end waits for those (ClockStage::before_relay) instead of competing with the Costas and
     // hand-off passes.  (Registered inputs start in order: the process call that takes one starts it if it still waits,
     // and starts the one behind it in front of its own relay kernels.)
-    const bool defer = d->clock.relay_by_default() && !d->no_defer;
+    // (bursts whose clock recovery walks overlapping blocks: the next process call enqueues everything that can run ahead)
+    const bool defer = (d->clock.relay_by_default() && !d->no_defer) || ov_call(d, n);
     if (!defer) {
         // (front ends run in the order of their inputs: one that is still waiting goes first)
         if (d->pf_count > 0 && !d->pf[0].launched) XR_TRY(launch_prefetched(d, d->pf[0], nullptr));
@@ -995,6 +1173,7 @@ int xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, fl
     int rc = stage_open(c, device);
     if (rc == XRIT_OK) rc = c->st.init(omega, gain_omega, mu, gain_mu, omega_rel_limit, 0, 0);
     if (rc != XRIT_OK) { stage_close(c); return rc; }
+    c->st.ov_allow = false;         // (the stage object hands out complex symbols: ClockRecovery::Work's output)
     *out = c;
     return XRIT_OK;
 }

@@ -165,18 +165,20 @@ struct ClockStage {
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
-    DevBuf xbuf[2];         // [pad | carry | new] input samples of a call.  Two of them: the producer of the NEXT call's samples
-                            // (the Costas loop of the next burst, started under this call's relay: xrit_demod_prefetch_device)
-                            // fills one while the walkers of the call in flight read the other
+    static constexpr int NXB = 3;
+    DevBuf xbuf[NXB];       // [pad | carry | new] input samples of a call.  Three of them (round 5): the producer of the samples of
+                            // the call after next (the Costas loop of burst b + 2: xrit_demod_prefetch_device) fills one while the
+                            // walkers of bursts b and b + 1 read the other two (round 4: two, one burst ahead)
     int xb = 0;             // the buffer the call in flight (the last call) reads
     int x_pending = -1;     // the buffer input_slot() handed out for the next call
     bool in_flight = false; // between begin() and finish()
-    // The new samples (the Costas loop's output rows of 128 bytes) start at a fixed place, XPAD samples into the buffer, on a
+    // The new samples (the Costas loop's output rows of 128 bytes) start at a fixed place, xpad samples into the buffer, on a
     // 128-byte boundary -- wherever the producer writes them it does not need to know how many samples the call before left
-    // unread --; those `carry` samples (at most XPAD) are copied in right in front of them when the call begins.
-    static constexpr size_t XPAD = 1024;
+    // unread --; those `carry` samples (at most 1024) are copied in right in front of them when the call begins.  Round 5: the
+    // pad also holds the HISTORY the overlapping walkers of clock_overlap.h warm up over (the last samples of the burst before).
+    size_t xpad = 1024;
     float2 *xbase_fixed = nullptr;
-    float2 *xdata() const { return xbuf[xb].as<float2>() + XPAD; }
+    float2 *xdata() const { return xbuf[xb].as<float2>() + xpad; }
     float2 *xbase() const { return xbase_fixed ? xbase_fixed : xdata() - carry; }
     DevBuf st;              // carried ClockState + carry count
     DevBuf S, E, J, om, work, counters, sym, dlin, flags, wsolve, jmean;
@@ -306,6 +308,57 @@ struct ClockStage {
     int enqueue_relay(int count, bool restart, hipStream_t s, Profiler *prof);
     int relay_limit() const;
     int relay_plan();
+
+    // ---- overlapping exactly walked blocks (clock_overlap.h, round 5): the default configuration's plan for calls of ov_min
+    // symbols or more.  A job is one such call; up to three exist at a time (xrit_demod_prefetch_device: the walkers of bursts
+    // b and b + 1 at work, burst b + 2's samples being written), each with its own sample buffer (xbuf[job]) and timing curve.
+    struct OvJob {
+        int state = 0;                  // 0: free; 1: slot handed out (samples being produced); 2: walkers enqueued; 3: being finalized
+        size_t n = 0;                   // new samples
+        long long N = 0, ni = 0;        // samples in [history | new], and how many of them a symbol may start at
+        int padN = 0;                   // history samples in front of the new ones
+        int G = 0, Ls = 0, first_bound = 0, store0 = 0, early = 0, stride = 0, hist = 0;
+        bool w0_carried = false;        // walker 0 starts from the carried state (no history to warm up over)
+        int w0_ii = 0;                  // buffer index the carried state's read index 0 corresponds to (padN - carry)
+        bool ahead = false;             // enqueued before the call in front of it had finished (its carry is not known to the plan)
+        int nb = 0, BL = 256;           // the timing statistic: nb blocks of BL samples, counted from the first new sample
+        bool om_ext = false, om_scanned = false;
+        DevBuf om, om_work, segs, S, stage, aux;
+        hipEvent_t ev_walk = nullptr;   // the walkers have finished
+        hipEvent_t ev_guess = nullptr;  // the history has been copied in and the start states computed
+        int hist_src = -1;              // the buffer whose last samples this job's first walkers warm up over (-1: none)
+        unsigned long long serial = 0;  // order of the calls (the job in front: serial - 1)
+    } ov[NXB];
+    bool ov_allow = true;       // the caller takes float soft symbols only (the chain sets it per call; stage objects: off)
+    bool ov_enabled = true;     // XRIT_NO_OVERLAP=1 (read at init): the relay of clock_relay.h for every call, as in round 4
+    long long ov_min = 1000000; // symbols from which the default configuration walks overlapping blocks
+    int ov_hist = 40960;        // symbols of exactly walked history in front of every range (XRIT_OV_HIST)
+    double ov_lratio = 1.0;     // range length aimed at, in histories (XRIT_OV_LRATIO): every symbol is walked 1 + 1 / ov_lratio times
+    int ov_job = -1;            // the job of the call being set up / in flight (-1: the call is not such a call)
+    unsigned long long ov_serial = 0;
+    // what the last finished call left in its buffer: the history the next call's first walkers warm up over
+    int hist_xb = -1;           // buffer
+    size_t hist_len = 0;        // samples in it that end where the stream stands ([pad | new] of that call, contiguous)
+    int hist_job = -1;          // ... and, when that call was an overlap job, the job whose timing curve covers them
+    DevBuf ov_claim;            // which SIMDs hold a walker (clock_relay.h), shared by the jobs in flight
+    int ov_pad_need = 0;        // history samples a warm walker 0 needs in front of the new samples
+    bool ov_eligible(size_t n) const;
+    int ov_plan(OvJob &j, bool ahead);
+    // the walkers of the call whose samples have been produced into the slot input_slot() handed out (and whose timing curve
+    // has been scanned): pad copy, start states, walkers, on `sw` -- ahead of the call itself (ahead: the call in front has not
+    // finished) or from begin()
+    int ov_launch(int job, hipStream_t sw, bool ahead, Profiler *prof);
+    bool ov_can_launch_ahead(int job) const;
+    int ov_finalize(int job, float *soft_out, size_t cap, hipStream_t s, Profiler *prof);
+    // a job whose walkers were started ahead on samples that have since been rewritten (the Costas loop went on from the host):
+    // waits for them (on `s`'s behalf: the host synchronises the event) and takes the job back to "samples produced"
+    int ov_restart(int job, hipStream_t s);
+    int ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof);
+    int ov_cur = -1;            // the overlap job of the call between begin() and finish()
+    float *ov_soft = nullptr; size_t ov_cap = 0; size_t carry_before_fallback = 0;
+    bool ov_fell_back = false;  // the last call's overlap result was not taken (low Es/N0, a joint that did not fit): relayed to closure
+    int ov_walkers = 0;         // walkers of the last overlap call
+    float ov_joint_max = 0.f;   // ... and the largest distance between two trajectories at a joint (samples)
 };
 
 // ---- helpers ---------------------------------------------------------------
