@@ -82,15 +82,15 @@ def test_bench_two_ranks_launched_like_the_driver_does():
 
 
 @pytest.mark.gpu
-def test_circuit_rate_burst_runs_the_two_pass_plan_with_four_walkers_per_cu():
-    """C1 at burst size (2^28 samples, no decimator: 63 M symbols): the relay plans two passes from the timing guess over
-    segments that still hold 49 152 symbols -- up to four walkers per CU (1023 segments on a 256-CU part; 512 before round 4's
-    second half) -- and every step closes its Costas loop in one pass over the samples."""
+def test_circuit_rate_burst_walks_overlapping_blocks_with_four_walkers_per_cu():
+    """C1 at burst size (2^28 samples, no decimator: 63 M symbols): the clock recovery walks overlapping blocks (round 5,
+    csrc/clock_overlap.h) -- one launch, no hand-off and no relay passes, up to four walkers per CU (1022 ranges of 62 k symbols
+    behind 41 k symbols of history on a 256-CU part) -- and every step closes its Costas loop in one pass over the samples."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--decimation", "1", "--steps", "3", "--warmup", "2",
                         "--no-cpu", "--no-exact", "--no-serial-floor"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     lp = d["loop_passes"]
-    assert lp["clock"] == 0 and lp["clock_relay"] == 2 and lp["costas"] == 1 and lp["costas_unconverged"] == 0, lp
+    assert lp["clock"] == 0 and lp["clock_relay"] == 1 and lp["clock_relay_closed"] == 0 and lp["costas"] == 1 and lp["costas_unconverged"] == 0, lp
     assert 3 * 256 <= lp["clock_relay_segments"] <= 4 * 256, lp
     assert d["value"] > 0 and d["config"]["decimation"] == 1

@@ -464,13 +464,16 @@ def test_north_star_1e_4_in_steady_state(xa, oracle_mod, case):
     assert r <= NORTH_STAR_RMS, (case, r, floor, rs)
 
 
-def test_bursts_that_fill_the_chip_are_relayed_from_the_timing_guess(xa, oracle_mod):
-    """6 M symbols or more in one call (here 26 M samples of LRIT at the circuit rate, two consecutive calls): the default
+def test_bursts_that_fill_the_chip_are_relayed_from_the_timing_guess(xa, oracle_mod, monkeypatch):
+    """(Round 4's plan for big calls, which round 5's overlapping blocks replaced as the default -- XRIT_NO_OVERLAP=1, read when
+    the handle is created, brings it back; it is also what a call falls back to.)
+    6 M symbols or more in one call (here 26 M samples of LRIT at the circuit rate, two consecutive calls): the default
     configuration runs NO hand-off pass -- every segment but the first is walked from the timing guess, then from the end
     states of the segments in front, three passes over segments of 24.6 k symbols.  Count and hard decisions are the serial
     trajectory's, the soft symbols within the default's usual distance of it and within 20 % of its floor against the oracle."""
     import torch
     from xritdemod_amd import _capi
+    monkeypatch.setenv("XRIT_NO_OVERLAP", "1")
     n, fs = 26000000, 1.25e6
     dev = torch.device("cuda", 0)
     buf = torch.empty((n, 2), dtype=torch.float32, device=dev)
@@ -615,11 +618,11 @@ def test_default_runs_two_relay_passes_on_long_segments(xa):
     assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
     r = float(np.sqrt(np.mean((got - ser) ** 2))), float(np.sqrt(np.mean((fast - ser) ** 2)))
     assert r[0] <= 1.0e-4 and r[0] < 0.6 * r[1], r
-    # left to itself the library cuts the call's 2.35 M symbols into some 145 segments of 16 k behind two hand-off passes:
-    # three relay passes
+    # left to itself the library walks the call's 2.35 M symbols as overlapping blocks (round 5: one launch, some 240 walkers);
+    # round 4 cut it into some 145 segments of 16 k behind two hand-off passes: three relay passes
     d3 = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
     d3.process(x)
-    assert d3.stats().clock_relay_passes == 3 and 140 <= d3.stats().clock_relay_segments <= 150, d3.stats().clock_relay_segments
+    assert d3.stats().clock_relay_passes == 1 and 200 <= d3.stats().clock_relay_segments <= 280, d3.stats().clock_relay_segments
 
 
 def test_exact_closure_edge_cases(xa):
@@ -700,7 +703,9 @@ def test_quick_relay_is_closer_than_the_hand_off_passes(xa, oracle_mod):
         big = np.abs(ser) > 1e-3
         assert np.array_equal(np.sign(got[big]), np.sign(ser[big]))
         out[ce] = rms(got - ser)
-        if ce != -2:
+        if ce == 0:       # (round 5: the default walks overlapping blocks on a call of this size -- one launch)
+            assert st.clock_passes == 0 and st.clock_relay_passes == 1, (ce, st.clock_passes, st.clock_relay_passes)
+        if ce == -3:
             assert st.clock_passes == 0 and 2 <= st.clock_relay_passes <= 4, (ce, st.clock_passes, st.clock_relay_passes)
     assert out[0] <= out[-3] <= out[-2] and out[-3] <= 1.6e-4, out
     x = x[:300000]
@@ -932,6 +937,134 @@ def test_prefetched_front_ends_give_the_same_symbols(xa, exact):
     assert np.array_equal(soft[:k].cpu().numpy(), plain[0])
     dem2.prefetch_device(xt[1].data_ptr(), n)
     del dem2
+
+
+def _device_bursts(kw, n, nb, jump_at=None, jump_kw=None):
+    """nb consecutive bursts of n samples of one synthetic stream, resident on the device (xrit_synth_generate_device); from burst
+    jump_at on the stream is another one (carrier / phase / timing jump)."""
+    import torch
+    from xritdemod_amd import _capi
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((nb, n, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for b in range(nb):
+        sp = _capi.synth_params(**(jump_kw if jump_at is not None and b >= jump_at else kw))
+        _capi.synth_generate_device(sp, b * n, n, buf[b].data_ptr(), device=0, stream=st)
+    torch.cuda.synchronize(dev)
+    return buf
+
+
+def _run_plan(xa, cfg, buf, plan, cap):
+    import torch
+    n = buf.shape[1]
+    soft = torch.empty(cap, dtype=torch.float32, device=buf.device)
+    dem = xa.Demodulator(cfg)
+    out, stats = [], []
+    for op, b in plan:
+        if op == "pf":
+            dem.prefetch_device(buf[b].data_ptr(), n)
+        else:
+            k = dem.process_device(buf[b].data_ptr(), n, soft.data_ptr(), cap)
+            out.append(soft[:k].cpu().numpy())
+            stats.append(dem.stats())
+    return out, stats
+
+
+def test_big_calls_walk_overlapping_blocks(xa, oracle_mod):
+    """Round 5, csrc/clock_overlap.h: a call of a million symbols or more in the default configuration cuts its de-rotated samples
+    at fixed sample positions into ranges; one walker per range starts 40 960 symbols in front of it from the timing guess -- the
+    first ones in the last samples of the burst before, kept in front of the new ones -- walks them quietly and stages the symbols
+    of its range; the joints are settled afterwards.  ONE launch, no passes (stats: 0 hand-off passes, 1 relay pass, the walkers as
+    its segments).  Count and hard decisions are the serial trajectory's on every burst, the soft symbols within the relay's
+    distance of it; streamed (two inputs registered behind the call in progress: front end, Costas loop and walkers of the next two
+    bursts run ahead) the words are those of plain consecutive calls, and a second run gives the same words."""
+    n, fs, nb = 1 << 23, 1.25e6, 4
+    buf = _device_bursts(dict(fs_in=fs), n, nb)
+    cap = int(n / 4.2) + 4096
+    cfg = lambda **k: xa.Demodulator.config("lrit", fs, 1, **k)      # noqa: E731
+    plain, st = _run_plan(xa, cfg(), buf, [("go", b) for b in range(nb)], cap)
+    for s_ in st:
+        assert s_.clock_passes == 0 and s_.clock_relay_passes == 1 and s_.clock_relay_closed == 0 and s_.clock_relay_segments >= 100, \
+            (s_.clock_passes, s_.clock_relay_passes, s_.clock_relay_segments)
+    again, _ = _run_plan(xa, cfg(), buf, [("go", b) for b in range(nb)], cap)
+    ahead, st2 = _run_plan(xa, cfg(), buf, [("pf", 0), ("pf", 1), ("pf", 2), ("go", 0), ("pf", 3), ("go", 1), ("go", 2), ("go", 3)], cap)
+    mixed, _ = _run_plan(xa, cfg(), buf, [("go", 0), ("pf", 1), ("go", 1), ("pf", 2), ("pf", 3), ("go", 2), ("go", 3)], cap)
+    serial, _ = _run_plan(xa, cfg(clock_serial=1), buf, [("go", b) for b in range(nb)], cap)
+    ref = oracle_mod.Demod(oracle_mod.config("lrit", fs, 1))
+    for b in range(nb):
+        assert np.array_equal(plain[b].view(np.uint32), again[b].view(np.uint32)), b
+        assert np.array_equal(plain[b].view(np.uint32), ahead[b].view(np.uint32)), b
+        assert np.array_equal(plain[b].view(np.uint32), mixed[b].view(np.uint32)), b
+        assert len(plain[b]) == len(serial[b]) > 1900000, b
+        big = np.abs(serial[b]) > 1e-3
+        assert np.array_equal(np.sign(plain[b][big]), np.sign(serial[b][big])), b
+        rs = rms(plain[b] - serial[b])
+        assert rs <= 1.0e-4, (b, rs)
+        want = ref.process(buf[b].cpu().numpy().view(np.complex64).reshape(-1))
+        assert len(want) == len(plain[b])
+        r, floor = rms(plain[b] - want), rms(serial[b] - want)
+        assert r <= max(NORTH_STAR_RMS, 1.2 * floor) and r <= 1.5e-4, (b, r, floor)
+    assert [s_.costas_passes for s_ in st] == [s_.costas_passes for s_ in st2]
+
+
+def test_overlapping_blocks_fall_back_to_closure_at_low_snr(xa):
+    """The default configuration walks a call whose soft symbols show Es/N0 below 7 dB to closure: a call that began as
+    overlapping blocks is then relayed (csrc/clock_relay.h) until it IS the serial trajectory -- also when the bursts were started
+    ahead -- and the stream goes on from there (the next burst's first walkers warm up over this burst's samples)."""
+    n, fs, nb = 1 << 23, 1.25e6, 3
+    buf = _device_bursts(dict(fs_in=fs, esn0_db=5.0), n, nb)
+    cap = int(n / 4.2) + 4096
+    cfg = lambda **k: xa.Demodulator.config("lrit", fs, 1, **k)      # noqa: E731
+    plain, st = _run_plan(xa, cfg(), buf, [("go", b) for b in range(nb)], cap)
+    ahead, _ = _run_plan(xa, cfg(), buf, [("pf", 0), ("pf", 1), ("pf", 2), ("go", 0), ("go", 1), ("go", 2)], cap)
+    serial, _ = _run_plan(xa, cfg(clock_serial=1), buf, [("go", b) for b in range(nb)], cap)
+    for b in range(nb):
+        assert st[b].clock_relay_closed == 1 and st[b].clock_relay_passes >= 2, (b, st[b].clock_relay_passes)
+        assert np.array_equal(plain[b].view(np.uint32), serial[b].view(np.uint32)), b
+        assert np.array_equal(ahead[b].view(np.uint32), serial[b].view(np.uint32)), b
+
+
+def test_overlapping_blocks_between_small_calls_and_through_a_jump(xa):
+    """Mode changes inside one stream: a small call (one exact walk) in front of a big one -- no history with a timing curve: walker
+    0 starts from the carried state --, a big one in front of a small one (the carried state and tail of the overlap call), and a
+    carrier / phase / timing jump in the middle of a streamed run: the Costas loop of that burst does not close inside its batch,
+    goes on from the host and rewrites its output, and walkers that were started behind the batch start over.  Everywhere: the
+    symbol count and the hard decisions of the serial trajectory, streamed words = plain words."""
+    import torch
+    fs = 1.25e6
+    n, nb = 1 << 23, 5
+    buf = _device_bursts(dict(fs_in=fs), n, nb, jump_at=2, jump_kw=dict(fs_in=fs, carrier_hz=-350.0, phase0=2.1, timing_offset=0.77, seed=77))
+    cap = int(n / 4.2) + 4096
+    cfg = lambda **k: xa.Demodulator.config("lrit", fs, 1, **k)      # noqa: E731
+    plan_plain = [("go", b) for b in range(nb)]
+    plan_ahead = [("pf", 0), ("pf", 1), ("go", 0), ("pf", 2), ("go", 1), ("pf", 3), ("go", 2), ("pf", 4), ("go", 3), ("go", 4)]
+    plain, st = _run_plan(xa, cfg(), buf, plan_plain, cap)
+    ahead, _ = _run_plan(xa, cfg(), buf, plan_ahead, cap)
+    serial, _ = _run_plan(xa, cfg(clock_serial=1), buf, plan_plain, cap)
+    assert max(s_.costas_passes for s_ in st[2:]) >= 3          # (the jump: more passes than a tracking loop's batch holds)
+    for b in range(nb):
+        assert np.array_equal(plain[b].view(np.uint32), ahead[b].view(np.uint32)), b
+        assert len(plain[b]) == len(serial[b]), b
+        if b != 2:      # (the burst of the jump re-acquires: its first symbols are not on any trajectory's floor)
+            big = np.abs(serial[b]) > 1e-3
+            assert np.array_equal(np.sign(plain[b][big]), np.sign(serial[b][big])), b
+            assert rms(plain[b] - serial[b]) <= 1.5e-4, (b, rms(plain[b] - serial[b]))
+    # small calls around big ones, one stream (no jump): 300 k samples, 2^23, 100 k, 2^23
+    x = _device_bursts(dict(fs_in=fs), n, 3).reshape(-1, 2)
+    cuts = [0, 300000, 300000 + n, 400000 + n, 400000 + 2 * n]
+    soft = torch.empty(cap, dtype=torch.float32, device=buf.device)
+    got, want = [], []
+    dd, ds = xa.Demodulator(cfg()), xa.Demodulator(cfg(clock_serial=1))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        for d_, acc in ((dd, got), (ds, want)):
+            k = d_.process_device(x[lo:hi].data_ptr(), hi - lo, soft.data_ptr(), cap)
+            acc.append(soft[:k].cpu().numpy())
+    assert dd.stats().clock_relay_passes == 1
+    for a, b in zip(got, want):
+        assert len(a) == len(b)
+        big = np.abs(b) > 1e-3
+        assert np.array_equal(np.sign(a[big]), np.sign(b[big])) and rms(a - b) <= 1.5e-4
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))          # (a call of 70 k symbols is ONE exact walk)
 
 
 def test_run_to_run_determinism(xa):

@@ -1061,6 +1061,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     ov_enabled = getenv("XRIT_NO_OVERLAP") == nullptr;
     if (const char *e = getenv("XRIT_OV_HIST")) { const int v = atoi(e); if (v >= 1024) ov_hist = v; }
     if (const char *e = getenv("XRIT_OV_MIN")) { const long long v = atoll(e); if (v > 0) ov_min = v; }
+    if (const char *e = getenv("XRIT_OV_SMALL_RING")) ov_small_ring = atoi(e) != 0;
     if (const char *e = getenv("XRIT_OV_LRATIO")) { const double v = atof(e); if (v >= 0.125 && v <= 16.0) ov_lratio = v; }
     {
         // history a warm walker 0 needs in front of the new samples: its warm-up, the symbols it stages in front of the carried
@@ -1602,6 +1603,7 @@ bool ClockStage::ov_eligible(size_t n) const
 {
     if (!ov_enabled || !ov_allow || exact != 0 || relay_quick || serial || relay_global || xbase_fixed) return false;
     if (relay_no_handoff == 0 || auto_passes <= 0) return false;          // (A/B switches that ask for round 3's / round 2's plans)
+    if (relay_window > 0) return false;                                    // (cfg.clock_exact_window: the caller asks for the relay's segments)
     if ((size_t)ov_pad_need > xpad) return false;                          // (no LDS-staged walker at this symbol rate)
     if (n >= ((size_t)1 << 31) - xpad - 4096) return false;
     return (double)n / (double)par.omega_mid >= (double)ov_min;
@@ -1771,7 +1773,8 @@ int ClockStage::ov_launch(int job, hipStream_t sw, bool ahead, Profiler *prof)
     XR_HIP(hipEventRecord(j.ev_guess, sw));       // (from here on the history this job was started from may be overwritten)
     {
         ProfScope ps(prof, "clock_overlap", sw);
-        hipLaunchKernelGGL(clock_overlap_kernel, dim3(j.G), dim3(128), 0, sw, a, span);
+        if (ov_small_ring && span + 8 <= 1024 - RELAY_XCH - 72) hipLaunchKernelGGL(clock_overlap_kernel<1024>, dim3(j.G), dim3(128), 0, sw, a, span);
+        else hipLaunchKernelGGL(clock_overlap_kernel<RELAY_RX>, dim3(j.G), dim3(128), 0, sw, a, span);
     }
     XR_HIP(hipGetLastError());
     XR_HIP(hipEventRecord(j.ev_walk, sw));

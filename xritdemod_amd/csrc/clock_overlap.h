@@ -71,10 +71,14 @@ __device__ __forceinline__ int overlap_bound(const OverlapArgs &a, int s)
 
 // Two waves per workgroup like clock_relay_kernel<.., RING = true>: the prefetcher keeps the sample ring filled, the walker
 // walks.  `span`: samples a block of 64 symbols can cover.
+// RX: samples in the ring.  (Measured, round 5, C2 streamed: rings of 1024 samples -- XRIT_OV_SMALL_RING=1 -- cost the walk more
+// than the LDS they free gives the front end beside it, 1.92 against 1.76 ms per burst; four walkers per workgroup, which puts a
+// burst's walkers on a quarter of the CUs, 1.94 against 1.90.)
+template <int RX>
 __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int span)
 {
     __shared__ float table[(XR_MM_NSTEPS + 1) * XR_MM_NTAPS];
-    __shared__ cf32 xr[RELAY_RX + RELAY_XMIR];
+    __shared__ cf32 xr[RX + RELAY_XMIR];
     __shared__ int sh_xhi, sh_pos_ii, sh_done, sh_simd[2], sh_swap, sh_claim;
     clock_table_to_lds(table, a.table);
     const int s = blockIdx.x, lane = threadIdx.x & 63;
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
         while (!relay_ld(&sh_done)) {
             if (++rounds > (1u << 24)) { if (lane == 0) a.stat[2] = 0xc0000000u | (unsigned)s; break; }   // watchdog
             const int pii = relay_ld(&sh_pos_ii);
-            const bool fx = x_hi + RELAY_XCH - RELAY_RX <= pii && (long long)x_hi <= xend && (long long)x_hi <= nlast + span + 16;
+            const bool fx = x_hi + RELAY_XCH - RX <= pii && (long long)x_hi <= xend && (long long)x_hi <= nlast + span + 16;
             if (!fx) { __builtin_amdgcn_s_sleep(4); continue; }
             cf32 vx[RELAY_XCH / 64];
 #pragma unroll
@@ -143,9 +147,9 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             }
 #pragma unroll
             for (int q = 0; q < RELAY_XCH / 64; ++q) {
-                const int slot = (x_hi + lane + 64 * q) & (RELAY_RX - 1);
+                const int slot = (x_hi + lane + 64 * q) & (RX - 1);
                 xr[slot] = vx[q];
-                if (slot < RELAY_XMIR) xr[RELAY_RX + slot] = vx[q];
+                if (slot < RELAY_XMIR) xr[RX + slot] = vx[q];
             }
             x_hi += RELAY_XCH;
             if (lane == 0) relay_st(&sh_xhi, x_hi);
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             ++rounds_total;
             inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
             cf32 w[XR_MM_NTAPS];
-            const cf32 *wp = xr + (cii & (RELAY_RX - 1));
+            const cf32 *wp = xr + (cii & (RX - 1));
 #pragma unroll
             for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = wp[q];
             p0 = clock_interp_arm(w, table, carm);
