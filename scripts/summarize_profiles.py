@@ -36,6 +36,7 @@ copy(os.path.join("stats_np", "c2_kernel_stats.csv"), f"{tag}_c2_kernel_stats_no
 copy("timeline.txt", f"{tag}_c2_timeline.txt")
 copy("timeline_streamed.txt", f"{tag}_c2_timeline_streamed.txt")
 copy("small_calls.txt", f"{tag}_small_calls.txt")
+copy("step_times_c2.json", f"{tag}_step_times_c2.json")
 copy("parity_floor_c2.json", f"{tag}_parity_floor_c2.json")
 copy("parity_floor_chain_sweep.json", f"{tag}_parity_floor_chain_sweep.json")
 copy("parity_floor_passes_sweep.json", f"{tag}_parity_floor_passes_sweep.json")
@@ -104,7 +105,8 @@ if os.path.exists(fpath) and os.path.exists(wpath):
     names = {"fir_decim": "fir_decim_kernel<3, false, 0, 0", "clock_pass": "clock_pass_kernel<1, 32, 20, false>", "clock_pass_writing": "clock_pass_kernel<1, 32, 20, true>",
              "clock_pass_jac": "clock_pass_kernel<3, 32, 20>", "costas_pass": "costas_pass_kernel<false>",
              "costas_final": "costas_pass_kernel<true>", "fir_rrc": "fir_decim_kernel<5, false, 0, 3",
-             "clock_output": "clock_output_kernel<32, 20, false>", "clock_relay_pass": "clock_relay_kernel<false, true>"}
+             "clock_output": "clock_output_kernel<32, 20, false>", "clock_relay_pass": "clock_relay_kernel<false, true>",
+             "clock_overlap": "clock_overlap_kernel<2048>"}
     d = {r[0]: r for r in rows}
     out = {}
     src_note = (f"profiles/{tag}_c2_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE "

@@ -58,10 +58,8 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
-    hipStream_t stream3[3] = {nullptr, nullptr, nullptr};           // the clock recovery's walkers of bursts started ahead (round 5):
-                                                                    // one stream per job, so that two bursts' walkers run side by side
-    hipStream_t stream_c = nullptr;                                 // ... and their Costas loops: the front end of burst b + 2 (stream2) runs
-                                                                    // beside the Costas loop of burst b + 1
+    hipStream_t stream3[2] = {nullptr, nullptr};                    // the clock recovery's walkers of bursts started ahead (round 5):
+                                                                    // two streams, so that two bursts' walkers run side by side
     hipEvent_t ev_done = nullptr;                                   // the current call's clock recovery has left its result
     hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
     hipEvent_t ev_relay = nullptr;                                  // the relay kernels of the current call come next
@@ -231,7 +229,6 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if (hipStreamCreate(&d->stream) != hipSuccess ||
             hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
             hipStreamCreate(&d->stream3[0]) != hipSuccess || hipStreamCreate(&d->stream3[1]) != hipSuccess ||
-            hipStreamCreate(&d->stream3[2]) != hipSuccess || hipStreamCreate(&d->stream_c) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
@@ -268,12 +265,10 @@ void xrit_demod_destroy(xrit_demod *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
-    if (d->stream_c) (void)hipStreamSynchronize(d->stream_c);
     for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
-    if (d->stream_c) { (void)hipStreamSynchronize(d->stream_c); (void)hipStreamDestroy(d->stream_c); }
     for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
@@ -295,7 +290,6 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
-    XR_HIP(hipStreamSynchronize(d->stream_c));
     for (auto w : d->stream3) XR_HIP(hipStreamSynchronize(w));      // ... and so do walkers
     if (d->costas.job.n && d->pf_count > 0) {
         // (a Costas loop begun ahead and never looked at: the stage's bookkeeping is brought to an end before its state is reset)
@@ -582,7 +576,7 @@ static int ov_service(xrit_demod *d, bool *progress)
             if (hipEventQuery(d->ev_costas) != hipSuccess) { costas_busy = true; continue; }
             if (f.length && d->agc.requested_flag() == 2.0f) f.agc_fallback = true;
             bool redone = false;
-            int rc = d->costas.finish(d->stream_c, prof, &redone);
+            int rc = d->costas.finish(d->stream2, prof, &redone);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
             f.c_passes = d->costas.passes; f.c_unconverged = d->costas.unconverged; f.c_max_residual = d->costas.max_residual;
             f.c_walked = d->costas.job.rescued && d->costas.walked;
@@ -590,7 +584,7 @@ static int ov_service(xrit_demod *d, bool *progress)
             if (redone && f.ov_job >= 0) {
                 // the loop went on from the host and rewrote its output (and the timing statistic): walkers that were started
                 // behind the first batch have read the old one
-                rc = d->clock.ov_restart(f.ov_job, d->stream_c);
+                rc = d->clock.ov_restart(f.ov_job, d->stream2);
                 if (rc != XRIT_OK) { d->poisoned = true; return rc; }
                 f.walk_launched = false;
             }
@@ -600,10 +594,13 @@ static int ov_service(xrit_demod *d, bool *progress)
             SliceIO io;
             io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
             // (on a stream of its own behind this input's front end: the front end of the input behind it runs beside this loop)
-            XR_HIP(hipStreamWaitEvent(d->stream_c, d->ev_fe[f.set], 0));
-            int rc = costas_enqueue(d, io, d->stream_c, prof, &f.slot);
+            // (on the front ends' stream, behind this input's: measured with every stream on a hardware queue of its own
+            // -- GPU_MAX_HW_QUEUES=8 -- a Costas stream beside the front ends' costs 10 %, 2.05 against 1.85 ms per C2 burst: the
+            // loop's passes and the next input's decimator fill the chip each and only slow one another)
+            hipStream_t sc = d->stream2;
+            int rc = costas_enqueue(d, io, sc, prof, &f.slot);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
-            XR_HIP(hipEventRecord(d->ev_costas, d->stream_c));
+            XR_HIP(hipEventRecord(d->ev_costas, sc));
             f.costas_begun = true;
             f.ov_job = d->clock.ov_job;
             costas_busy = true;
@@ -611,7 +608,8 @@ static int ov_service(xrit_demod *d, bool *progress)
         }
         if (f.costas_begun && f.ov_job >= 0 && !f.walk_launched && d->clock.ov_can_launch_ahead(f.ov_job)) {
             // (behind the Costas loop's batch and the timing curve: speculative until the host has seen the loop's stop test)
-            hipStream_t sw = d->stream3[f.ov_job % 3];
+            // (two walker streams, alternating: the walkers of bursts b and b + 1 side by side, those of b + 2 behind b's)
+            hipStream_t sw = d->stream3[d->clock.ov[f.ov_job].serial & 1];
             XR_HIP(hipStreamWaitEvent(sw, d->ev_costas, 0));
             int rc = d->clock.ov_launch(f.ov_job, sw, true, prof);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
