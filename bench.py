@@ -485,12 +485,13 @@ def main():
             torch.cuda.synchronize(dev)
             x0 = time.perf_counter()
             # (streamed like the headline: the front end of burst b + 1 under the loops of burst b)
+            # (one input registered ahead: these configurations keep round 4's pipeline -- the next burst's front end and Costas
+            # loop beside this burst's relay or hand-off passes)
             if prefetch:
-                for q in range(min(depth, Kx)):
-                    xd.prefetch_device(bursts[(Wx + q) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+                xd.prefetch_device(bursts[Wx % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
             for b in range(Wx, Wx + Kx):
-                if prefetch and b + depth < Wx + Kx:
-                    xd.prefetch_device(bursts[(b + depth) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+                if prefetch and b + 1 < Wx + Kx:
+                    xd.prefetch_device(bursts[(b + 1) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
                 xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
                 sx = xd.stats()
                 closed = closed and bool(sx.clock_relay_closed)

@@ -177,18 +177,21 @@ int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft_out, size_t cap, 
  * with the symbol history negated -- right to 1e-3 sample in timing, which takes 1e4..1e5 symbols to settle).
  * Refused like xrit_demod_redo_clock_flipped while a prefetched input waits. */
 int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
-/* Streaming at full rate: run the front end (ingest, decimator, AGC, matched filter) of a LATER call's input now, on
- * the handle's second stream, so that it overlaps the feedback loops of the call made in between:
- *     prefetch(b);  prefetch(b+1); process_device(b);  prefetch(b+2); process_device(b+1);  ...
- * Inputs are taken by the process calls in the order they were prefetched (each must pass exactly the prefetched
- * pointer, count and type); at most two may be waiting.  The reference's input FIFO plays the same role
- * (demodulator.cpp:38,54-74: the frontend thread fills it while the DSP thread works).  A no-op while stage copies
- * or full per-kernel profiling are on.
- * Unless the relay is off (clock_exact < 0) the input is only registered: the process call in between starts its
- * front end in front of its own relay kernels -- three waves per CU, next to which the front end runs almost for
- * free -- instead of under the Costas and hand-off passes that fill the chip (2.86 -> 2.35 ms per 256 Mi-sample burst
- * in the default configuration); the input must stay valid until the process call that takes it has returned either way.
- * The second stream has the lowest stream priority: a hardware queue of its own, behind the loops where they compete. */
+/* Streaming at full rate: register the input of a LATER process call now, so that the library can run it ahead of
+ * that call on streams of its own while the calls in between are at work:
+ *     prefetch(b); prefetch(b+1);  prefetch(b+2); process_device(b);  prefetch(b+3); process_device(b+1);  ...
+ * Inputs are taken by the process calls in the order they were registered (each must pass exactly the registered
+ * pointer, count and type) and must stay valid until the call that takes them has returned.  The reference's input FIFO
+ * plays the same role (demodulator.cpp:38,54-74: the frontend thread fills it while the DSP thread works).  A no-op while
+ * stage copies or full per-kernel profiling are on.  What runs ahead, and how many inputs may wait:
+ *   * calls of a million symbols or more in the default configuration (round 5: the clock recovery walks overlapping
+ *     blocks, csrc/clock_overlap.h, and waits for no other burst): the front end, the Costas loop AND the clock
+ *     recovery's walkers of the next TWO bursts -- three inputs may wait (the call in progress and two behind it).  A
+ *     process call enqueues what the newest registration allows, waits for its own walkers and lays out its symbols;
+ *   * every other call (smaller calls, clock_exact != 0): the front end and the Costas loop of the NEXT burst, started in
+ *     front of the current call's relay kernels (round 4) or at once (clock_exact < 0) -- two inputs may wait.
+ * The symbols are those of plain consecutive calls, word for word, either way.  XRIT_E_INVALID when as many inputs as
+ * may wait are waiting already. */
 int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type, void *stream);
 /* Back to the state right after xrit_demod_create (filter histories, gain, loop states, unread tail), without
  * giving up the device buffers: the start of another stream.  Also revives a handle a failed call left unusable. */

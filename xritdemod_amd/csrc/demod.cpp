@@ -860,7 +860,15 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     if (!d || (n && !d_samples)) { set_error("null argument"); return XRIT_E_INVALID; }
     if (type < 0 || type > 3) { set_error("unknown sample type %d", type); return XRIT_E_INVALID; }
     if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
-    if (d->pf_count >= 3) { set_error("three prefetched inputs are already waiting for their process calls"); return XRIT_E_INVALID; }
+    // Two sets of front-end buffers: the front end of the input two behind a call would overwrite what that call's loops still
+    // read.  Bursts whose clock recovery walks overlapping blocks hold their front ends back until that is safe (ov_service) and
+    // may wait three deep -- the call in progress and two behind it --; everything else two deep, as before round 5.
+    {
+        bool all_ov = ov_call(d, n);
+        for (int i = 0; i < d->pf_count && all_ov; ++i) all_ov = ov_call(d, d->pf[i].n);
+        const int room = all_ov ? 3 : 2;
+        if (d->pf_count >= room) { set_error("%d prefetched inputs are already waiting for their process calls", d->pf_count); return XRIT_E_INVALID; }
+    }
     // stage copies and per-kernel event brackets belong to one call at a time: no running ahead then
     if (d->keep_stages || d->keep_symbols || (d->prof.enabled && !d->prof.light)) return XRIT_OK;
     XR_HIP(hipSetDevice(d->device));
