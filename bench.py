@@ -246,7 +246,9 @@ def main():
     # (the warm-up steps are fed like the timed ones -- the next warm-up burst registered ahead -- so that both sets of the
     # handle's buffers exist before the clock starts; the last warm-up step has nothing registered behind it: the timed region
     # begins on an empty pipeline)
-    depth = max(1, min(2, args.prefetch_depth))       # inputs registered behind the call in progress
+    # inputs registered behind the call in progress: what the library takes for calls of this size (2 for bursts whose clock
+    # recovery walks overlapping blocks, else 1)
+    depth = max(1, min(args.prefetch_depth, dem.prefetch_depth(n_burst), 2))
     if not args.no_prefetch:
         for q in range(min(depth, W)):
             dem.prefetch_device(bursts[q % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)

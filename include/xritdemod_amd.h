@@ -193,6 +193,9 @@ int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
  * The symbols are those of plain consecutive calls, word for word, either way.  XRIT_E_INVALID when as many inputs as
  * may wait are waiting already. */
 int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n_complex, int sample_type, void *stream);
+/* How many inputs of n_complex samples may wait BEHIND the call in progress on this handle: 2 (calls that walk overlapping
+ * blocks), 1 (every other call), 0 (stage copies or full profiling are on: nothing runs ahead). */
+int xrit_demod_prefetch_depth(xrit_demod *d, size_t n_complex);
 /* Back to the state right after xrit_demod_create (filter histories, gain, loop states, unread tail), without
  * giving up the device buffers: the start of another stream.  Also revives a handle a failed call left unusable. */
 int xrit_demod_reset(xrit_demod *d, void *stream);

@@ -1069,6 +1069,41 @@ def test_overlapping_blocks_between_small_calls_and_through_a_jump(xa):
     assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))          # (a call of 70 k symbols is ONE exact walk)
 
 
+def test_flipped_rerun_behind_a_call_of_overlapping_blocks(xa):
+    """xrit_demod_redo_clock_flipped (one capture across GPUs: a rank that locked pi away, csrc/group.hip) behind a call whose
+    clock recovery walked overlapping blocks: the call's samples still lie in its job's buffer, the re-run takes the relay of
+    csrc/clock_relay.h on the negated samples from the state the call started from.  Same symbol count to within a symbol, the
+    decisions of the negated stream, and the stream goes on (the next call joins its first walker to the re-run's carried state)."""
+    import torch
+    n, fs, nb = 1 << 23, 1.25e6, 3
+    buf = _device_bursts(dict(fs_in=fs), n, nb)
+    cap = int(n / 4.2) + 4096
+    dev = buf.device
+    soft = torch.empty(cap, dtype=torch.float32, device=dev)
+    d = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
+    k0 = d.process_device(buf[0].data_ptr(), n, soft.data_ptr(), cap)
+    k1 = d.process_device(buf[1].data_ptr(), n, soft.data_ptr(), cap)
+    a = soft[:k1].cpu().numpy().copy()
+    assert d.stats().clock_relay_passes == 1
+    k1f = d.redo_clock_flipped(soft.data_ptr(), cap)
+    b = soft[:k1f].cpu().numpy().copy()
+    assert abs(k1f - k1) <= 1 and k0 > 1900000
+    m = min(k1, k1f)
+    big = np.abs(a[:m]) > 0.05
+    # (the loop on -y is another loop than minus the loop on y -- the detector slices to {0, 1} --: same decisions, soft values 3e-3 apart)
+    assert np.mean(np.sign(b[:m][big]) == -np.sign(a[:m][big])) > 0.9999 and rms(a[:m] + b[:m]) < 2e-2
+    k2 = d.process_device(buf[2].data_ptr(), n, soft.data_ptr(), cap)
+    c = soft[:k2].cpu().numpy()
+    ref = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1))
+    for q in range(3):
+        kr = ref.process_device(buf[q].data_ptr(), n, soft.data_ptr(), cap)
+    r = soft[:kr].cpu().numpy()
+    assert abs(k2 - kr) <= 1
+    m = min(k2, kr)
+    big = np.abs(r[:m]) > 0.05
+    assert np.mean(np.sign(c[:m][big]) == -np.sign(r[:m][big])) > 0.9999          # (the stream's polarity stays flipped: the Costas phase moved by pi)
+
+
 def test_run_to_run_determinism(xa):
     """Two fresh handles on the same input give bit-identical symbols (the hand-off passes, their stop test and
     every reduction are order independent)."""

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "xrit_group_restart": (C.c_int, [_vp]),
     "xrit_demod_prepare_flipped": (C.c_int, [_vp, _vp]),
+    "xrit_demod_prefetch_depth": (C.c_int, [_vp, _sz]),
     "xrit_demod_redo_clock_flipped": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "xrit_demod_profile_samples": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     "xrit_quantize_i8_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp]),
@@ -354,6 +355,20 @@ class Demodulator(_Handle):
     def reset(self, stream=None):
         """Back to the freshly created state (another stream begins); device buffers are kept."""
         _check(lib().xrit_demod_reset(self._h, C.c_void_p(stream) if stream else None))
+
+    def prefetch_depth(self, n):
+        """Inputs of n samples that may wait behind the call in progress (xrit_demod_prefetch_depth)."""
+        return lib().xrit_demod_prefetch_depth(self._h, n)
+
+    def redo_clock_flipped(self, d_soft_ptr, cap, stream=None):
+        """The last call's clock recovery once more on the sign-flipped Costas output (xrit_demod_redo_clock_flipped)."""
+        n_out = C.c_size_t(0)
+        _check(lib().xrit_demod_redo_clock_flipped(self._h, C.c_void_p(d_soft_ptr), cap, C.byref(n_out),
+                                                   C.c_void_p(stream) if stream else None))
+        return n_out.value
+
+    def prepare_flipped(self, stream=None):
+        _check(lib().xrit_demod_prepare_flipped(self._h, C.c_void_p(stream) if stream else None))
 
     def keep_stages(self, enable=True):
         _check(lib().xrit_demod_keep_stages(self._h, int(enable)))

@@ -1062,6 +1062,7 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     if (const char *e = getenv("XRIT_OV_HIST")) { const int v = atoi(e); if (v >= 1024) ov_hist = v; }
     if (const char *e = getenv("XRIT_OV_MIN")) { const long long v = atoll(e); if (v > 0) ov_min = v; }
     if (const char *e = getenv("XRIT_OV_SMALL_RING")) ov_small_ring = atoi(e) != 0;
+    if (const char *e = getenv("XRIT_OV_MINL")) { const int v = atoi(e); if (v >= 1024) ov_min_range = v; }
     if (const char *e = getenv("XRIT_OV_MINW")) { const int v = atoi(e); if (v >= 1) ov_min_walkers = v; }
     if (const char *e = getenv("XRIT_OV_LRATIO")) { const double v = atof(e); if (v >= 0.125 && v <= 16.0) ov_lratio = v; }
     {
@@ -1642,7 +1643,7 @@ int ClockStage::ov_plan(OvJob &j, bool ahead)
     const double nsym = (double)j.n / (double)par.omega_mid;
     double gt = nsym / ((double)ov_hist * ov_lratio);
     if (gt < (double)ov_min_walkers) gt = (double)ov_min_walkers;
-    if (nsym / gt < 8192.0) gt = nsym / 8192.0;
+    if (nsym / gt < (double)ov_min_range) gt = nsym / (double)ov_min_range;
     if (gt > 4.0 * cu_count - 2.0) gt = 4.0 * cu_count - 2.0;
     if (gt < 1.0) gt = 1.0;
     long long Ls = (long long)ceil((double)j.n / gt);

@@ -58,6 +58,10 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
+    hipStream_t stream_c = nullptr;                                 // ... and, for bursts whose Costas loop is a handful of small kernels
+                                                                    // (few circuit-rate samples: large decimations), that loop: its launches
+                                                                    // then run beside the next burst's decimator instead of behind it
+    size_t costas_own_stream_below = 16u << 20;                     // circuit-rate samples per burst (XRIT_OV_CSTREAM_BELOW)
     hipStream_t stream3[2] = {nullptr, nullptr};                    // the clock recovery's walkers of bursts started ahead (round 5):
                                                                     // two streams, so that two bursts' walkers run side by side
     hipEvent_t ev_done = nullptr;                                   // the current call's clock recovery has left its result
@@ -75,6 +79,7 @@ struct xrit_demod {
         bool costas_finished = false;   // the host has looked at the loop's stop test (and continued it where it had not closed)
         int ov_job = -1;                // the clock stage's job of this input
         bool walk_launched = false;     // its walkers have been enqueued (stream3)
+        int costas_stream = 0;          // 1: its Costas loop runs on stream_c
         bool agc_fallback = false;      // what the AGC's guard and the Costas loop reported for this input
         int c_passes = 0; unsigned c_unconverged = 0; float c_max_residual = 0; bool c_walked = false;
         bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
@@ -229,6 +234,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if (hipStreamCreate(&d->stream) != hipSuccess ||
             hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
             hipStreamCreate(&d->stream3[0]) != hipSuccess || hipStreamCreate(&d->stream3[1]) != hipSuccess ||
+            hipStreamCreate(&d->stream_c) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
@@ -251,6 +257,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
 #ifdef XRIT_EXPERIMENTS
         d->no_defer = getenv("XRIT_NO_DEFER") != nullptr;
 #endif
+        if (const char *e = getenv("XRIT_OV_CSTREAM_BELOW")) d->costas_own_stream_below = (size_t)atoll(e);
         d->clock.relay_window = cfg->clock_exact_window > 0 ? cfg->clock_exact_window : 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
@@ -265,10 +272,12 @@ void xrit_demod_destroy(xrit_demod *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
+    if (d->stream_c) (void)hipStreamSynchronize(d->stream_c);
     for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
+    if (d->stream_c) { (void)hipStreamSynchronize(d->stream_c); (void)hipStreamDestroy(d->stream_c); }
     for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
@@ -290,11 +299,12 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
+    XR_HIP(hipStreamSynchronize(d->stream_c));
     for (auto w : d->stream3) XR_HIP(hipStreamSynchronize(w));      // ... and so do walkers
     if (d->costas.job.n && d->pf_count > 0) {
         // (a Costas loop begun ahead and never looked at: the stage's bookkeeping is brought to an end before its state is reset)
         for (int i = 0; i < d->pf_count; ++i)
-            if (d->pf[i].costas_begun && !d->pf[i].costas_finished) { bool redone = false; (void)d->costas.finish(d->stream2, nullptr, &redone); }
+            if (d->pf[i].costas_begun && !d->pf[i].costas_finished) { bool redone = false; (void)d->costas.finish(d->pf[i].costas_stream ? d->stream_c : d->stream2, nullptr, &redone); }
     }
     d->pf_count = 0;
     d->last_fe_set = -1;
@@ -576,7 +586,7 @@ static int ov_service(xrit_demod *d, bool *progress)
             if (hipEventQuery(d->ev_costas) != hipSuccess) { costas_busy = true; continue; }
             if (f.length && d->agc.requested_flag() == 2.0f) f.agc_fallback = true;
             bool redone = false;
-            int rc = d->costas.finish(d->stream2, prof, &redone);
+            int rc = d->costas.finish(f.costas_stream ? d->stream_c : d->stream2, prof, &redone);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
             f.c_passes = d->costas.passes; f.c_unconverged = d->costas.unconverged; f.c_max_residual = d->costas.max_residual;
             f.c_walked = d->costas.job.rescued && d->costas.walked;
@@ -597,7 +607,11 @@ static int ov_service(xrit_demod *d, bool *progress)
             // (on the front ends' stream, behind this input's: measured with every stream on a hardware queue of its own
             // -- GPU_MAX_HW_QUEUES=8 -- a Costas stream beside the front ends' costs 10 %, 2.05 against 1.85 ms per C2 burst: the
             // loop's passes and the next input's decimator fill the chip each and only slow one another)
-            hipStream_t sc = d->stream2;
+            // (... unless the loop is a handful of small kernels -- C5: 2 M samples at the circuit rate, 0.3 ms of launches --, which
+            // then overlap the next input's decimator: 1.1 -> 0.9 ms per C5 burst)
+            f.costas_stream = f.length < d->costas_own_stream_below ? 1 : 0;
+            hipStream_t sc = f.costas_stream ? d->stream_c : d->stream2;
+            if (f.costas_stream) XR_HIP(hipStreamWaitEvent(sc, d->ev_fe[f.set], 0));
             int rc = costas_enqueue(d, io, sc, prof, &f.slot);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
             XR_HIP(hipEventRecord(d->ev_costas, sc));
@@ -853,6 +867,13 @@ int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft, size_t cap, size
     d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
     *n_out = k;
     return XRIT_OK;
+}
+
+int xrit_demod_prefetch_depth(xrit_demod *d, size_t n)
+{
+    if (!d) return 0;
+    if (d->keep_stages || d->keep_symbols || (d->prof.enabled && !d->prof.light)) return 0;
+    return ov_call(d, n) ? 2 : 1;
 }
 
 int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, int type, void *stream)

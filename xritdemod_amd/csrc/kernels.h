@@ -333,6 +333,7 @@ struct ClockStage {
     bool ov_enabled = true;     // XRIT_NO_OVERLAP=1 (read at init): the relay of clock_relay.h for every call, as in round 4
     long long ov_min = 1000000; // symbols from which the default configuration walks overlapping blocks
     int ov_hist = 49152;        // symbols of exactly walked history in front of every range (XRIT_OV_HIST)
+    int ov_min_range = 8192;    // symbols per range at least (XRIT_OV_MINL)
     int ov_min_walkers = 240;   // walkers at least, where ranges of 8192 symbols allow (XRIT_OV_MINW): few walkers, long latency
     bool ov_small_ring = false; // XRIT_OV_SMALL_RING=1: sample rings of 1024 instead of 2048 samples where a block's span allows
     double ov_lratio = 1.0;     // range length aimed at, in histories (XRIT_OV_LRATIO): every symbol is walked 1 + 1 / ov_lratio times
