@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import xritdemod_amd as xa
 from xritdemod_amd import _capi
@@ -18,9 +18,10 @@ def run(fs, D, log2, calls, prefetch):
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(dev)[0]
     t0 = time.perf_counter(); tot = 0; worst = (0, 0)
-    if prefetch: dem.prefetch_device(buf[0].data_ptr(), n, stream=st.cuda_stream)
+    depth = dem.prefetch_depth(n) if prefetch else 0
+    for q in range(min(depth, calls)): dem.prefetch_device(buf[q % nbuf].data_ptr(), n, stream=st.cuda_stream)
     for c in range(calls):
-        if prefetch and c + 1 < calls: dem.prefetch_device(buf[(c + 1) % nbuf].data_ptr(), n, stream=st.cuda_stream)
+        if prefetch and c + depth < calls: dem.prefetch_device(buf[(c + depth) % nbuf].data_ptr(), n, stream=st.cuda_stream)
         tot += dem.process_device(buf[c % nbuf].data_ptr(), n, soft.data_ptr(), cap, stream=st.cuda_stream)
         s = dem.stats()
         worst = (max(worst[0], s.costas_passes), max(worst[1], s.clock_relay_passes))
