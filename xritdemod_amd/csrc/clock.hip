@@ -1060,11 +1060,14 @@ int ClockStage::init(float omega, float gain_omega, float mu, float gain_mu, flo
     carry = 0;
     ov_enabled = getenv("XRIT_NO_OVERLAP") == nullptr;
     if (const char *e = getenv("XRIT_OV_HIST")) { const int v = atoi(e); if (v >= 1024) ov_hist = v; }
+#ifdef XRIT_EXPERIMENTS
+    // (the plan's other parameters: A/B runs of DESIGN.md sections 5-6, not in the shipped library)
     if (const char *e = getenv("XRIT_OV_MIN")) { const long long v = atoll(e); if (v > 0) ov_min = v; }
     if (const char *e = getenv("XRIT_OV_SMALL_RING")) ov_small_ring = atoi(e) != 0;
     if (const char *e = getenv("XRIT_OV_MINL")) { const int v = atoi(e); if (v >= 1024) ov_min_range = v; }
     if (const char *e = getenv("XRIT_OV_MINW")) { const int v = atoi(e); if (v >= 1) ov_min_walkers = v; }
     if (const char *e = getenv("XRIT_OV_LRATIO")) { const double v = atof(e); if (v >= 0.125 && v <= 16.0) ov_lratio = v; }
+#endif
     {
         // history a warm walker 0 needs in front of the new samples: its warm-up, the symbols it stages in front of the carried
         // position, the two symbols of history its start state interpolates

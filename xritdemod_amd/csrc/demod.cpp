@@ -257,7 +257,9 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
 #ifdef XRIT_EXPERIMENTS
         d->no_defer = getenv("XRIT_NO_DEFER") != nullptr;
 #endif
+#ifdef XRIT_EXPERIMENTS
         if (const char *e = getenv("XRIT_OV_CSTREAM_BELOW")) d->costas_own_stream_below = (size_t)atoll(e);
+#endif
         d->clock.relay_window = cfg->clock_exact_window > 0 ? cfg->clock_exact_window : 0;
         if (cfg->clock_min_passes > 0)
             d->clock.min_passes = cfg->clock_min_passes < d->clock.max_passes ? cfg->clock_min_passes : d->clock.max_passes;
