@@ -130,6 +130,9 @@ __device__ __forceinline__ void fir_leave_history(const void *__restrict__ in, c
 // (8 mod 64: two lanes per bank, the minimum for 128 dwords)
 template <bool MF> __device__ __forceinline__ int fir_mf_pos(int q) { return MF ? q + 20 * (q / 80) : q; }
 
+#ifndef XRIT_FE_PRIO
+#define XRIT_FE_PRIO 1
+#endif
 template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1, bool MF = false>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
@@ -137,9 +140,12 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
                  int tile_len, float2 *__restrict__ stat, int statL, AgcEpilogue agc, AgcFill af,
                  float2 *__restrict__ hist_new, const float *__restrict__ mfb = nullptr)
 {
-#ifdef XRIT_FE_SETPRIO
-    __builtin_amdgcn_s_setprio(XRIT_FE_SETPRIO);      // (experiment: the filters' waves in front of the relay's walkers at issue)
-#endif
+    // The filters' waves go in front of the clock recovery's walkers at instruction issue.  Round 3 measured this as a loss
+    // (a burst waited for its relay's three dependent passes: an issue slot a walker lost was lost for good); since round 5
+    // the walkers' latency is hidden behind two more bursts (demod.cpp) and what counts is how long the front end's stream is
+    // busy per burst: 1.73-1.76 against 1.80-1.85 ms per C2 burst (same box, interleaved; the Costas passes at the same
+    // priority as well: 1.79-1.82, so they stay where they are).
+    __builtin_amdgcn_s_setprio(XRIT_FE_PRIO);
     // (AGC in the window fill: `in` is the serially produced AGC output if the guard has tripped, else see below)
     if (hist_new != nullptr && blockIdx.x == gridDim.x - 1 && (APL == 0 || af.state_out[1] != 0.0f))
         fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
@@ -398,6 +404,8 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
                 const float *__restrict__ hq /* [DP][NQ] */, int T, long long n_out, long long n_in, int tile_len,
                 float2 *__restrict__ hist_new)
 {
+    // (no raised issue priority here, unlike fir_decim_kernel: C5's bursts have few walkers and a short front end, the walkers'
+    // latency is not hidden there -- 1.27 against 1.07 ms per burst with it)
     if (hist_new != nullptr && blockIdx.x == 0) fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *tile = reinterpret_cast<float2 *>(smem_raw);
