@@ -422,6 +422,8 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     return XRIT_OK;
 }
 
+static bool ov_call(xrit_demod *d, size_t n);
+
 // the front end of a registered input on stream2 (xrit_demod_prefetch_device); `after`: not before this event
 static int launch_prefetched(xrit_demod *d, xrit_demod::Prefetched &f, hipEvent_t after)
 {
@@ -434,7 +436,10 @@ static int launch_prefetched(xrit_demod *d, xrit_demod::Prefetched &f, hipEvent_
     d->next_set ^= 1;
     SliceIO io;
     Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    // (the filters' waves in front of the walkers at issue -- where the walkers' latency is hidden: bursts that walk overlapping blocks)
+    d->dec.prio = d->rrc.prio = ov_call(d, f.n) ? 1 : 0;
     int rc = front_end(d, f.samples, f.n, f.type, set, d->stream2, prof, &io);
+    d->dec.prio = d->rrc.prio = 0;
     if (rc != XRIT_OK) { d->poisoned = true; return rc; }
     XR_HIP(hipEventRecord(d->ev_fe[set], d->stream2));
     d->last_fe_set = set;

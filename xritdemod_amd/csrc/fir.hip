@@ -145,7 +145,11 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
     // the walkers' latency is hidden behind two more bursts (demod.cpp) and what counts is how long the front end's stream is
     // busy per burst: 1.73-1.76 against 1.80-1.85 ms per C2 burst (same box, interleaved; the Costas passes at the same
     // priority as well: 1.79-1.82, so they stay where they are).
-    __builtin_amdgcn_s_setprio(XRIT_FE_PRIO);
+    // (asked for per launch -- FirStage::prio, carried in the upper half of statL --: the chain raises it for bursts whose clock
+    // recovery walks overlapping blocks; beside the RELAY, whose passes a burst still waits for, it is the loss round 3 measured:
+    // cfg.clock_exact = -3 2.60 against 2.02 ms per C2 burst)
+    if (statL >> 16) __builtin_amdgcn_s_setprio(XRIT_FE_PRIO);
+    statL &= 0xffff;
     // (AGC in the window fill: `in` is the serially produced AGC output if the guard has tripped, else see below)
     if (hist_new != nullptr && blockIdx.x == gridDim.x - 1 && (APL == 0 || af.state_out[1] != 0.0f))
         fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
@@ -649,24 +653,24 @@ static int fir_launch_t(const FirStage &f, const void *in, int type, float2 *out
     const float *g = f.g.as<float>();
 #define XR_FIR_GO(TY)                                                                                          \
     hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, TY>), dim3(blocks), dim3(f.threads), f.lds_bytes, s, in, h,  \
-                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL, agc, af, \
+                       out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in, f.tile_len, stat, statL | (f.prio << 16), agc, af, \
                        f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr)
 #ifdef XRIT_EXPERIMENTS
     if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && f.mfma_dec && f.threads == 256)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5, (RC == 3 && !PAD)>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes + (f.tile_len / 80 + 1) * 20 * 8, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
-                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr,
+                           f.tile_len, stat, statL | (f.prio << 16), agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr,
                            f.mfb.as<float>());
     else
 #endif
     if (RC == 3 && !PAD && f.T == 151 && f.D == 5 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_dec)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 3 && !PAD) ? 151 : 0, 5>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
-                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
+                           f.tile_len, stat, statL | (f.prio << 16), agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
     else if (RC == 5 && !PAD && f.T == 63 && f.D == 1 && type == XRIT_SAMPLE_FLOATIQ && !f.no_static_mf)
         hipLaunchKernelGGL((fir_decim_kernel<RC, PAD, XRIT_SAMPLE_FLOATIQ, 0, (RC == 5 && !PAD) ? 63 : 0>), dim3(blocks),
                            dim3(f.threads), f.lds_bytes, s, in, h, out, g, f.T, f.D, f.Wpad, (long long)n_out, (long long)n_in,
-                           f.tile_len, stat, statL, agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
+                           f.tile_len, stat, statL | (f.prio << 16), agc, af, f.T > 1 ? f.hist[f.cur ^ 1].as<float2>() : (float2 *)nullptr);
     else if (type == XRIT_SAMPLE_FLOATIQ) XR_FIR_GO(XRIT_SAMPLE_FLOATIQ);
     else if (type == XRIT_SAMPLE_S16IQ) XR_FIR_GO(XRIT_SAMPLE_S16IQ);
     else XR_FIR_GO(XRIT_SAMPLE_S8IQ);
@@ -693,11 +697,11 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
         if (f.T == 63 && !f.no_static_mf)
             hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3, 63>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                                in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
-                               (long long)n, f.tile_len, stat, statL, none, af, f.hist[f.cur ^ 1].as<float2>());
+                               (long long)n, f.tile_len, stat, statL | (f.prio << 16), none, af, f.hist[f.cur ^ 1].as<float2>());
         else
         hipLaunchKernelGGL((fir_decim_kernel<5, false, XRIT_SAMPLE_FLOATIQ, 3>), dim3(blocks), dim3(f.threads), f.lds_bytes, s,
                            in, f.hist[f.cur].as<float2>(), out, f.g.as<float>(), f.T, f.D, f.Wpad, (long long)n,
-                           (long long)n, f.tile_len, stat, statL, none, af, f.hist[f.cur ^ 1].as<float2>());
+                           (long long)n, f.tile_len, stat, statL | (f.prio << 16), none, af, f.hist[f.cur ^ 1].as<float2>());
     }
     XR_HIP(hipGetLastError());
     f.cur ^= 1;
