@@ -1190,6 +1190,9 @@ int ClockStage::om_scan(hipStream_t s)
     if (ov_job >= 0 && ov[ov_job].state == 1) {
         OvJob &j = ov[ov_job];
         if (!j.om_ext || j.nb < 1) return XRIT_OK;
+        // (an overlap job's curve is needed by its walkers' start states only: unwrapped on THEIR stream, ov_launch -- the
+        // producer's stream, which sets a burst's pace, is spared two launches)
+        if (!ov_scan_now) return XRIT_OK;
         const int nb = j.nb, nbB = scan_blocks(nb);
         XR_TRY(j.om_work.reserve((size_t)(nbB + 2) * sizeof(double)));
         double2 *X = j.om.as<double2>();
@@ -1622,7 +1625,7 @@ int ClockStage::ov_plan(OvJob &j, bool ahead)
     j.hist = (int)ceil((double)ov_hist * (double)par.omega_mid);
     j.early = (int)ceil(1.5 * wmax) + 2;
     // history: the samples the call in front left at the end of its buffer, and the timing curve that covers them
-    const bool have_hist = hist_xb >= 0 && hist_len >= (size_t)ov_pad_need && hist_job >= 0 && ov[hist_job].om_scanned;
+    const bool have_hist = hist_xb >= 0 && hist_len >= (size_t)ov_pad_need && hist_job >= 0 && ov[hist_job].om_scanned;      // (scanned: the job in front has been launched)
     if (ahead && !have_hist) { set_error("clock recovery: an overlap job cannot start ahead without the history of the call in front"); return XRIT_E_INVALID; }
     j.ahead = ahead;
     if (have_hist) {
@@ -1680,7 +1683,7 @@ int ClockStage::ov_plan(OvJob &j, bool ahead)
 
 bool ClockStage::ov_can_launch_ahead(int job) const
 {
-    if (job < 0 || job >= NXB || ov[job].state != 1 || !ov[job].om_scanned) return false;
+    if (job < 0 || job >= NXB || ov[job].state != 1 || !ov[job].om_ext) return false;
     // the job in front must be an overlap job whose samples and timing curve are in place (its walkers may still be at work)
     for (int q = 0; q < NXB; ++q)
         if (q != job && ov[q].state >= 1 && ov[q].serial + 1 == ov[job].serial)
@@ -1705,6 +1708,7 @@ int ClockStage::ov_launch(int job, hipStream_t sw, bool ahead, Profiler *prof)
         for (int q = 0; q < NXB; ++q) if (q != job && ov[q].state >= 1 && ov[q].serial + 1 == j.serial) front = q;
         if (front < 0) { set_error("clock recovery: no job in front of a job launched ahead"); return XRIT_E_INVALID; }
         h_xb = front; h_job = front; h_len = (size_t)ov[front].padN + ov[front].n;
+        XR_HIP(hipStreamWaitEvent(sw, ov[front].ev_guess, 0));      // (the curve of the job in front is unwrapped on ITS walkers' stream)
         // (the plan looks at hist_*: described for the duration of the plan)
         const int k_xb = hist_xb, k_job = hist_job; const size_t k_len = hist_len;
         hist_xb = h_xb; hist_job = h_job; hist_len = h_len;
@@ -1740,7 +1744,9 @@ int ClockStage::ov_launch(int job, hipStream_t sw, bool ahead, Profiler *prof)
         const int k_job = ov_job;
         const int k_state = j.state;
         ov_job = job; j.state = 1;
+        ov_scan_now = true;
         const int rc = om_scan(sw);
+        ov_scan_now = false;
         ov_job = k_job; j.state = k_state;
         XR_TRY(rc);
     }
