@@ -574,12 +574,12 @@ static bool ov_call(xrit_demod *d, size_t n)
 
 // whatever can be enqueued for the registered inputs, oldest first, without waiting for the device.  Returns an error code;
 // *progress: something was enqueued or finished.
-static int ov_service(xrit_demod *d, bool *progress)
+static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
 {
     Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
     if (progress) *progress = false;
     bool costas_busy = false;       // a Costas loop begun and not yet finished: the stage takes the next input behind it
-    for (int i = 0; i < d->pf_count; ++i) {
+    for (int i = 0; i < d->pf_count && i < limit; ++i) {
         xrit_demod::Prefetched &f = d->pf[i];
         if (!ov_call(d, f.n)) break;                    // (inputs that take the other path are started by their own calls)
         // (two sets of front-end buffers: the input two in front used the set this one takes, and its Costas loop reads that set
@@ -663,9 +663,11 @@ static int process_overlap(xrit_demod *d, const void *d_samples, size_t n, int t
     int rc = ov_service(d, nullptr);
     if (rc != XRIT_OK) return fail(rc);
     // this call's Costas loop must have been looked at before its clock recovery is laid out
+    // (only THIS input here: what the host enqueues for the inputs behind it -- a Costas loop, a front end: 0.2 ms of launches --
+    // goes behind this call's walkers, which are on the critical path when nothing ran ahead)
     for (int spins = 0; !d->pf[0].costas_finished; ++spins) {
         if (d->pf[0].costas_begun) { if (hipEventSynchronize(d->ev_costas) != hipSuccess) { set_error("hipEventSynchronize failed"); return fail(XRIT_E_HIP); } }
-        if ((rc = ov_service(d, nullptr)) != XRIT_OK) return fail(rc);
+        if ((rc = ov_service(d, nullptr, 1)) != XRIT_OK) return fail(rc);
         if (spins > 8) { set_error("the Costas loop of the call could not be started"); return fail(XRIT_E_INVALID); }
     }
     xrit_demod::Prefetched &f0 = d->pf[0];
@@ -678,6 +680,7 @@ static int process_overlap(xrit_demod *d, const void *d_samples, size_t n, int t
     rc = d->clock.begin(f0.length, d_soft, nullptr, cap, s, prof);
     if (rc != XRIT_OK) return fail(rc);
     if (hipEventRecord(d->ev_done, s) != hipSuccess) { set_error("hipEventRecord failed"); return fail(XRIT_E_HIP); }
+    if ((rc = ov_service(d, nullptr)) != XRIT_OK) return fail(rc);
     // while the walkers finish: keep the inputs behind this one moving (the Costas loop of the next one may close meanwhile,
     // which frees the stage for the one after it)
     for (;;) {
