@@ -1650,7 +1650,10 @@ int ClockStage::ov_plan(OvJob &j, bool ahead)
     double gt = nsym / ((double)ov_hist * ov_lratio);
     if (gt < (double)ov_min_walkers) gt = (double)ov_min_walkers;
     if (nsym / gt < (double)ov_min_range) gt = nsym / (double)ov_min_range;
-    if (gt > 4.0 * cu_count - 2.0) gt = 4.0 * cu_count - 2.0;
+    // (at most 2.5 per CU: bursts at the circuit rate -- 63 M / 100 M symbols -- would take four per CU by the rule above; with 640
+    // walkers of 98 k / 156 k symbols every symbol is walked 1.5 / 1.3 times instead of 1.8 / 1.5: C1 4.8 instead of 5.1 ms per
+    // burst, C3 5.4 instead of 5.55 -- their latency is hidden like any other's)
+    if (gt > 2.5 * cu_count) gt = 2.5 * cu_count;
     if (gt < 1.0) gt = 1.0;
     long long Ls = (long long)ceil((double)j.n / gt);
     Ls = (Ls + 63) & ~63LL;
