@@ -1098,6 +1098,52 @@ def test_flipped_rerun_behind_a_call_of_overlapping_blocks(xa):
     assert np.mean(np.sign(c[:m][big]) == -np.sign(r[:m][big])) > 0.9999          # (the stream's polarity stays flipped: the Costas phase moved by pi)
 
 
+def test_overlap_pipeline_survives_resets_refusals_and_abandoned_inputs(xa):
+    """The three-bursts-in-flight pipeline (two inputs registered behind the call in progress) at its edges: a call refused for
+    its capacity consumes nothing (the retry gives the plain words); inputs must be taken in the order they were registered; a
+    fourth waiting input is refused; a handle reset -- or destroyed -- while the walkers of two bursts and the front end of a
+    third are at work starts over cleanly."""
+    import torch
+    n, fs, nb = 1 << 23, 1.25e6, 4
+    buf = _device_bursts(dict(fs_in=fs), n, nb)
+    cap = int(n / 4.2) + 4096
+    cfg = xa.Demodulator.config("lrit", fs, 1)
+    plain, _ = _run_plan(xa, cfg, buf, [("go", b) for b in range(nb)], cap)
+    soft = torch.empty(cap, dtype=torch.float32, device=buf.device)
+    d = xa.Demodulator(cfg)
+    assert d.prefetch_depth(n) == 2 and d.prefetch_depth(1 << 20) == 1
+    for b in range(3):
+        d.prefetch_device(buf[b].data_ptr(), n)
+    with pytest.raises(xa.XritError):                    # three are waiting (the call in progress and two behind it)
+        d.prefetch_device(buf[3].data_ptr(), n)
+    with pytest.raises(xa.XritError):                    # refused before anything runs: nothing consumed
+        d.process_device(buf[0].data_ptr(), n, soft.data_ptr(), 1000)
+    k = d.process_device(buf[0].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy().view(np.uint32), plain[0].view(np.uint32))
+    d.prefetch_device(buf[3].data_ptr(), n)
+    k = d.process_device(buf[1].data_ptr(), n, soft.data_ptr(), cap)
+    assert np.array_equal(soft[:k].cpu().numpy().view(np.uint32), plain[1].view(np.uint32))
+    # bursts 2 and 3 are in flight (front ends, a Costas loop, walkers): the stream is left
+    d.reset()
+    for b in range(2):
+        d.prefetch_device(buf[b].data_ptr(), n)
+    for b in range(2):
+        k = d.process_device(buf[b].data_ptr(), n, soft.data_ptr(), cap)
+        assert np.array_equal(soft[:k].cpu().numpy().view(np.uint32), plain[b].view(np.uint32)), b
+    # out of order: the handle cannot go on
+    d.prefetch_device(buf[2].data_ptr(), n)
+    with pytest.raises(xa.XritError):
+        d.process_device(buf[3].data_ptr(), n, soft.data_ptr(), cap)
+    del d
+    # destroyed with work in flight
+    d2 = xa.Demodulator(cfg)
+    for b in range(3):
+        d2.prefetch_device(buf[b].data_ptr(), n)
+    d2.process_device(buf[0].data_ptr(), n, soft.data_ptr(), cap)
+    del d2
+    torch.cuda.synchronize()
+
+
 def test_run_to_run_determinism(xa):
     """Two fresh handles on the same input give bit-identical symbols (the hand-off passes, their stop test and
     every reduction are order independent)."""
