@@ -216,6 +216,25 @@ def test_no_signal_is_not_walked_to_closure(xa):
     assert len(yf) > 150000 and sf.clock_relay_passes <= 96 and (sf.clock_relay_closed == 0 or sf.clock_relay_segments <= 96)
 
 
+def test_no_signal_in_a_big_call_is_not_walked_to_closure_either(xa):
+    """The same on a call long enough for overlapping blocks (1.6 M symbols of noise): walkers of a loop that is not locked do not
+    meet at their joints, the call falls back -- to the relay's own default, three passes, not to a closure that would take one pass
+    per segment -- and the stream goes on."""
+    import time
+    rng = np.random.default_rng(6)
+    n = 1 << 25
+    x = (0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    for _ in range(2):
+        t0 = time.perf_counter()
+        y = dem.process(x)
+        dt = time.perf_counter() - t0
+        st = dem.stats()
+        assert len(y) > 1500000 and np.isfinite(y).all()
+        assert st.clock_relay_closed == 0 and 1 <= st.clock_relay_passes <= 8, (st.clock_relay_passes, st.clock_relay_closed)
+        assert dt < 10.0, dt         # (host buffers, first-call allocations; what a closure would cost is in the pass count above)
+
+
 def test_clock_stage(xa, oracle_mod, lrit_1m):
     o = oracle_mod
     d = o.Demod(o.config("lrit", 1.25e6, 1))

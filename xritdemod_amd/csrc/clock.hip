@@ -1808,14 +1808,16 @@ int ClockStage::ov_restart(int job, hipStream_t s)
 
 // a call that began as an overlap job and whose result is not taken (low Es/N0: the default walks such calls to closure; a joint
 // that did not fit: a timing guess off by a symbol): the relay of clock_relay.h, to closure, on the same samples
-int ClockStage::ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof)
+int ClockStage::ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof, bool to_closure)
 {
     const int job = ov_cur;
     OvJob &j = ov[job];
     ov_cur = -1;
     j.state = 0;
     const int k_exact = exact;
-    exact = 1;
+    // (no signal -- the walkers of a loop that is not locked do not meet at the joints --: the relay's own default, which does not
+    // pursue a closure on such an input either; ClockStage::finish)
+    exact = to_closure ? 1 : 0;
     xb = job;
     xbase_fixed = xbuf[job].as<float2>() + xpad - carry;        // (the call's samples lie where they were produced; the tail goes in front)
     const int rc = run(j.n, ov_soft, nullptr, ov_cap, n_out, s, prof);
@@ -2145,8 +2147,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         // -- walked to closure, the serial trajectory whatever the noise --, and a joint whose two trajectories do not meet within a
         // quarter symbol -- the timing guess and the loop disagree about a symbol count.
         const bool signal = snr2 >= auto_snr_floor;
-        if ((signal && !(snr2 >= auto_snr)) || hc[17] > 0 || (!r.ok && r.n_symbols <= oj.stride * (unsigned long long)oj.G && (size_t)r.n_symbols <= ov_cap && hc[17] > 0))
-            return ov_fallback(n_out, s, prof);
+        if ((signal && !(snr2 >= auto_snr)) || hc[17] > 0) return ov_fallback(n_out, s, prof, signal);
         oj.state = 0;
         const int jb = ov_cur;
         ov_cur = -1;

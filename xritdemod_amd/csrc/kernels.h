@@ -357,7 +357,7 @@ struct ClockStage {
     // a job whose walkers were started ahead on samples that have since been rewritten (the Costas loop went on from the host):
     // waits for them (on `s`'s behalf: the host synchronises the event) and takes the job back to "samples produced"
     int ov_restart(int job, hipStream_t s);
-    int ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof);
+    int ov_fallback(size_t *n_out, hipStream_t s, Profiler *prof, bool to_closure);
     bool ov_scan_now = false;   // om_scan() is being called from ov_launch (an overlap job's curve is unwrapped on its walkers' stream)
     int ov_cur = -1;            // the overlap job of the call between begin() and finish()
     float *ov_soft = nullptr; size_t ov_cap = 0; size_t carry_before_fallback = 0;
