@@ -248,7 +248,7 @@ def main():
     # begins on an empty pipeline)
     # inputs registered behind the call in progress: what the library takes for calls of this size (2 for bursts whose clock
     # recovery walks overlapping blocks, else 1)
-    depth = max(1, min(args.prefetch_depth, dem.prefetch_depth(n_burst), 2))
+    depth = max(1, min(args.prefetch_depth, dem.prefetch_depth(n_burst)))
     if not args.no_prefetch:
         for q in range(min(depth, W)):
             dem.prefetch_device(bursts[q % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)

@@ -1146,6 +1146,20 @@ int ClockStage::reset(hipStream_t s)
 
 void ClockStage::release()
 {
+#ifdef XRIT_RELAY_TIMING
+    if (getenv("XRIT_WALKER_PHASES")) {
+        // (everything the overlap walkers of this process spent since the last look: no copy inside the pipeline, which a
+        // hipMemcpy on the null stream would serialise)
+        unsigned long long hd[16] = {0}, z[16] = {0};
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(hd, HIP_SYMBOL(relay_dbg), sizeof hd) == hipSuccess && hd[6]) {
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z);
+            const double st = (double)hd[6];
+            fprintf(stderr, "[xrit] overlap walkers over the handle's life, cycles per step: ring wait %.0f, setup %.0f, guess rounds %.0f, literal step + verdict %.0f, "
+                            "stage + commit %.0f, loop %.0f; sum %.0f (%llu steps)\n", hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st,
+                    hd[5] / st, (hd[0] + hd[1] + hd[2] + hd[3] + hd[4] + hd[5]) / st, hd[6]);
+        }
+    }
+#endif
     for (auto &b : xbuf) b.release();
     for (auto &j : ov) {
         j.om.release(); j.om_work.release(); j.segs.release(); j.S.release(); j.stage.release(); j.aux.release();
@@ -1223,14 +1237,14 @@ int ClockStage::input_slot(size_t n, float2 **slot, hipStream_t s)
 {
     // A buffer nobody reads: not the one of the call in flight, not one whose walkers are at work (overlap jobs), and not the
     // one that holds the stream's last samples -- the history the next overlap call's first walkers warm up over.
-    bool busy[NXB] = {false, false, false};
+    bool busy[NXB] = {};
     if (in_flight) busy[xb] = true;
     for (int q = 0; q < NXB; ++q) if (ov[q].state != 0) busy[q] = true;
     int b = -1;
     // (the call that follows the stream's last samples may not overwrite them -- unless nothing else is free)
     for (int q = 0; q < NXB && b < 0; ++q) { const int c = (xb + 1 + q) % NXB; if (!busy[c] && c != hist_xb) b = c; }
     for (int q = 0; q < NXB && b < 0; ++q) { const int c = (xb + q) % NXB; if (!busy[c]) b = c; }
-    if (b < 0) { set_error("clock recovery: no free sample buffer (three calls are already in flight)"); return XRIT_E_INVALID; }
+    if (b < 0) { set_error("clock recovery: no free sample buffer (%d calls are already in flight)", NXB); return XRIT_E_INVALID; }
     // (a job whose first walkers warm up over what this buffer holds must have read it: its pad copy and start states)
     for (int q = 0; q < NXB; ++q)
         if (ov[q].state >= 2 && ov[q].hist_src == b) XR_HIP(hipStreamWaitEvent(s, ov[q].ev_guess, 0));
@@ -2141,6 +2155,16 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
                             "joints: %d do not fit, largest distance %.3e sample; 2 Es/N0 = %.1f; %llu symbols%s\n",
                     oj.G, oj.Ls, oj.hist, oj.w0_carried ? "walker 0 from the carried state" : "walker 0 warms up in the burst before", hs[0],
                     hs[0] ? (double)hs[1] / hs[0] : 0.0, hc[17], (double)far_, (double)snr2, (unsigned long long)r.n_symbols, r.ok ? "" : " -- NOT taken");
+#ifdef XRIT_RELAY_TIMING
+            // (what the walkers that have finished since the last look spent per step, whichever burst they belong to)
+            unsigned long long hd[16] = {0}, z[16] = {0};
+            XR_HIP(hipMemcpyFromSymbol(hd, HIP_SYMBOL(relay_dbg), sizeof hd));
+            XR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z));
+            const double st = hd[6] ? (double)hd[6] : 1.0;
+            fprintf(stderr, "[xrit] overlap walkers, cycles per step: ring wait %.0f, setup %.0f, guess rounds %.0f, literal step + verdict %.0f, "
+                            "stage + commit %.0f, loop %.0f; sum %.0f (%llu steps)\n", hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st,
+                    hd[5] / st, (hd[0] + hd[1] + hd[2] + hd[3] + hd[4] + hd[5]) / st, hd[6]);
+#endif
         }
         if (hc[15]) { set_error("clock recovery: a walker gave up waiting for its sample ring (watchdog)"); oj.state = 0; ov_cur = -1; return XRIT_E_HIP; }
         // The default configuration's two looks at such a call (ClockStage::finish below has them for the relay): Es/N0 below 7 dB

@@ -168,7 +168,11 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
     bool exhausted = false, stuck = false;
     int x_hi = x_lo;
     float m1 = 0.f, m2 = 0.f;
+#ifdef XRIT_RELAY_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        RELAY_TICK(5);
         const int ii0 = (int)T.ii;
         if ((unsigned)ii0 >= (unsigned)ni_w) { exhausted = true; break; }
         if (ii0 >= hi) break;                               // the next symbol is the next walker's
@@ -185,6 +189,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             }
             if (stuck) break;
         }
+        RELAY_TICK(0);
         // the walker's state on the lattice; first guess: symbol n + lane at the walker's own rate
         const int mu0u = (int)(T.mu * 16777216.0f), W0 = (int)(T.omega * 16777216.0f);
         const int wint = W0 >> 24, wfrac = W0 & 0xffffff;
@@ -197,6 +202,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
         float mm = 0.f;
         ClockState hs{};
         bool stale = false, inrange = true;
+        RELAY_TICK(1);
         for (int round = 0; round < RELAY_ROUNDS; ++round) {
             ++rounds_total;
             inrange = cii >= ii0 && cii + XR_MM_NTAPS <= need_x;
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             cii = nii; carm = narm; cmu = nmu; com = nom;
             if (!__any(stale)) break;
         }
+        RELAY_TICK(2);
         // the literal step from every lane's state, compared with the neighbour's state bit for bit
         ClockState st = hs;
         st.ii = cii; st.mu = cmu; st.omega = com;
@@ -245,6 +252,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
         nv = nv < g ? nv : g;
         nv = nv < h ? nv : h;
         if (e < nv) { nv = e; exhausted = true; }
+        RELAY_TICK(3);
         if (nv > 0) {
             // stage the verified symbols read inside the range (the lanes' positions rise with the lane: a suffix of [0, nv))
             const int l0 = lom ? __builtin_ctzll(lom) : 64;
@@ -268,8 +276,15 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             T = nt;
             if (lane == 0) relay_st(&sh_pos_ii, (int)T.ii);
         }
+        RELAY_TICK(4);
         if (exhausted || nv == 0) { exhausted = true; break; }
     }
+#ifdef XRIT_RELAY_TIMING
+    if (lane == 0) {
+        for (int q = 0; q < 6; ++q) atomicAdd(&relay_dbg[q], tacc[q]);
+        atomicAdd(&relay_dbg[6], (unsigned long long)steps);
+    }
+#endif
     for (int off = 32; off > 0; off >>= 1) { m1 += __shfl_xor(m1, off, 64); m2 += __shfl_xor(m2, off, 64); }
     if (lane == 0) {
         relay_st(&sh_done, 1);

@@ -62,7 +62,10 @@ struct xrit_demod {
                                                                     // (few circuit-rate samples: large decimations), that loop: its launches
                                                                     // then run beside the next burst's decimator instead of behind it
     size_t costas_own_stream_below = 16u << 20;                     // circuit-rate samples per burst (XRIT_OV_CSTREAM_BELOW)
-    hipStream_t stream3[2] = {nullptr, nullptr};                    // the clock recovery's walkers of bursts started ahead (round 5):
+#ifndef XRIT_WALK_STREAMS
+#define XRIT_WALK_STREAMS 2
+#endif
+    hipStream_t stream3[XRIT_WALK_STREAMS] = {};                    // the clock recovery's walkers of bursts started ahead (round 5):
                                                                     // two streams, so that two bursts' walkers run side by side
     hipEvent_t ev_done = nullptr;                                   // the current call's clock recovery has left its result
     hipEvent_t ev_ready = nullptr, ev_fe[2] = {nullptr, nullptr};   // input ready on the caller's stream / front end of a set done
@@ -85,7 +88,7 @@ struct xrit_demod {
         bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
                                 // starts the front end of the next burst in front of the relay kernels of the current one,
                                 // which leave most of the chip idle, instead of under the loops that fill it
-    } pf[3];                    // inputs registered ahead, oldest first: the one of the next process call and the two behind it
+    } pf[XRIT_AHEAD + 1];                    // inputs registered ahead, oldest first: the one of the next process call and the two behind it
     int pf_count = 0;
     RtlIngestStage rtl;
     bool poisoned = false;      // a call failed after some stage had advanced its carried state
@@ -190,6 +193,12 @@ void xrit_demod_config_hrit(xrit_demod_config *c, float sample_rate, uint32_t de
     c->rrc_alpha = 0.3f;       // HRIT_RRC_ALPHA
 }
 
+static bool create_walker_streams(xrit_demod *d)
+{
+    for (auto &w : d->stream3) if (hipStreamCreate(&w) != hipSuccess) return false;
+    return true;
+}
+
 int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
 {
     if (!cfg || !out) { set_error("null argument"); return XRIT_E_INVALID; }
@@ -233,7 +242,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if (hipStreamCreate(&d->stream) != hipSuccess ||
             hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
-            hipStreamCreate(&d->stream3[0]) != hipSuccess || hipStreamCreate(&d->stream3[1]) != hipSuccess ||
+            !create_walker_streams(d) ||
             hipStreamCreate(&d->stream_c) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
@@ -630,7 +639,7 @@ static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
         if (f.costas_begun && f.ov_job >= 0 && !f.walk_launched && d->clock.ov_can_launch_ahead(f.ov_job)) {
             // (behind the Costas loop's batch and the timing curve: speculative until the host has seen the loop's stop test)
             // (two walker streams, alternating: the walkers of bursts b and b + 1 side by side, those of b + 2 behind b's)
-            hipStream_t sw = d->stream3[d->clock.ov[f.ov_job].serial & 1];
+            hipStream_t sw = d->stream3[d->clock.ov[f.ov_job].serial % XRIT_WALK_STREAMS];
             XR_HIP(hipStreamWaitEvent(sw, d->ev_costas, 0));
             int rc = d->clock.ov_launch(f.ov_job, sw, true, prof);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
@@ -883,7 +892,7 @@ int xrit_demod_prefetch_depth(xrit_demod *d, size_t n)
 {
     if (!d) return 0;
     if (d->keep_stages || d->keep_symbols || (d->prof.enabled && !d->prof.light)) return 0;
-    return ov_call(d, n) ? 2 : 1;
+    return ov_call(d, n) ? XRIT_AHEAD : 1;
 }
 
 int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, int type, void *stream)
@@ -897,7 +906,7 @@ int xrit_demod_prefetch_device(xrit_demod *d, const void *d_samples, size_t n, i
     {
         bool all_ov = ov_call(d, n);
         for (int i = 0; i < d->pf_count && all_ov; ++i) all_ov = ov_call(d, d->pf[i].n);
-        const int room = all_ov ? 3 : 2;
+        const int room = all_ov ? XRIT_AHEAD + 1 : 2;
         if (d->pf_count >= room) { set_error("%d prefetched inputs are already waiting for their process calls", d->pf_count); return XRIT_E_INVALID; }
     }
     // stage copies and per-kernel event brackets belong to one call at a time: no running ahead then

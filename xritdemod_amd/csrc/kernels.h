@@ -166,7 +166,10 @@ struct ClockStage {
     int max_passes = 48, min_passes = 4;
     int jac_passes = 1;     // passes that recompute the chain Jacobians (then quasi-Newton; measured: no gain from more)
     DevBuf table;           // 129 x 8 MMSE taps
-    static constexpr int NXB = 3;
+#ifndef XRIT_AHEAD
+#define XRIT_AHEAD 2            // inputs that may wait behind the call in progress (bursts that walk overlapping blocks)
+#endif
+    static constexpr int NXB = XRIT_AHEAD + 1;
     DevBuf xbuf[NXB];       // [pad | carry | new] input samples of a call.  Three of them (round 5): the producer of the samples of
                             // the call after next (the Costas loop of burst b + 2: xrit_demod_prefetch_device) fills one while the
                             // walkers of bursts b and b + 1 read the other two (round 4: two, one burst ahead)
