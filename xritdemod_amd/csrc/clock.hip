@@ -1155,8 +1155,8 @@ void ClockStage::release()
             (void)hipMemcpyToSymbol(HIP_SYMBOL(relay_dbg), z, sizeof z);
             const double st = (double)hd[6];
             fprintf(stderr, "[xrit] overlap walkers over the handle's life, cycles per step: ring wait %.0f, setup %.0f, guess rounds %.0f, literal step + verdict %.0f, "
-                            "stage + commit %.0f, loop %.0f; sum %.0f (%llu steps)\n", hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st,
-                    hd[5] / st, (hd[0] + hd[1] + hd[2] + hd[3] + hd[4] + hd[5]) / st, hd[6]);
+                            "stage + commit %.0f, loop %.0f; sum %.0f (%llu steps; the ring's fill level read %.3f times per step, %.3f sleeps per step)\n", hd[0] / st, hd[1] / st, hd[2] / st, hd[3] / st, hd[4] / st,
+                    hd[5] / st, (hd[0] + hd[1] + hd[2] + hd[3] + hd[4] + hd[5]) / st, hd[6], hd[7] / st, hd[8] / st);
         }
     }
 #endif

@@ -88,7 +88,6 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
     T.ii = __builtin_amdgcn_readfirstlane((int)T.ii);
     T.mu = relay_lane(T.mu, 0); T.omega = relay_lane(T.omega, 0);
     T.p0 = cf32{relay_lane(T.p0.x, 0), relay_lane(T.p0.y, 0)}; T.p1 = cf32{relay_lane(T.p1.x, 0), relay_lane(T.p1.y, 0)};
-    T.c0 = cf32{relay_lane(T.c0.x, 0), relay_lane(T.c0.y, 0)}; T.c1 = cf32{relay_lane(T.c1.x, 0), relay_lane(T.c1.y, 0)};
     const int ni_w = (int)(a.ni < 0x7fffffffLL ? a.ni : 0x7fffffffLL);
     // staging begins with the symbols read at or beyond lo; those read at or beyond hi are the next walker's
     const int lo = s == 0 ? a.store0 : overlap_bound(a, s) - a.early;
@@ -170,6 +169,7 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
     float m1 = 0.f, m2 = 0.f;
 #ifdef XRIT_RELAY_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    unsigned n_refresh = 0, n_spin = 0;
 #endif
     for (;;) {
         RELAY_TICK(5);
@@ -180,10 +180,16 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
         const int need_x = ii0 + span + 8;
         if (x_hi < need_x) {
             int spins = 0;
+#ifdef XRIT_RELAY_TIMING
+            ++n_refresh;
+#endif
 #pragma nounroll
             while (x_hi < need_x) {
                 x_hi = relay_ld(&sh_xhi);
                 if (x_hi >= need_x) break;
+#ifdef XRIT_RELAY_TIMING
+                ++n_spin;
+#endif
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 22)) { if (lane == 0) a.stat[2] = 0x80000000u | (unsigned)s; stuck = true; break; }
             }
@@ -211,11 +217,13 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
 #pragma unroll
             for (int q = 0; q < XR_MM_NTAPS; ++q) w[q] = wp[q];
             p0 = clock_interp_arm(w, table, carm);
-            const cf32 sl{p0.x > 0.f ? 1.f : 0.f, p0.y > 0.f ? 1.f : 0.f};
             hs.p0 = cf32{relay_shr1_from(p0.x, T.p0.x), relay_shr1_from(p0.y, T.p0.y)};
             hs.p1 = cf32{relay_shr1_from(hs.p0.x, T.p1.x), relay_shr1_from(hs.p0.y, T.p1.y)};
-            hs.c0 = cf32{relay_shr1_from(sl.x, T.c0.x), relay_shr1_from(sl.y, T.c0.y)};
-            hs.c1 = cf32{relay_shr1_from(hs.c0.x, T.c1.x), relay_shr1_from(hs.c0.y, T.c1.y)};
+            // (the slicer decisions of the two symbols in front ARE the signs of those symbols -- clock_advance sets them so,
+            // the start states of clock_overlap_guess_kernel and a flipped state too --: taken from the shifted symbols
+            // instead of being shifted and carried themselves: four lane reads less per step)
+            hs.c0 = cf32{hs.p0.x > 0.f ? 1.f : 0.f, hs.p0.y > 0.f ? 1.f : 0.f};
+            hs.c1 = cf32{hs.p1.x > 0.f ? 1.f : 0.f, hs.p1.y > 0.f ? 1.f : 0.f};
             mm = clock_timing_error(p0, hs);
             const int dW = (int)rintf(mm * gkw) << sh_om;
             const int dM = (int)rintf(mm * gkm) << sh_mu;
@@ -271,8 +279,6 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
             nt.omega = relay_lane(st.omega, src);
             nt.p0 = cf32{relay_lane(st.p0.x, src), relay_lane(st.p0.y, src)};
             nt.p1 = cf32{relay_lane(st.p1.x, src), relay_lane(st.p1.y, src)};
-            nt.c0 = cf32{relay_lane(st.c0.x, src), relay_lane(st.c0.y, src)};
-            nt.c1 = cf32{relay_lane(st.c1.x, src), relay_lane(st.c1.y, src)};
             T = nt;
             if (lane == 0) relay_st(&sh_pos_ii, (int)T.ii);
         }
@@ -283,6 +289,8 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
     if (lane == 0) {
         for (int q = 0; q < 6; ++q) atomicAdd(&relay_dbg[q], tacc[q]);
         atomicAdd(&relay_dbg[6], (unsigned long long)steps);
+        atomicAdd(&relay_dbg[7], (unsigned long long)n_refresh);
+        atomicAdd(&relay_dbg[8], (unsigned long long)n_spin);
     }
 #endif
     for (int off = 32; off > 0; off >>= 1) { m1 += __shfl_xor(m1, off, 64); m2 += __shfl_xor(m2, off, 64); }
@@ -294,6 +302,8 @@ __global__ void __launch_bounds__(128) clock_overlap_kernel(OverlapArgs a, int s
         atomicAdd(&a.stat[3], 1u);
         atomicAdd(&a.moments[0], (unsigned long long)((double)m1 * 1048576.0));
         atomicAdd(&a.moments[1], (unsigned long long)((double)m2 * 1048576.0));
+        T.c0 = cf32{T.p0.x > 0.f ? 1.f : 0.f, T.p0.y > 0.f ? 1.f : 0.f};
+        T.c1 = cf32{T.p1.x > 0.f ? 1.f : 0.f, T.p1.y > 0.f ? 1.f : 0.f};
         seg->end = T;
         seg->count = n_st < stride ? n_st : stride;
         seg->flags = (stuck ? OV_STUCK : 0) | (exhausted && !stuck ? OV_EXHAUSTED : 0) | (n_st > stride ? OV_STUCK : 0);

@@ -17,7 +17,10 @@ struct FirStage {
     bool no_static_dec = false, no_static_mf = false;   // XRIT_NO_STATIC_DEC / XRIT_NO_STATIC_MF, read once in init (A/B runs)
     int prio = 0;        // 1: this launch's waves at a raised issue priority (fir_decim_kernel; set by the chain per front end)
     bool poly = false;   // polyphase kernel (lanes = phases) for decimation 16 / 32 / 64
-    static constexpr int POLY_PR = 16, POLY_NQ = 32;     // outputs per lane group, taps per phase (T <= 32 * D)
+#ifndef XRIT_POLY_PR
+#define XRIT_POLY_PR 16
+#endif
+    static constexpr int POLY_PR = XRIT_POLY_PR, POLY_NQ = 32;     // outputs per lane group, taps per phase (T <= 32 * D)
     size_t lds_bytes = 0;
     DevBuf g;        // RC x Wpad window taps (polyphase: D x POLY_NQ phase taps)
     DevBuf mfb;      // matrix-pipe experiment: the Toeplitz tap operand, one float per (step, lane)
