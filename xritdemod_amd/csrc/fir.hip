@@ -402,8 +402,11 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
 // addresses (no skew, no conflicts) -- and one LDS read feeds up to PR multiply-adds (the phase's own little FIR
 // slides over the outputs).  The DP partial sums of an output are then added across the lanes with DPP row
 // rotations.  64 / DP groups per wave, PR outputs per group.
+#ifndef XRIT_POLY_THREADS
+#define XRIT_POLY_THREADS 256
+#endif
 template <int DP, int PR, int NQ, int TYPE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(XRIT_POLY_THREADS)
 fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                 const float *__restrict__ hq /* [DP][NQ] */, int T, long long n_out, long long n_in, int tile_len,
                 float2 *__restrict__ hist_new)
@@ -431,7 +434,7 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
         float4 *tile4 = reinterpret_cast<float4 *>(tile);
         const int pairs = tile_len >> 1;
         // the whole window in one batch of loads per thread (256 threads): one memory latency per block
-        constexpr int UF = (((NQ + (256 / DP) * PR - 1) * DP + 2) / 2 + 255) / 256;
+        constexpr int UF = (((NQ + (XRIT_POLY_THREADS / DP) * PR - 1) * DP + 2) / 2 + XRIT_POLY_THREADS - 1) / XRIT_POLY_THREADS;
 #ifndef XRIT_NO_LDS_DIRECT
         // (loads that write LDS themselves, as in fir_decim_kernel)
         for (int p = tid; p - (tid & 63) < pairs; p += nthr)
@@ -493,6 +496,64 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
     float2 acc[PR];
 #pragma unroll
     for (int c = 0; c < PR; ++c) acc[c] = make_float2(accv[c].x, accv[c].y);
+    if (PR == 16) {
+        // Add the DP phases of every output -- as a butterfly (round 5, late): every lane holds 16 partial sums and only ONE
+        // lane has to end up with each output's total, so a step adds the partner lane's sums of the outputs THIS lane keeps
+        // (lane ^ 8: outputs 0..7 or 8..15 by the lane's bit 3; then lane ^ 4, ^ 2, ^ 1), and lane c of a row ends with the
+        // row's sum of output c: 8 + 4 + 2 + 1 adds (+ as many selects) per component instead of 4 x 16, and the lane that
+        // stores an output holds it -- no chain of 15 selects in front of the store.  A tenth of the kernel's instructions.
+        // The same pairs are added as by the rotations below (lane l with l + 8, the pair sums with those 4 away, ...: sums
+        // of the same two words commute), so the outputs are the same words.
+        const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+        float2 m8[8], m4[4], m2[2];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float2 lo = acc[c], hi = acc[c + 8];
+            const float xr = lo.x + agc_dpp<0x128>(0.f, lo.x), xi = lo.y + agc_dpp<0x128>(0.f, lo.y);       // row_ror:8 = lane ^ 8
+            const float yr = hi.x + agc_dpp<0x128>(0.f, hi.x), yi = hi.y + agc_dpp<0x128>(0.f, hi.y);
+            m8[c] = b3 ? make_float2(yr, yi) : make_float2(xr, xi);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // lanes with bit 2 clear keep outputs c (partner 4 lanes up: row_ror:12), the others c + 4 (4 lanes down: row_ror:4)
+            const float2 lo = m8[c], hi = m8[c + 4];
+            const float xr = lo.x + agc_dpp<0x12C>(0.f, lo.x), xi = lo.y + agc_dpp<0x12C>(0.f, lo.y);
+            const float yr = hi.x + agc_dpp<0x124>(0.f, hi.x), yi = hi.y + agc_dpp<0x124>(0.f, hi.y);
+            m4[c] = b2 ? make_float2(yr, yi) : make_float2(xr, xi);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float2 lo = m4[c], hi = m4[c + 2];
+            const float xr = lo.x + agc_dpp<0x4E>(0.f, lo.x), xi = lo.y + agc_dpp<0x4E>(0.f, lo.y);         // quad_perm [2,3,0,1] = lane ^ 2
+            const float yr = hi.x + agc_dpp<0x4E>(0.f, hi.x), yi = hi.y + agc_dpp<0x4E>(0.f, hi.y);
+            m2[c] = b1 ? make_float2(yr, yi) : make_float2(xr, xi);
+        }
+        float sr, si;
+        {
+            const float2 lo = m2[0], hi = m2[1];
+            const float xr = lo.x + agc_dpp<0xB1>(0.f, lo.x), xi = lo.y + agc_dpp<0xB1>(0.f, lo.y);         // quad_perm [1,0,3,2] = lane ^ 1
+            const float yr = hi.x + agc_dpp<0xB1>(0.f, hi.x), yi = hi.y + agc_dpp<0xB1>(0.f, hi.y);
+            sr = b0 ? yr : xr;
+            si = b0 ? yi : xi;
+        }
+        // lane c of every row now holds the row's sum of output c; the rows of a group: rows 1 and 3 add the row below them,
+        // then (64 phases) rows 2 and 3 the sum two rows below -- the order of the row broadcasts below
+        if (DP >= 32) {
+            const float tr = __shfl_up(sr, 16, 64), ti = __shfl_up(si, 16, 64);
+            if (lane & 16) { sr += tr; si += ti; }
+        }
+        if (DP >= 64) {
+            const float tr = __shfl_up(sr, 32, 64), ti = __shfl_up(si, 32, 64);
+            if (lane & 32) { sr += tr; si += ti; }
+        }
+        // the LAST row of 16 lanes of every group holds the group's sums: its lane c stores output c
+        const int pl = p - (DP - 16);
+        if (pl >= 0) {
+            const long long m = out_base + (long long)grp * PR + pl;
+            if (m < n_out) out[m] = make_float2(sr, si);
+        }
+        return;
+    }
     // add the DP phases of every output: rotations inside the rows of 16 lanes, then across rows
 #pragma unroll
     for (int c = 0; c < PR; ++c) {
@@ -540,7 +601,7 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     // large decimations whose phases map onto lanes take the polyphase kernel
     poly = (D == 16 || D == 32 || D == 64) && (T + D - 1) / D <= POLY_NQ;
     if (poly) {
-        threads = 256;
+        threads = XRIT_POLY_THREADS;
         RC = 1;
         pad = false;
         const int OB = (threads / D) * POLY_PR;
