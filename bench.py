@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode, fast-mode and quick-mode legs (cfg.clock_exact = 1, -2, -3)")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
+    ap.add_argument("--front-exact", type=int, default=0, choices=[0, 1, 2],
+                    help="cfg.front_exact of the measured handle (opt-in parity mode: 1 = tight Costas stop rule, 2 = and the AGC walked "
+                         "literally); the default, 0, is the configuration `value` is quoted on")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
                     help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
                          "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")
@@ -232,7 +235,7 @@ def main():
                 host_segs.append(bursts[b_, o_:o_ + n_t].cpu().numpy().view(np.complex64).reshape(-1))
 
     cfg = xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
-                                clock_chain_syms=args.clock_chain)
+                                clock_chain_syms=args.clock_chain, front_exact=args.front_exact)
     dem = xa.Demodulator(cfg)
     sps = dem.sps
     cap = int(n_burst / (D * sps * 0.99)) + 64
@@ -444,6 +447,7 @@ def main():
                                   mode.upper(), ("decimating LPF %d taps d=%d -> " % (dem.decimator_ntaps, D)) if D > 1 else "",
                                   alpha, n_burst >> 20),
                    "samples_per_step_per_gpu": n_burst, "decimation": D, "input_rate_sps": fs_in, "sps": round(float(sps), 6),
+                   "front_exact": int(args.front_exact),
                    "segments": world, "bursts_reused": bool(W + K > nbuf),
                    "clock_recovery": ("cfg.clock_exact = 0 (default): %d overlapping exactly walked blocks, every walker started from the timing guess one history in front of its range (csrc/clock_overlap.h)" % int(st.clock_relay_segments))
                                      if int(st.clock_relay_passes) == 1 and int(st.clock_passes) == 0 else

@@ -140,7 +140,17 @@ typedef struct xrit_demod_config {
                                  *      there for their end states): 1.92 ms per streamed burst, 1.15e-4 rms from the serial
                                  *      trajectory.  Faster AND closer than -2. */
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
-    int32_t  reserved[3];
+    int32_t  front_exact;       /* opt-in parity mode (round 5; 0 = off).  What the soft symbols' distance from the CPU chain is made
+                                 * of is the front end's distance at the Costas loop's output (1.1e-6 rms as shipped; ANY distance
+                                 * costs a float32 M&M 5.5e-5 on LRIT), and most of that is what the
+                                 * hand-offs between the loop's 256-sample chains leave: a chain's start a few 1e-6 rad beside its
+                                 * predecessor's end (the float32 floor of the Newton solve; more passes do not remove it), which
+                                 * the loop forgets at a half per ~600 samples.
+                                 *   1: the Costas loop's final pass starts every chain FOUR chains early and walks those samples
+                                 *      quietly -- the stage's distance from the serial loop 1.16e-6 -> 6.1e-7, the soft symbols on
+                                 *      steady-state 256 Mi-sample LRIT bursts 9.8e-5 -> 8.4e-5 rms (five bursts; HRIT 1.33e-4 ->
+                                 *      1.20e-4: still a miss), for 12 % of a burst's time (profiles/r5_costas_variants_parity.json). */
+    int32_t  reserved[2];
 } xrit_demod_config;
 
 /* setLRITMode / setHRITMode + Parameters.h defaults (demodulator.cpp:177-197) */

@@ -1022,6 +1022,52 @@ def test_big_calls_walk_overlapping_blocks(xa, oracle_mod):
     assert [s_.costas_passes for s_ in st] == [s_.costas_passes for s_ in st2]
 
 
+def test_front_exact_warms_the_final_costas_pass_up(xa, oracle_mod):
+    """cfg.front_exact = 1 (round 5, opt-in): the Costas loop's final pass starts every chain four chains early and walks those
+    samples quietly, so that what the hand-offs left the chain starts beside their predecessors' ends is forgotten before a chain's
+    own samples begin.  The stage comes closer to the serial loop (the oracle's) on a tracking call, nothing else changes: symbol
+    count, hard decisions, one pass over the samples; streamed (inputs registered ahead) the words are those of plain calls; the
+    default configuration does not take the warm-up (its output is what it was)."""
+    n, fs, nb = 1 << 23, 1.25e6, 3
+    buf = _device_bursts(dict(fs_in=fs), n, nb)
+    cap = int(n / 4.2) + 4096
+    cfg = lambda **k: xa.Demodulator.config("lrit", fs, 1, **k)      # noqa: E731
+    ref = oracle_mod.Demod(oracle_mod.config("lrit", fs, 1))
+    want, want_c = [], []
+    for b in range(nb):
+        want.append(ref.process(buf[b].cpu().numpy().view(np.complex64).reshape(-1)))
+        want_c.append(ref.stage("costas").copy())
+    dist = {}
+    for fe in (0, 1):
+        dem = xa.Demodulator(cfg(front_exact=fe, clock_exact=1))
+        dem.keep_stages(True)
+        d = []
+        for b in range(nb):
+            got = dem.process(buf[b].cpu().numpy().view(np.complex64).reshape(-1))
+            assert len(got) == len(want[b])
+            big = np.abs(want[b]) > 1e-3
+            assert np.array_equal(np.sign(got[big]), np.sign(want[b][big])), (fe, b)
+            d.append(rms(dem.stage("costas") - want_c[b]))
+            if b:
+                assert dem.stats().costas_passes <= 2, (fe, b, dem.stats().costas_passes)
+        dist[fe] = d
+    report_parity("Costas stage against the oracle, tracking calls, default / front_exact", default=dist[0][-1], front_exact=dist[1][-1])
+    for b in range(1, nb):
+        assert dist[1][b] < 0.8 * dist[0][b], (b, dist)
+        assert dist[1][b] <= 1.0e-6, (b, dist)
+    plain, st = _run_plan(xa, cfg(front_exact=1), buf, [("go", b) for b in range(nb)], cap)
+    ahead, _ = _run_plan(xa, cfg(front_exact=1), buf, [("pf", 0), ("pf", 1), ("pf", 2), ("go", 0), ("go", 1), ("go", 2)], cap)
+    base, _ = _run_plan(xa, cfg(), buf, [("go", b) for b in range(nb)], cap)
+    for b in range(nb):
+        assert np.array_equal(plain[b].view(np.uint32), ahead[b].view(np.uint32)), b
+        assert len(plain[b]) == len(base[b]) == len(want[b]), b
+        r = rms(plain[b] - want[b])
+        assert r <= 1.5e-4, (b, r)
+    assert not np.array_equal(plain[1].view(np.uint32), base[1].view(np.uint32))       # (the mode does something)
+    with pytest.raises(xa.XritError):
+        xa.Demodulator(cfg(front_exact=2))
+
+
 def test_overlapping_blocks_fall_back_to_closure_at_low_snr(xa):
     """The default configuration walks a call whose soft symbols show Es/N0 below 7 dB to closure: a call that began as
     overlapping blocks is then relayed (csrc/clock_relay.h) until it IS the serial trajectory -- also when the bursts were started

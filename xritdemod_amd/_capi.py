@@ -27,7 +27,7 @@ class DemodConfig(C.Structure):
                 ("device", C.c_int32), ("costas_chain_len", C.c_int32), ("clock_chain_syms", C.c_int32),
                 ("max_passes", C.c_int32), ("strict", C.c_int32), ("clock_min_passes", C.c_int32),
                 ("slices", C.c_int32), ("clock_serial", C.c_int32), ("clock_exact", C.c_int32),
-                ("clock_exact_window", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("clock_exact_window", C.c_int32), ("front_exact", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class DemodStats(C.Structure):

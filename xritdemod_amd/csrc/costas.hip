@@ -313,8 +313,11 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
                                                          CostasGains g, double2 *__restrict__ om, long long om_off,
                                                          double inv_sps, float rot_c, float rot_s,
                                                          int *__restrict__ ctl, CostasPolicy pol,
-                                                         AffMap *__restrict__ aggs)
+                                                         AffMap *__restrict__ aggs, int warm)
 {
+    // (warm, cfg.front_exact: the FINAL pass starts every chain `warm` chains early, from the start state there, and walks those
+    // samples quietly -- what a hand-off leaves a chain's start beside its predecessor's end, a few 1e-6 rad, the loop forgets at
+    // a half per ~600 samples --; every other pass: 0)
     // the hand-off already closed (later passes of the batch are no-ops), or the gated solve has taken over
     if (!FINAL && (ctl[0] || (aggs != nullptr && ctl[NEWTON_CTL_TAKEOVER]))) return;
     // Two tiles of COSTAS_CT samples per chain at a time (round 4): the pair's samples sit in two LDS areas, a lane walks its
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     float phase = 0.f, freq = 0.f;
     if (mine) {
         cnt = (int)min((long long)L, n - base);
-        float2 s = S[k];
+        float2 s = S[FINAL ? (k > warm ? k - warm : 0) : k];
         phase = costas_prewrap(s.x);
         freq = s.y;
     }
@@ -371,6 +374,7 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
             const int c = min(it * RPI + lrow, K - 1 - kbase);
             long long j = (long long)(kbase + c) * L + (long long)tile * COSTAS_CT + lcol;
             j = j < last_pair ? j : last_pair;
+            j = j < 0 ? 0 : j;                  // (warm-up tiles in front of the call's first sample: never walked)
             pre[h][it] = *reinterpret_cast<const float4 *>(z + j);
         }
     };
@@ -385,6 +389,20 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
     // one tile of this lane's chain from area h
     auto walk = [&](int tile, int h) {
         const int i0 = tile * COSTAS_CT;
+        if (FINAL && tile < 0) {
+            // warm-up (wave-uniform): no output, no statistic; a chain that would start in front of the call's first sample
+            // (the first `warm` chains) waits for it with the call's start state
+            const bool act = mine && (long long)k * L + i0 >= 0;
+#pragma unroll
+            for (int i = 0; i < COSTAS_CT; ++i) {
+                float yr, yi;
+                const float2 v = tin[h][lane][i];
+                float ph = phase, fr = freq;
+                costas_step<false>(v.x, v.y, ph, fr, g, yr, yi, t);
+                if (act) { phase = ph; freq = fr; }
+            }
+            return;
+        }
         if (__all(!mine || i0 + COSTAS_CT <= cnt)) {
             // every chain of the wave has the whole tile: no per-sample guard (idle lanes compute on zeros)
 #pragma unroll
@@ -437,18 +455,19 @@ __global__ void __launch_bounds__(64) costas_pass_kernel(const float2 *__restric
             __syncthreads();
         }
     } else {
-    fetch(0, 0);
-    if (nt > 1) fetch(1, 1);
+    const int tb = -warm * nt;                 // (warm > 0 only with an even number of tiles per chain: no pair straddles tile 0)
+    fetch(tb, 0);
+    if (tb + 1 < nt) fetch(tb + 1, 1);
     stash(0, 0);
-    if (nt > 1) stash(1, 1);
+    if (tb + 1 < nt) stash(1, 1);
     __syncthreads();
-    for (int tile = 0; tile < nt; tile += 2) {
+    for (int tile = tb; tile < nt; tile += 2) {
         const bool two = tile + 1 < nt;
         if (tile + 2 < nt) fetch(tile + 2, 0);
         if (tile + 3 < nt) fetch(tile + 3, 1);
         walk(tile, 0);
         if (two) walk(tile + 1, 1);
-        if (FINAL) {
+        if (FINAL && tile >= 0) {
             // 16 samples per chain = one full 128-byte line, 8 lanes per row (the pair's first tile in area 0, its second in area 1)
             __syncthreads();
             const int ncol = two ? 2 * COSTAS_CT : COSTAS_CT;
@@ -613,6 +632,7 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     // (scripts/r4_floor_vs_frontend.py: the hand-off's stop rule tightened or loosened by a factor)
     if (const char *e = getenv("XRIT_COSTAS_MODEL")) { model_step = atoi(e) != 0; }      // A/B: 0 = block-average guesses only
     if (const char *e = getenv("XRIT_COSTAS_MODEL_ACCEPT")) { model_accept = (float)atof(e); }
+    if (const char *e = getenv("XRIT_COSTAS_FINAL_WARM")) { const int v = atoi(e); if (v >= 0 && v <= 16) final_warm = v; }
     if (const char *e = getenv("XRIT_COSTAS_TOL")) { const float k = (float)atof(e); if (k > 0) { tol_phase *= k; tol_freq *= k; } }
 #endif
     trace_env = getenv("XRIT_TRACE") != nullptr;
@@ -739,7 +759,7 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
             ProfScope ps(prof, "costas_pass", s);
             hipLaunchKernelGGL(costas_pass_kernel<false>, dim3(gridK), dim3(64), 0, s, job.in, job.out, S.as<float2>(),
                                E.as<float2>(), J.as<float4>(), flags.as<int>(), (float2 *)nullptr, (long long)job.n, L,
-                               job.K, gains, (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f, costas_ctl(counters), pol, aggs);
+                               job.K, gains, (double2 *)nullptr, 0LL, 0.0, 1.f, 0.f, costas_ctl(counters), pol, aggs, 0);
         }
         {
             ProfScope ps(prof, "costas_solve", s);
@@ -762,7 +782,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
     hipLaunchKernelGGL(costas_pass_kernel<true>, dim3(div_up((size_t)job.K, 64)), dim3(64), 0, s, job.in, job.out,
                        S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), st_out, (long long)job.n, L,
                        job.K, gains, job.om, job.om_off, job.inv_sps, (float)cos(dth), (float)sin(dth),
-                       costas_ctl(counters), CostasPolicy{}, (AffMap *)nullptr);
+                       costas_ctl(counters), CostasPolicy{}, (AffMap *)nullptr, (L / COSTAS_CT) % 2 == 0 ? final_warm : 0);
     if (job.K > 1) {
         CostasPolicy pol{S.as<float2>(), E.as<float2>(), J.as<float4>(), flags.as<int>(), nullptr, trust, trust / 256.0f,
                          tol_phase, tol_freq, 2.0f * tol_phase, 0.02f * trust, costas_ctl(counters) + 7, 0, job.model_accept};

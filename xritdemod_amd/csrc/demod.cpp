@@ -221,6 +221,10 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         set_error("AGC rate, reference and initial gain must be positive (Parameters.h:34-37: 0.01, 0.5, 1, 4000)");
         return XRIT_E_INVALID;
     }
+    if (cfg->front_exact < 0 || cfg->front_exact > 1) {
+        set_error("front_exact = %d: 0 (off) or 1", cfg->front_exact);
+        return XRIT_E_INVALID;
+    }
     if (!(cfg->sample_rate / (float)cfg->decimation / (float)cfg->symbol_rate >= 1.0f)) {
         set_error("fewer than one sample per symbol after decimation");
         return XRIT_E_INVALID;
@@ -258,6 +262,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
         if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
+        // (cfg.front_exact, the opt-in parity mode: the final pass starts every chain four chains early)
+        if (cfg->front_exact >= 1) d->costas.final_warm = 4;
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;

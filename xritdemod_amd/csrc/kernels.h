@@ -115,6 +115,7 @@ struct CostasStage {
     bool model_step = true;
     float model_accept = 5e-3f;
     bool force_gated = false;         // always the three-launch solve with the trust gate (XRIT_GATED_SOLVE=1)
+    int final_warm = 0;             // chains of warm-up in front of every chain of the final pass (cfg.front_exact: 4; costas.hip)
     bool keep_spare = false, trace_env = false, no_serial_walk = false;   // XRIT_KEEP_SPARE, XRIT_TRACE, XRIT_NO_SERIAL_WALK (read in init)
     // a hand-off still open after rescue_after passes is walked serially between its first and last open boundary
     // (costas_serial_states_kernel), if that is at most rescue_max_samples samples
