@@ -58,9 +58,8 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
-    hipStream_t stream_c = nullptr;                                 // ... and, for bursts whose Costas loop is a handful of small kernels
-                                                                    // (few circuit-rate samples: large decimations), that loop: its launches
-                                                                    // then run beside the next burst's decimator instead of behind it
+    // bursts whose Costas loop is a handful of small kernels (few circuit-rate samples: large decimations) run that loop on the
+    // walker stream their own walkers will take, beside the next burst's decimator instead of behind it (ov_service)
     size_t costas_own_stream_below = 16u << 20;                     // circuit-rate samples per burst (XRIT_OV_CSTREAM_BELOW)
 #ifndef XRIT_WALK_STREAMS
 #define XRIT_WALK_STREAMS 2
@@ -82,7 +81,8 @@ struct xrit_demod {
         bool costas_finished = false;   // the host has looked at the loop's stop test (and continued it where it had not closed)
         int ov_job = -1;                // the clock stage's job of this input
         bool walk_launched = false;     // its walkers have been enqueued (stream3)
-        int costas_stream = 0;          // 1: its Costas loop runs on stream_c
+        int costas_stream = 0;          // 1: its Costas loop runs on the walker stream its own walkers will take (c_stream)
+        hipStream_t c_stream = nullptr; // the stream its Costas loop was enqueued on
         bool agc_fallback = false;      // what the AGC's guard and the Costas loop reported for this input
         int c_passes = 0; unsigned c_unconverged = 0; float c_max_residual = 0; bool c_walked = false;
         bool launched = true;   // false: registered only -- a handle whose clock recovery is relayed (cfg.clock_exact >= 1)
@@ -193,9 +193,32 @@ void xrit_demod_config_hrit(xrit_demod_config *c, float sample_rate, uint32_t de
     c->rrc_alpha = 0.3f;       // HRIT_RRC_ALPHA
 }
 
+// A stream with a hardware queue of its own.  HIP deals ordinary streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4) by
+// its own count of what the process has created so far, and two streams of a handle that land in one queue serialise: the
+// walkers of two bursts behind one another, or a Costas loop behind a burst's walkers -- measured late in round 5: the second and
+// the fourth handle of a process ran their bursts in 2.5 ms instead of 1.8, and so did a handle created after others had been
+// destroyed.  A stream created with a CU mask gets a queue of its own; the mask here is every CU.  (Not a guarantee either: with
+// eight handles alive in one process -- 16 such queues beside HIP's pools -- the fourth and later ones were slow again, hardware
+// queue slots being what they are; the first three handles of a process run at the same speed, which HIP's own dealing did not
+// give the second one.  XRIT_SHARED_QUEUES=1: plain hipStreamCreate.)
+static hipError_t create_own_queue_stream(hipStream_t *s)
+{
+    if (getenv("XRIT_SHARED_QUEUES")) return hipStreamCreate(s);      // (A/B: HIP's own dealing)
+    uint32_t mask[32];
+    for (auto &m : mask) m = 0xffffffffu;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint32_t words = (uint32_t)((cus + 31) / 32);
+    if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
+    const hipError_t e = hipExtStreamCreateWithCUMask(s, words <= 32 ? words : 32, mask);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    return hipStreamCreate(s);
+}
+
 static bool create_walker_streams(xrit_demod *d)
 {
-    for (auto &w : d->stream3) if (hipStreamCreate(&w) != hipSuccess) return false;
+    for (auto &w : d->stream3) if (create_own_queue_stream(&w) != hipSuccess) return false;
     return true;
 }
 
@@ -247,7 +270,6 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         if (hipStreamCreate(&d->stream) != hipSuccess ||
             hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
             !create_walker_streams(d) ||
-            hipStreamCreate(&d->stream_c) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
@@ -289,12 +311,10 @@ void xrit_demod_destroy(xrit_demod *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
-    if (d->stream_c) (void)hipStreamSynchronize(d->stream_c);
     for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
-    if (d->stream_c) { (void)hipStreamSynchronize(d->stream_c); (void)hipStreamDestroy(d->stream_c); }
     for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
@@ -316,12 +336,11 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
-    XR_HIP(hipStreamSynchronize(d->stream_c));
     for (auto w : d->stream3) XR_HIP(hipStreamSynchronize(w));      // ... and so do walkers
     if (d->costas.job.n && d->pf_count > 0) {
         // (a Costas loop begun ahead and never looked at: the stage's bookkeeping is brought to an end before its state is reset)
         for (int i = 0; i < d->pf_count; ++i)
-            if (d->pf[i].costas_begun && !d->pf[i].costas_finished) { bool redone = false; (void)d->costas.finish(d->pf[i].costas_stream ? d->stream_c : d->stream2, nullptr, &redone); }
+            if (d->pf[i].costas_begun && !d->pf[i].costas_finished) { bool redone = false; (void)d->costas.finish(d->pf[i].c_stream ? d->pf[i].c_stream : d->stream2, nullptr, &redone); }
     }
     d->pf_count = 0;
     d->last_fe_set = -1;
@@ -608,7 +627,7 @@ static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
             if (hipEventQuery(d->ev_costas) != hipSuccess) { costas_busy = true; continue; }
             if (f.length && d->agc.requested_flag() == 2.0f) f.agc_fallback = true;
             bool redone = false;
-            int rc = d->costas.finish(f.costas_stream ? d->stream_c : d->stream2, prof, &redone);
+            int rc = d->costas.finish(f.c_stream ? f.c_stream : d->stream2, prof, &redone);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
             f.c_passes = d->costas.passes; f.c_unconverged = d->costas.unconverged; f.c_max_residual = d->costas.max_residual;
             f.c_walked = d->costas.job.rescued && d->costas.walked;
@@ -631,8 +650,13 @@ static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
             // loop's passes and the next input's decimator fill the chip each and only slow one another)
             // (... unless the loop is a handful of small kernels -- C5: 2 M samples at the circuit rate, 0.3 ms of launches --, which
             // then overlap the next input's decimator: 1.1 -> 0.9 ms per C5 burst)
+            // (round 5, late: not a stream of its own but the walker stream this burst's OWN walkers will take -- the one the
+            // walkers of the burst two in front are on: the loop then runs behind them instead of beside them, and its walkers
+            // behind it.  That is what HIP's dealing of streams onto hardware queues had arranged by accident on the first handle
+            // of a process, and measured better than a queue of its own: C5 1.08 against 1.11-1.14 ms per burst)
             f.costas_stream = f.length < d->costas_own_stream_below ? 1 : 0;
-            hipStream_t sc = f.costas_stream ? d->stream_c : d->stream2;
+            hipStream_t sc = f.costas_stream ? d->stream3[(d->clock.ov_serial + 1) % XRIT_WALK_STREAMS] : d->stream2;
+            f.c_stream = sc;
             if (f.costas_stream) XR_HIP(hipStreamWaitEvent(sc, d->ev_fe[f.set], 0));
             int rc = costas_enqueue(d, io, sc, prof, &f.slot);
             if (rc != XRIT_OK) { d->poisoned = true; return rc; }
