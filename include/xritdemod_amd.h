@@ -144,7 +144,8 @@ typedef struct xrit_demod_config {
                                  * of is the front end's distance at the Costas loop's output (1.1e-6 rms as shipped; ANY distance
                                  * costs a float32 M&M 5.5e-5 on LRIT), and most of that is what the
                                  * hand-offs between the loop's 256-sample chains leave: a chain's start a few 1e-6 rad beside its
-                                 * predecessor's end (the float32 floor of the Newton solve; more passes do not remove it), which
+                                 * predecessor's end (a chain walked again from a start an ulp away rounds its 256 steps afresh: more passes do not
+                                 * remove it), which
                                  * the loop forgets at a half per ~600 samples.
                                  *   1: the Costas loop's final pass starts every chain FOUR chains early and walks those samples
                                  *      quietly -- the stage's distance from the serial loop 1.16e-6 -> 6.1e-7, the soft symbols on
