@@ -1,5 +1,5 @@
 """Steady-state parity of the chain against the oracle for the Costas stage's late round-5 variants, on consecutive bursts of one
-stream (bursts 1.. of N; C2: 2^28 samples, C3: 2^26): the default, two chains of warm-up in the final pass (XRIT_COSTAS_FINAL_WARM,
+stream (bursts 1.. of N; C2, C5: 2^28 samples, C1, C3: 2^26): the default, two chains of warm-up in the final pass (XRIT_COSTAS_FINAL_WARM,
 library built with -DXRIT_EXPERIMENTS) and cfg.front_exact = 1 (four).
     python scripts/r5_costas_variants_parity.py [--bursts 6] [--out gpurun_out/r5_costas_variants_parity.json]"""
 import argparse, json, os, sys
@@ -20,7 +20,8 @@ def main():
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream(dev)
     rep = {"what": __doc__.split("\n    python")[0], "configs": {}}
-    for name, mode, fs_in, D, sym, alpha, log2 in (("C2", "lrit", 6.25e6, 5, 293883.0, 0.5, 28), ("C3", "hrit", 2.5e6, 1, 927000.0, 0.3, 26)):
+    for name, mode, fs_in, D, sym, alpha, log2 in (("C2", "lrit", 6.25e6, 5, 293883.0, 0.5, 28), ("C3", "hrit", 2.5e6, 1, 927000.0, 0.3, 26),
+                                                    ("C1", "lrit", 1.25e6, 1, 293883.0, 0.5, 26), ("C5", "lrit", 40e6, 32, 293883.0, 0.5, 28)):
         n = 1 << log2; n -= n % D
         sp = _capi.synth_params(fs_in=fs_in, symbol_rate=sym, alpha=alpha)
         buf = torch.empty((n, 2), dtype=torch.float32, device=dev)
