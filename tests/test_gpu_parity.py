@@ -1429,6 +1429,36 @@ def test_host_program_fifo_chunking_is_the_reference_rule(xa, oracle_mod, tmp_pa
     assert f"chunks of {512 * 1024} .. {512 * 1024} samples" in r.stderr and f"{3 * (9 * P - 512 * 1024)} samples lost to overflow" in r.stderr, r.stderr
 
 
+def test_host_program_front_exact_switch(xa, oracle_mod, tmp_path):
+    """--front-exact (cfg.front_exact = 1) through the host program: the same number of symbols, int8 values within one step of
+    the oracle's, and not the default's bytes (the mode is on)."""
+    import subprocess
+    host_bin = os.path.join(ROOT, "xritdemod_amd", "bin", "xrit_demod_host")
+    fs, D = 6.25e6, 5
+    n = 6000000
+    x = synth_signal(n, fs_in=fs)
+    f = tmp_path / "capture.cf32"
+    x.tofile(f)
+    outs = {}
+    for tag, extra in (("default", []), ("front_exact", ["--front-exact"])):
+        out = tmp_path / f"sym_{tag}.s8"
+        r = subprocess.run([host_bin, "--input", str(f), "--sample-rate", str(fs), "--decimation", str(D), "--block", "2000000",
+                            "--sink", f"file:{out}"] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = np.fromfile(out, np.int8)
+    od = oracle_mod.Demod(oracle_mod.config("lrit", fs, D))
+    want = oracle_mod.quantize_i8(np.concatenate([od.process(x[i:i + 2000000]) for i in range(0, n, 2000000)]))
+    for tag, g in outs.items():
+        assert len(g) == len(want), tag
+        d = np.abs(g.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and np.mean(d == 0) > 0.99, tag
+    soft = {}
+    for fe in (0, 1):      # (the int8 steps hide a difference of 1e-6: the float symbols of the two modes must differ)
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, front_exact=fe))
+        soft[fe] = np.concatenate([dem.process(x[i:i + 2000000]) for i in range(0, n, 2000000)])
+    assert len(soft[0]) == len(soft[1]) == len(want) and not np.array_equal(soft[0], soft[1])
+
+
 def test_host_program_symbol_manager_loss_semantics(xa, oracle_mod, tmp_path):
     """--drop: SymbolManager's queue between the DSP thread and the sender thread, with the reference's two ways of
     losing symbols (SymbolManager.cpp:78-83: everything queued is dropped while no decoder is connected; :97-101: a
