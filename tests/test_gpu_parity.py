@@ -1102,6 +1102,29 @@ def test_front_exact_warms_the_final_costas_pass_up(xa, oracle_mod):
         xa.Demodulator(cfg(front_exact=2))
 
 
+@pytest.mark.parametrize("mode,fs,D,kw", [("lrit", 6.25e6, 5, dict(fs_in=6.25e6)), ("hrit", 2.5e6, 1, dict(fs_in=2.5e6, symbol_rate=927000.0, alpha=0.3))])
+def test_front_exact_on_ragged_calls(xa, oracle_mod, mode, fs, D, kw):
+    """cfg.front_exact = 1 on calls of every size: empty, shorter than a tile, shorter than the four chains of warm-up (the first
+    chains then wait at the call's first sample with its start state), a chain more or less, the reference's chunk sizes, a big
+    one.  Symbol count per call and hard decisions are the oracle's, the soft symbols in the family of the default's."""
+    sizes = [100, 1000, D * 255, D * 256, D * 257, 5000, 70000, 3, 0, 262144, D * 1024, D * 1023, 524288, 40000, 2000000, 7, 1300000]
+    x = synth_signal(sum(sizes), **kw)
+    ref = oracle_mod.Demod(oracle_mod.config(mode, fs, D))
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=1))
+    pos, got, want = 0, [], []
+    for n in sizes:
+        seg = x[pos:pos + n]
+        pos += n
+        w, g = ref.process(seg), dem.process(seg)
+        assert len(g) == len(w), (n, len(g), len(w))
+        got.append(g)
+        want.append(w)
+    g, w = np.concatenate(got), np.concatenate(want)
+    big = np.abs(w) > 1e-3
+    assert np.array_equal(np.sign(g[big]), np.sign(w[big]))
+    assert rms(g - w) <= 1.5e-4, rms(g - w)
+
+
 def test_overlapping_blocks_fall_back_to_closure_at_low_snr(xa):
     """The default configuration walks a call whose soft symbols show Es/N0 below 7 dB to closure: a call that began as
     overlapping blocks is then relayed (csrc/clock_relay.h) until it IS the serial trajectory -- also when the bursts were started
