@@ -150,7 +150,7 @@ typedef struct xrit_demod_config {
                                  *   1: the Costas loop's final pass starts every chain FOUR chains early and walks those samples
                                  *      quietly -- the stage's distance from the serial loop 1.16e-6 -> 6.1e-7, the soft symbols on
                                  *      steady-state 256 Mi-sample LRIT bursts 9.8e-5 -> 8.4e-5 rms (five bursts; HRIT 1.33e-4 ->
-                                 *      1.20e-4: still a miss), for 12 % of such a burst's time (3 % at decimation 32; 20-30 % without a decimator, where the
+                                 *      1.20e-4: still a miss), for 12 % of such a burst's time (3-5 % at decimation 32; 20-30 % without a decimator, where the
                                  *      circuit-rate stream is the whole burst: profiles/r5_costas_variants_parity.json, r5_bench_c*.json). */
     int32_t  reserved[2];
 } xrit_demod_config;
