@@ -1,5 +1,5 @@
 """Streamed (xrit_demod_prefetch_device) against plain calls on one stream cut in calls of random sizes: the symbols must be the same words.
-python scripts/random_prefetch.py [calls] [seed]"""
+python scripts/random_prefetch.py [calls] [seed]      (FRONT_EXACT=1: cfg.front_exact = 1)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +22,7 @@ offs = np.concatenate([[0], np.cumsum(sizes)])
 cap = max(sizes) // (D * 4) + 4096
 soft = torch.empty((cap,), dtype=torch.float32, device=dev)
 def run(prefetch):
-    dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, front_exact=int(os.environ.get("FRONT_EXACT", "0"))))
     out, stats = [], []
     reg = 0          # inputs registered so far: as many ahead as the library takes (round 5: up to two behind the call in progress)
     def feed(c):
