@@ -89,6 +89,7 @@ def lib():
         L.xo_agc_work.argtypes = [C.POINTER(Agc), vp, vp, C.c_int]
         L.xo_costas_init.argtypes = [C.POINTER(Costas), C.c_float]
         L.xo_costas_work.argtypes = [C.POINTER(Costas), vp, vp, C.c_int]
+        L.xo_sincosf.argtypes = [C.c_float, fp, fp]
         L.xo_mm_create.restype = vp
         L.xo_mm_create.argtypes = [C.c_float] * 5
         L.xo_mm_destroy.argtypes = [vp]
@@ -222,6 +223,20 @@ class CostasLoop:
         out = np.zeros(len(x), np.complex64)
         lib().xo_costas_work(C.byref(self.s), _p(x), _p(out), len(x))
         return out
+
+
+def sincosf(x):
+    """xo_sincosf (glibc 2.35's __sincosf_fma restated) on an array of float32: (sin, cos)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    sv, cv = C.c_float(), C.c_float()
+    f = lib().xo_sincosf
+    for i, v in enumerate(x.tolist()):
+        f(v, C.byref(sv), C.byref(cv))
+        s[i] = sv.value
+        c[i] = cv.value
+    return s, c
 
 
 class RtlIngest:

@@ -13,6 +13,7 @@
 #include "xrit_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -318,6 +319,65 @@ void xo_costas_init(xo_costas *c, float loop_bw)
     c->imag_axis = g_knobs.costas_imag_axis;
 }
 
+/* sin and cos of the loop phase.  The upstream block calls the C library's sincosf (gr::sincosf -> ::sincosf); on this
+ * image that is glibc 2.35's __sincosf_fma (sysdeps/ieee754/flt-32/s_sincosf.c with the x86 two-lane polynomial of
+ * sysdeps/x86/fpu/sincosf_poly.h, selected by ifunc on every CPU with FMA): range reduction and two polynomials in
+ * double precision with fused multiply-adds, rounded to float once.  It is restated here operation for operation so that
+ * (a) the oracle's bits do not depend on which variant the host's ifunc picks, and (b) the device can evaluate the very
+ * same double-precision operations (csrc/exact_sincos.h).  tests/test_oracle_kat.py::test_sincosf_restatement checks
+ * it against the C library on a sample; oracle/check_sincosf.c does so for EVERY float with |x| < 120 (2 246 049 792
+ * arguments, 0 differences on this image).  |x| >= 120 (never a loop phase: those are wrapped to +-2 pi) defers to libm. */
+static const double XO_SC_HPI_INV = 0x1.45F306DC9C883p+23;   /* 2/pi * 2^24 */
+static const double XO_SC_HPI = 0x1.921FB54442D18p0;         /* pi/2 */
+static const double XO_SC_C[5] = {0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10,
+                                  0x1.99343027bf8c3p-16};
+static const double XO_SC_S[3] = {-0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+
+static inline void xo_sincosf_poly(double x, double x2, int negc, int n, float *sinp, float *cosp)
+{
+    /* quadrants 2 and 3 (n & 2): the cosine polynomial negated, the sine's sign folded into x by the caller */
+    const double c0 = negc ? -XO_SC_C[0] : XO_SC_C[0], c1 = negc ? -XO_SC_C[1] : XO_SC_C[1];
+    const double c2 = negc ? -XO_SC_C[2] : XO_SC_C[2], c3 = negc ? -XO_SC_C[3] : XO_SC_C[3];
+    const double c4 = negc ? -XO_SC_C[4] : XO_SC_C[4];
+    const double x3 = x2 * x, x4 = x2 * x2;
+    const double s1 = __builtin_fma(x2, XO_SC_S[2], XO_SC_S[1]);
+    const double cc2 = __builtin_fma(x2, c4, c3);
+    const double cc1 = __builtin_fma(x2, c1, c0);
+    const double x5 = x3 * x2, x6 = x4 * x2;
+    const double s = __builtin_fma(x3, XO_SC_S[0], x);
+    const double c = __builtin_fma(x4, c2, cc1);
+    const float sv = (float)__builtin_fma(x5, s1, s);
+    const float cv = (float)__builtin_fma(x6, cc2, c);
+    if (n & 1) { *sinp = cv; *cosp = sv; }
+    else { *sinp = sv; *cosp = cv; }
+}
+
+void xo_sincosf(float y, float *sinp, float *cosp)
+{
+    uint32_t u;
+    memcpy(&u, &y, 4);
+    const uint32_t top = (u >> 20) & 0x7ff;       /* abstop12 */
+    const double x = (double)y;
+    if (top < 0x3f4) {                            /* |y| < pi/4 */
+        if (top < 0x398) {                        /* |y| < 2^-12 */
+            *sinp = y;
+            *cosp = 1.0f;
+            return;
+        }
+        xo_sincosf_poly(x, x * x, 0, 0, sinp, cosp);
+        return;
+    }
+    if (top >= 0x42f) {                           /* |y| >= 120: not a loop phase */
+        sincosf(y, sinp, cosp);
+        return;
+    }
+    const double r = x * XO_SC_HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double xr = __builtin_fma(-(double)n, XO_SC_HPI, x);
+    const double sg = ((n + 1) & 2) ? -1.0 : 1.0; /* sign[n & 3] = {1, -1, -1, 1} */
+    xo_sincosf_poly(xr * sg, xr * xr, (n & 2) != 0, n, sinp, cosp);
+}
+
 static inline float xo_clip(float x, float clip)
 {
     /* branchless_clip: 0.5*(|x+clip| - |x-clip|) */
@@ -336,7 +396,7 @@ void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n)
     float phase = c->phase, freq = c->freq;
     for (int i = 0; i < n; i++) {
         float s, co;
-        sincosf(-phase, &s, &co);
+        xo_sincosf(-phase, &s, &co);
         float yr = in[i].re * co - in[i].im * s;
         float yi = in[i].re * s + in[i].im * co;
         out[i].re = yr;

@@ -94,6 +94,8 @@ void xo_agc_work(xo_agc *a, const xo_cf *in, xo_cf *out, int n);
 typedef struct { float phase, freq, alpha, beta, max_freq, min_freq; int wrap_pi, imag_axis; } xo_costas;
 void xo_costas_init(xo_costas *c, float loop_bw);
 void xo_costas_work(xo_costas *c, const xo_cf *in, xo_cf *out, int n);
+/* the loop's sincosf: glibc 2.35's __sincosf_fma restated operation for operation (xrit_oracle.c) */
+void xo_sincosf(float y, float *sinp, float *cosp);
 
 /* ---- ClockRecovery(omega, gainOmega, mu, gainMu, omegaRelativeLimit) ---- */
 typedef struct xo_mm xo_mm;

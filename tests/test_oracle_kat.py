@@ -638,3 +638,34 @@ def test_costas_sub_block_model_follows_the_loop(oracle_mod):
     r_model, r_avg = float(np.sqrt(np.mean(np.square(err_model)))), float(np.sqrt(np.mean(np.square(err_avg))))
     assert len(err_model) > 1000
     assert r_model <= 1e-3 and r_avg >= 10 * r_model, (r_model, r_avg)
+
+
+# ---------------------------------------------------------------- the loop's sincosf
+def test_sincosf_restatement_is_the_c_library(oracle_mod):
+    """xo_sincosf restates glibc 2.35's __sincosf_fma operation for operation (double-precision reduction and two
+    polynomials with fused multiply-adds, one rounding to float) so that the device can run the same operations
+    (csrc/exact_sincos.h).  Here: bit for bit the C library's sincosf on a sample of loop phases and on the branch
+    boundaries; oracle/check_sincosf.c does it for every float with |x| < 120 (0 differences on this image).  A host whose
+    ifunc picks another variant (no FMA) fails this test -- the oracle itself does not depend on it."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.uniform(-2 * np.pi - 1.5, 2 * np.pi + 1.5, 20000),
+        rng.uniform(-120, 120, 5000),
+        rng.normal(0, 1e-3, 2000),
+        np.array([0.0, -0.0, 2.0 ** -12, np.nextafter(np.float32(2.0 ** -12), np.float32(0)), np.pi / 4, 0.78539819, 0.7853981,
+                  np.pi / 2, np.pi, 2 * np.pi, 6.2831855, -6.2831855, 119.99999, 1e-30, 1e-40]),
+    ]).astype(np.float32)
+    s, c = oracle_mod.sincosf(x)
+    rs, rc = np.empty_like(x), np.empty_like(x)
+    sv, cv = C.c_float(), C.c_float()
+    for i, v in enumerate(x.tolist()):
+        libm.sincosf(v, C.byref(sv), C.byref(cv))
+        rs[i], rc[i] = sv.value, cv.value
+    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), rc.view(np.uint32))
+    # and it is a sincos: within 1 ulp of the double-precision value
+    assert np.max(np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64)))) < 1.2e-7
+    assert np.max(np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64)))) < 1.2e-7
