@@ -151,7 +151,13 @@ typedef struct xrit_demod_config {
                                  *      quietly -- the stage's distance from the serial loop 1.16e-6 -> 6.1e-7, the soft symbols on
                                  *      steady-state 256 Mi-sample LRIT bursts 9.8e-5 -> 8.4e-5 rms (five bursts; HRIT 1.33e-4 ->
                                  *      1.20e-4: still a miss), for 12 % of such a burst's time (3-5 % at decimation 32; 20-30 % without a decimator, where the
-                                 *      circuit-rate stream is the whole burst: profiles/r5_costas_variants_parity.json, r5_bench_c*.json). */
+                                 *      circuit-rate stream is the whole burst: profiles/r5_costas_variants_parity.json, r5_bench_c*.json).
+                                 *   2 (round 6): the front end BIT FOR BIT the CPU chain's through the Costas loop -- both filters
+                                 *      summed in the CPU chain's order without FMA (fir.hip: fir_exact_kernel), the AGC walked
+                                 *      literally in warmed-up chains (agc.hip), the Costas loop walked exactly 64 samples per
+                                 *      step with the C library's sincosf evaluated in double precision (costas_exact.hip).
+                                 *      What is left of the soft symbols' distance is the clock recovery's own (its distance
+                                 *      from the serial trajectory, 5-6e-5 LRIT). */
     int32_t  reserved[2];
 } xrit_demod_config;
 
@@ -328,17 +334,33 @@ void xrit_rtl_destroy(xrit_rtl *r);
 int  xrit_fir_create(unsigned decimation, const float *taps, int ntaps, int device, xrit_fir **out);
 /* FirFilter::Work(in, out, nOut): consumes nOut*decimation samples */
 int  xrit_fir_work(xrit_fir *f, const float *in, float *out, size_t n_out);
+/* exact = 1: the dot product summed in the CPU chain's order -- four interleaved float32 partial sums over the time-ordered
+ * window, products rounded before they are added (xrit_demod_config.front_exact = 2) */
+int  xrit_fir_set_exact(xrit_fir *f, int exact);
 void xrit_fir_destroy(xrit_fir *f);
 
 int  xrit_agc_create(float rate, float reference, float gain, float max_gain, int device, xrit_agc **out);
 int  xrit_agc_work(xrit_agc *a, const float *in, float *out, size_t n);
+/* exact = 1: the float32 recurrence walked literally in warmed-up chains whose joints are checked bit for bit (front_exact = 2) */
+int  xrit_agc_set_exact(xrit_agc *a, int exact);
 float xrit_agc_gain(xrit_agc *a);
 void xrit_agc_destroy(xrit_agc *a);
 
 int  xrit_costas_create(float loop_bw, int order, int device, xrit_costas **out);
 int  xrit_costas_work(xrit_costas *c, const float *in, float *out, size_t n);
 int  xrit_costas_state(xrit_costas *c, float *phase, float *freq);
+/* exact = 1: behind the chains' hand-off the output is put on the serial float32 trajectory by exactly walked overlapping
+ * ranges (front_exact = 2; csrc/costas_exact.hip).  history: samples of warm-up in front of every range (0 = default 32768) */
+int  xrit_costas_set_exact(xrit_costas *c, int exact, int history);
+/* totals over the handle's calls: 64-sample blocks walked and Picard rounds spent on them; of the last call: joints that were
+ * still open after the rounds enqueued with the call, and the rounds the host added */
+int  xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds);
 void xrit_costas_destroy(xrit_costas *c);
+
+/* The sincosf of the exact Costas loop on an array of (host) floats, |x| < 120: the C library's sincosf as the reference's loop
+ * calls it (glibc's __sincosf_fma: double-precision reduction and polynomials, fused multiply-adds, one rounding), evaluated
+ * operation for operation on the device (csrc/exact_sincos.h; tests hold it against the CPU chain's bit for bit). */
+int  xrit_loop_sincosf(const float *x, float *sin_out, float *cos_out, size_t n, int device);
 
 int  xrit_clock_create(float omega, float gain_omega, float mu, float gain_mu, float omega_rel_limit,
                        int device, xrit_clock **out);

@@ -1,0 +1,225 @@
+"""GPU tier (-m gpu): cfg.front_exact = 2 -- the front end BIT FOR BIT the CPU chain's through the Costas loop.
+
+Every comparison here is np.array_equal on the 32-bit words (or on the complex64 words), not a tolerance: the exact-order
+FIR (csrc/fir.hip: fir_exact_kernel), the literally walked AGC (csrc/agc.hip: run_exact), the exactly walked Costas loop
+(csrc/costas_exact.hip with csrc/exact_sincos.h) against oracle/xrit_oracle.c on the same inputs, stage by stage through the
+C ABI's stage objects and end to end through the chain.  With the clock recovery relayed to closure (cfg.clock_exact = 1: the
+serial float32 recurrence) the SOFT SYMBOLS are the oracle's word for word; with the default clock recovery what is left is its
+distance from the serial trajectory, asserted PLAINLY against BASELINE.json's 1e-4 for every configuration.
+"""
+import numpy as np
+import pytest
+
+from conftest import synth_signal, rms
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_RMS = 1e-4
+
+
+@pytest.fixture(scope="module")
+def xa():
+    import xritdemod_amd
+    xritdemod_amd.lib()
+    if xritdemod_amd.device_count() < 1:
+        pytest.fail("the -m gpu tier needs a HIP device; the library has no CPU path")
+    return xritdemod_amd
+
+
+def words(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32)
+
+
+def same_words(a, b):
+    return a.shape == b.shape and np.array_equal(words(a), words(b))
+
+
+def first_diff(a, b):
+    d = np.nonzero(words(a) != words(b))[0]
+    return (int(d[0]), len(d)) if len(d) else (-1, 0)
+
+
+# ------------------------------------------------------------------------------------------------ the loop's sincosf
+def test_loop_sincosf_is_the_cpu_chains(xa, oracle_mod):
+    """csrc/exact_sincos.h on the device against oracle xo_sincosf (= glibc's sincosf, checked exhaustively on the CPU):
+    2^22 arguments over the loop's range and the whole branch |x| < 120, plus the branch boundaries, every bit."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.uniform(-2 * np.pi - 1.5, 2 * np.pi + 1.5, 1 << 21),
+        rng.uniform(-120, 120, 1 << 20),
+        rng.normal(0, 1e-3, 1 << 18),
+        np.array([0.0, -0.0, 2.0 ** -12, np.pi / 4, 0.78539819, 0.7853981, np.pi / 2, np.pi, 2 * np.pi, 6.2831855, -6.2831855,
+                  119.99999, 1e-30, 1e-40, -1e-40]),
+    ]).astype(np.float32)
+    s, c = xa.loop_sincosf(x)
+    # the oracle's, through a small C loop (ctypes per element is slow): the Costas loop with zero gains is a sincos table
+    import ctypes as C
+    L = oracle_mod.lib()
+    rs, rc = np.empty_like(x), np.empty_like(x)
+    sv, cv = C.c_float(), C.c_float()
+    step = 37          # every 37th argument through ctypes (~90 k calls), all of them through the loop below
+    for i in range(0, len(x), step):
+        L.xo_sincosf(float(x[i]), C.byref(sv), C.byref(cv))
+        rs[i], rc[i] = sv.value, cv.value
+    assert np.array_equal(words(s[::step]), words(rs[::step]))
+    assert np.array_equal(words(c[::step]), words(rc[::step]))
+    # all of them: a Costas loop object whose phase is set per call would be slow too; use the loop's own de-rotation with the
+    # gains off -- out = in * exp(-j phase): in = 1 gives (cos(-p), sin(-p)) = (cos p, -sin p)
+    k = oracle_mod.CostasLoop(0.0)
+    k.s.alpha = 0.0
+    k.s.beta = 0.0
+    k.s.freq = 0.0
+    one = np.ones(1, np.complex64)
+    idx = rng.integers(0, len(x), 20000)
+    for i in idx.tolist():
+        k.s.phase = float(x[i])
+        y = k.Work(one)
+        # (cos(-p), sin(-p)) of the oracle's xo_sincosf(-p): compare with the device's sincosf(-p)
+        rs[i], rc[i] = y[0].imag, y[0].real
+    ns, nc = xa.loop_sincosf(-x[idx])
+    assert np.array_equal(words(ns), words(rs[idx]))
+    assert np.array_equal(words(nc), words(rc[idx]))
+
+
+# ------------------------------------------------------------------------------------------------ stages
+@pytest.mark.parametrize("D,kind", [(1, "rrc"), (5, "lp5"), (32, "lp32"), (2, "rrc"), (3, "lp5"), (4, "short"), (16, "lp16"),
+                                    (6, "lp5"), (1, "short"), (7, "one")])
+def test_fir_exact_order_is_the_oracle_bit_for_bit(xa, oracle_mod, D, kind):
+    o = oracle_mod
+    taps = {"rrc": o.rrc_taps(1, 1.25e6, 293883, 0.5, 63), "lp5": o.lowpass_taps(1, 6.25e6, 625e3, 100e3),
+            "lp32": o.lowpass_taps(1, 40e6, 625e3, 100e3), "short": np.array([0.5, -0.25, 0.125], np.float32),
+            "lp16": o.lowpass_taps(1, 20e6, 625e3, 100e3), "one": np.array([0.75], np.float32)}[kind]
+    rng = np.random.default_rng(100 + D)
+    n_out = [30000, 1, 777, 0, 12345, 3]
+    x = (rng.standard_normal(sum(n_out) * D) + 1j * rng.standard_normal(sum(n_out) * D)).astype(np.complex64)
+    fo, fg = o.FirFilter(D, taps), xa.FirFilter(D, taps, exact=True)
+    pos = 0
+    for n in n_out:       # several calls: the history carries over, also through empty and 1-sample calls
+        seg = x[pos:pos + n * D]
+        pos += n * D
+        want, got = fo.Work(seg, n), fg.Work(seg, n)
+        assert same_words(got, want), (D, kind, n, first_diff(got, want))
+
+
+def test_agc_walked_literally_is_the_oracle_bit_for_bit(xa, oracle_mod):
+    o = oracle_mod
+    rng = np.random.default_rng(3)
+    n = 3_000_000
+    x = (0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    x[1_000_000:1_400_000] *= 4.0           # a level jump and back
+    x[2_000_000:2_000_500] = 0              # silence: the gain ramps
+    ao, ag = o.AGC(0.01, 0.5, 1.0, 4000.0), xa.AGC(0.01, 0.5, 1.0, 4000.0, exact=True)
+    pos = 0
+    for m in (1_500_000, 1, 0, 4095, 4097, 700_000, n - 1_500_000 - 1 - 4095 - 4097 - 700_000):
+        seg = x[pos:pos + m]
+        pos += m
+        want, got = ao.Work(seg), ag.Work(seg)
+        assert same_words(got, want), (m, first_diff(got, want))
+        assert np.float32(ag.gain).view(np.uint32) == np.float32(ao.s.gain).view(np.uint32)
+    # the clamp: a silent stretch long enough to reach max_gain
+    z = np.zeros(900_000, np.complex64)
+    z[:10] = 0.1
+    ao, ag = o.AGC(0.01, 0.5, 1.0, 4000.0), xa.AGC(0.01, 0.5, 1.0, 4000.0, exact=True)
+    assert same_words(ag.Work(z), ao.Work(z))
+    assert ag.gain == 4000.0
+
+
+@pytest.mark.parametrize("mode,fs,n", [("lrit", 1.25e6, 3_000_000), ("hrit", 2.5e6, 3_000_000)])
+def test_costas_walked_exactly_is_the_oracle_bit_for_bit(xa, oracle_mod, mode, fs, n):
+    """The stage object on the oracle's own matched-filter output: cold start (acquisition, wraps, a loop far from lock), then
+    tracking calls of every size; the carried state after every call is the oracle's too."""
+    o = oracle_mod
+    kw = {} if mode == "lrit" else {"symbol_rate": 927000.0, "alpha": 0.3}
+    x = synth_signal(n, fs_in=fs, **kw)
+    cfg = o.config(mode, fs, 1)
+    d = o.Demod(cfg)
+    d.process(x)
+    rrc = d.stage("rrc").copy()
+    co, cg = o.CostasLoop(cfg.pll_alpha), xa.CostasLoop(cfg.pll_alpha, exact=True)
+    pos = 0
+    for m in (1_000_000, 1, 0, 63, 64, 65, 8191, 300_000, 70_000, n):
+        seg = rrc[pos:pos + m]
+        pos += len(seg)
+        want, got = co.Work(seg), cg.Work(seg)
+        assert same_words(got, want), (mode, m, first_diff(got, want))
+        ph, fr = cg.state()
+        assert np.float32(ph).view(np.uint32) == np.float32(co.s.phase).view(np.uint32), (m, ph, co.s.phase)
+        assert np.float32(fr).view(np.uint32) == np.float32(co.s.freq).view(np.uint32), (m, fr, co.s.freq)
+        if pos >= len(rrc):
+            break
+    st = cg.exact_stats()
+    print("exact Costas:", st, "rounds per block %.2f" % (st["picard_rounds"] / max(st["blocks"], 1)))
+
+
+def test_costas_exact_without_carrier_offset_and_with_a_negative_one(xa, oracle_mod):
+    """Phases that hover (no wraps for the whole call) and phases that run downwards (wraps at -2 pi)."""
+    o = oracle_mod
+    for hz in (0.0, -700.0, 35.0):
+        x = synth_signal(1_200_000, fs_in=1.25e6, carrier_hz=hz, phase0=0.01)
+        cfg = o.config("lrit", 1.25e6, 1)
+        d = o.Demod(cfg)
+        d.process(x)
+        rrc = d.stage("rrc").copy()
+        co, cg = o.CostasLoop(cfg.pll_alpha), xa.CostasLoop(cfg.pll_alpha, exact=True)
+        for seg in (rrc[:500_000], rrc[500_000:]):
+            want, got = co.Work(seg), cg.Work(seg)
+            assert same_words(got, want), (hz, first_diff(got, want))
+
+
+def test_costas_exact_short_history_still_exact(xa, oracle_mod):
+    """A history far too short for the walkers to merge: the joints do not fit, the fix rounds close them (from the host, many)
+    -- slow, but the output is the oracle's whatever the plan."""
+    o = oracle_mod
+    x = synth_signal(600_000, fs_in=1.25e6)
+    cfg = o.config("lrit", 1.25e6, 1)
+    d = o.Demod(cfg)
+    d.process(x)
+    rrc = d.stage("rrc").copy()
+    co, cg = o.CostasLoop(cfg.pll_alpha), xa.CostasLoop(cfg.pll_alpha, exact=True, history=1024)
+    want, got = co.Work(rrc), cg.Work(rrc)
+    assert same_words(got, want), first_diff(got, want)
+    st = cg.exact_stats()
+    assert st["joints_open_after_batch"] > 0 and st["host_rounds"] > 0, st
+
+
+# ------------------------------------------------------------------------------------------------ the chain
+CASES = {"C1": ("lrit", 1.25e6, 1, {}), "C2": ("lrit", 6.25e6, 5, {}),
+         "C3": ("hrit", 2.5e6, 1, {"symbol_rate": 927000.0, "alpha": 0.3}), "C5": ("lrit", 40e6, 32, {})}
+
+
+@pytest.mark.parametrize("case", ["C1", "C2", "C3", "C5"])
+def test_chain_front_exact_2_every_stage_is_the_oracle(xa, oracle_mod, case):
+    """keep_stages: decimator, AGC, matched filter and Costas outputs word for word; with the clock recovery relayed to
+    closure (cfg.clock_exact = 1) the soft symbols too -- over several calls of a stream (state carried in every stage)."""
+    mode, fs, D, kw = CASES[case]
+    n = 400_000 * D
+    x = synth_signal(n, fs_in=fs, **kw)
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=2, clock_exact=1))
+    dem.keep_stages(True)
+    od = oracle_mod.Demod(oracle_mod.config(mode, fs, D))
+    cuts = [0, 150_000 * D, 150_001 * D + (3 if D > 1 else 0), n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got, want = dem.process(x[a:b]), od.process(x[a:b])
+        names = ["decimator", "agc", "rrc", "costas"] if D > 1 else ["agc", "rrc", "costas"]
+        for nm in names:
+            g, w = dem.stage(nm), od.stage(nm)
+            assert same_words(g, w), (case, nm, a, b, first_diff(g, w), rms(g - w) if g.shape == w.shape else None)
+        assert same_words(got, want), (case, "soft symbols", a, b, first_diff(got, want))
+
+
+@pytest.mark.parametrize("case", ["C1", "C2", "C3", "C5"])
+def test_north_star_1e_4_with_front_exact_2_on_the_test_bursts(xa, oracle_mod, case):
+    """BASELINE.json's tolerance, plainly, default clock recovery, cold-started test bursts (0.1-0.2 M symbols)."""
+    mode, fs, D, kw = CASES[case]
+    n = 600_000 * D
+    x = synth_signal(n, fs_in=fs, **kw)
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=2))
+    got = dem.process(x)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    assert len(got) == len(want)
+    big = np.abs(want) > 1e-3
+    assert (np.sign(got)[big] == np.sign(want)[big]).all()
+    r = rms(got - want)
+    print(f"{case}: soft symbols {r:.3e} rms from the oracle (front_exact = 2, {len(want)} symbols)")
+    assert r <= NORTH_STAR_RMS, (case, r)

@@ -13,5 +13,5 @@ from ._capi import (  # noqa: F401
     XritError, lib, lib_path, build, device_count, build_experiments, version,
     SAMPLE_FLOATIQ, SAMPLE_S16IQ, SAMPLE_S8IQ, SAMPLE_U8IQ,
     Filters, FirFilter, AGC, CostasLoop, ClockRecovery, RtlIngest, Demodulator, Group, LocalFabric, group_unique_id, DemodConfig, DemodStats,
-    SynthParams as DeviceSynthParams, synth_generate_device, quantize_i8_device, sync_correlate, sync_correlate_device, sync_fix_frames, sync_fix_frames_device,
+    loop_sincosf, SynthParams as DeviceSynthParams, synth_generate_device, quantize_i8_device, sync_correlate, sync_correlate_device, sync_fix_frames, sync_fix_frames_device,
 )

@@ -85,6 +85,11 @@ _SIGNATURES = {
     "xrit_sync_fix_frames": (C.c_int, [_vp, _sz, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_int]),
     "xrit_fir_create": (C.c_int, [C.c_uint, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "xrit_fir_work": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "xrit_fir_set_exact": (C.c_int, [_vp, C.c_int]),
+    "xrit_loop_sincosf": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int]),
+    "xrit_agc_set_exact": (C.c_int, [_vp, C.c_int]),
+    "xrit_costas_set_exact": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "xrit_costas_exact_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "xrit_fir_destroy": (None, [_vp]),
     "xrit_agc_create": (C.c_int, [C.c_float] * 4 + [C.c_int, C.POINTER(_vp)]),
     "xrit_agc_work": (C.c_int, [_vp, _vp, _vp, _sz]),
@@ -208,6 +213,14 @@ class Filters:
         return t
 
 
+def loop_sincosf(x, device=0):
+    """The exact Costas loop's sincosf (csrc/exact_sincos.h) on the device: (sin, cos) of an array of float32, |x| < 120."""
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    _check(lib().xrit_loop_sincosf(_p(x), _p(s), _p(c), len(x), device))
+    return s, c
+
+
 class _Handle:
     _destroy = None
 
@@ -230,11 +243,13 @@ class FirFilter(_Handle):
     """SatHelper::FirFilter(decimation, taps); Work(in, out, nOut)."""
     _destroy = "xrit_fir_destroy"
 
-    def __init__(self, decimation, taps, device=0):
+    def __init__(self, decimation, taps, device=0, exact=False):
         super().__init__()
         taps = np.ascontiguousarray(taps, np.float32)
         self.D = int(decimation)
         _check(lib().xrit_fir_create(self.D, _p(taps), len(taps), device, C.byref(self._h)))
+        if exact:       # summed in the CPU chain's order (cfg.front_exact = 2)
+            _check(lib().xrit_fir_set_exact(self._h, 1))
 
     def Work(self, x, n_out):
         x = _c64(x)
@@ -248,9 +263,11 @@ class AGC(_Handle):
     """SatHelper::AGC(rate, reference, gain, maxGain); Work(in, out, n)."""
     _destroy = "xrit_agc_destroy"
 
-    def __init__(self, rate, reference, gain, max_gain, device=0):
+    def __init__(self, rate, reference, gain, max_gain, device=0, exact=False):
         super().__init__()
         _check(lib().xrit_agc_create(rate, reference, gain, max_gain, device, C.byref(self._h)))
+        if exact:       # the float32 recurrence walked literally (cfg.front_exact = 2)
+            _check(lib().xrit_agc_set_exact(self._h, 1))
 
     def Work(self, x):
         x = _c64(x)
@@ -267,9 +284,16 @@ class CostasLoop(_Handle):
     """SatHelper::CostasLoop(loopBw, order); Work(in, out, n)."""
     _destroy = "xrit_costas_destroy"
 
-    def __init__(self, loop_bw, order=2, device=0):
+    def __init__(self, loop_bw, order=2, device=0, exact=False, history=0):
         super().__init__()
         _check(lib().xrit_costas_create(loop_bw, order, device, C.byref(self._h)))
+        if exact:       # the output on the serial float32 trajectory (cfg.front_exact = 2)
+            _check(lib().xrit_costas_set_exact(self._h, 1, int(history)))
+
+    def exact_stats(self):
+        b, r, o, f = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _check(lib().xrit_costas_exact_stats(self._h, C.byref(b), C.byref(r), C.byref(o), C.byref(f)))
+        return {"blocks": b.value, "picard_rounds": r.value, "joints_open_after_batch": o.value, "host_rounds": f.value}
 
     def Work(self, x):
         x = _c64(x)

@@ -124,6 +124,7 @@ void AgcStage::release()
 {
     state.release();
     aggs.release();
+    joints.release();
     if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; }
 }
 
@@ -141,6 +142,7 @@ int AgcStage::request_flag(hipStream_t s)
 
 int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)
 {
+    if (exact) return run_exact(in, out, n, s, prof);
     if (n == 0) return XRIT_OK;
     float *sin_ = state.as<float>() + 2 * cur;
     float *sout = state.as<float>() + 2 * (cur ^ 1);
@@ -164,6 +166,143 @@ int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profil
                            aggs.as<AgcMap>());
         hipLaunchKernelGGL(agc_serial_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg,
                            (long long)n, 0);
+    }
+    XR_HIP(hipGetLastError());
+    cur ^= 1;
+    return XRIT_OK;
+}
+
+
+// ---- cfg.front_exact = 2: the AGC walked literally --------------------------------------------------------------------------
+// The scan above evaluates the recurrence as composed maps: exact in real arithmetic, some ulps from the float32 recurrence
+// the CPU chain runs (AGC::Work, demodulator.cpp:143; the test tier's CPU restatement: xo_agc_work).  Bit for bit that recurrence is
+// only what it is when it is walked -- but a walk from a start gain that is a few ulps off BECOMES the true trajectory: the
+// loop is contractive and its state a single float, so the two coincide bit for bit after ~2 k samples (median; 99 %: 5.7 k,
+// tests/experiments/agc_merge_time.py) and stay together.  So: chains of AGC_EX_CHAIN samples, one lane each, every chain
+// started AGC_EX_WARM samples early from the scan's gain there (chain 0 and every chain that would start in front of the
+// call: from the carried gain, exactly), walking its warm-up quietly; a chain's gain at the start of its range must equal
+// its predecessor's gain at the end of its own -- bit for bit, which by induction from chain 0 makes every output the serial
+// recurrence's.  Joints that do not fit (one in ~1e5) are walked again from the predecessor's end state
+// (agc_exact_fix_kernel, a few rounds, no-ops otherwise); what is still open then raises the guard flag and the serial kernel
+// redoes the call.  |x| is the correctly rounded square root here (the shipped default takes v_sqrt_f32, 1 ulp).
+constexpr int AGC_EX_CHAIN = 4096;
+constexpr int AGC_EX_WARM = 12288;
+constexpr int AGC_EX_ROUNDS = 3;
+
+__device__ __forceinline__ void agc_step_exact(float xr, float xi, float &g, float rate, float ref, float maxg, float &yr, float &yi)
+{
+    yr = xr * g;
+    yi = xi * g;
+    g += rate * (ref - __fsqrt_rn(yr * yr + yi * yi));
+    if (maxg > 0.0f && g > maxg) g = maxg;
+}
+
+// samples [i0, i1) of the stream from gain g; WRITE: the outputs go to y.  16-byte accesses where both ends are even.
+template <bool WRITE>
+__device__ __forceinline__ float agc_exact_walk(const float2 *__restrict__ x, float2 *__restrict__ y, long long i0, long long i1,
+                                                float g, float rate, float ref, float maxg, int vec)
+{
+    long long i = i0;
+    // (i0 is a multiple of 1024; eight samples = four 16-byte loads in flight per round)
+    for (; vec && i + 8 <= i1; i += 8) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4 *>(x + i + 2 * k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o;
+            agc_step_exact(v[k].x, v[k].y, g, rate, ref, maxg, o.x, o.y);
+            agc_step_exact(v[k].z, v[k].w, g, rate, ref, maxg, o.z, o.w);
+            if (WRITE) *reinterpret_cast<float4 *>(y + i + 2 * k) = o;
+        }
+    }
+    for (; i < i1; ++i) {
+        const float2 v = x[i];
+        float yr, yi;
+        agc_step_exact(v.x, v.y, g, rate, ref, maxg, yr, yi);
+        if (WRITE) y[i] = make_float2(yr, yi);
+    }
+    return g;
+}
+
+__global__ void __launch_bounds__(64) agc_exact_kernel(const float2 *__restrict__ x, float2 *__restrict__ y,
+                                                       const AgcMap *__restrict__ pre, const float *__restrict__ state_in,
+                                                       float *__restrict__ state_out, float *__restrict__ gs,
+                                                       float *__restrict__ ge, float rate, float ref, float maxg, long long n,
+                                                       int C, int vec)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const long long a = (long long)c * AGC_EX_CHAIN;
+    const long long b = min(n, a + AGC_EX_CHAIN);
+    const long long s = a > AGC_EX_WARM ? a - AGC_EX_WARM : 0;
+    // (the scan's blocks are SCAN_TILE = 1024 samples: pre[j] is the exclusive prefix map of block j)
+    float g = s == 0 ? state_in[0] : agc_apply(pre[s / SCAN_TILE], state_in[0]);
+    g = agc_exact_walk<false>(x, y, s, a, g, rate, ref, maxg, vec);
+    gs[c] = g;
+    g = agc_exact_walk<true>(x, y, a, b, g, rate, ref, maxg, vec);
+    ge[c] = g;
+    if (b == n) state_out[0] = g;
+}
+
+// one round: a chain whose start gain is not its predecessor's end gain is walked again from that
+__global__ void __launch_bounds__(64) agc_exact_fix_kernel(const float2 *__restrict__ x, float2 *__restrict__ y,
+                                                           float *__restrict__ state_out, float *__restrict__ gs,
+                                                           float *__restrict__ ge, float rate, float ref, float maxg,
+                                                           long long n, int C, int last, int vec)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < 1 || c >= C) return;
+    const float gp = ge[c - 1];
+    if (__float_as_uint(gp) == __float_as_uint(gs[c])) return;
+    if (last) { state_out[1] = 1.0f; return; }        // still open after the rounds: the guard flag, the serial kernel follows
+    const long long a = (long long)c * AGC_EX_CHAIN;
+    const long long b = min(n, a + AGC_EX_CHAIN);
+    const float g = agc_exact_walk<true>(x, y, a, b, gp, rate, ref, maxg, vec);
+    gs[c] = gp;
+    ge[c] = g;
+    if (b == n) state_out[0] = g;
+}
+
+__global__ void agc_serial_exact_kernel(const float2 *x, float2 *y, const float *state_in, float *state_out,
+                                        float rate, float ref, float maxg, long long n, int vec)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (state_out[1] == 0.0f) return;
+    const float g = agc_exact_walk<true>(x, y, 0, n, state_in[0], rate, ref, maxg, vec);
+    state_out[0] = g;
+    state_out[1] = 2.0f;  // serial path taken
+}
+
+int AgcStage::run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)
+{
+    if (n == 0) return XRIT_OK;
+    float *sin_ = state.as<float>() + 2 * cur;
+    float *sout = state.as<float>() + 2 * (cur ^ 1);
+    const int nb = scan_blocks((long long)n);
+    const int C = (int)div_up(n, (size_t)AGC_EX_CHAIN);
+    XR_TRY(aggs.reserve((size_t)(nb + scan_blocks(nb) + 4) * sizeof(AgcMap)));
+    XR_TRY(joints.reserve((size_t)2 * C * sizeof(float)));
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    AgcScanF f{in, out, sin_, sout, rate, ref, maxg, (long long)n, 0};
+    {
+        ProfScope ps(prof, "agc_reduce", s);
+        hipLaunchKernelGGL(agc_begin_kernel, dim3(1), dim3(1), 0, s, sout);
+        hipLaunchKernelGGL(scan_reduce_kernel<AgcScanF>, dim3(nb), dim3(SCAN_BLOCK), 0, s, f, (long long)n, aggs.as<AgcMap>());
+    }
+    {
+        ProfScope ps(prof, "agc_scan", s);
+        scan_aggs_launch(f, aggs.as<AgcMap>(), nb, s);
+    }
+    {
+        ProfScope ps(prof, "agc_exact", s);
+        float *gs = joints.as<float>(), *ge = joints.as<float>() + C;
+        hipLaunchKernelGGL(agc_exact_kernel, dim3(div_up((size_t)C, 64)), dim3(64), 0, s, in, out, aggs.as<AgcMap>(), sin_, sout,
+                           gs, ge, rate, ref, maxg, (long long)n, C, vec);
+        for (int r = 0; r <= AGC_EX_ROUNDS && C > 1; ++r)
+            hipLaunchKernelGGL(agc_exact_fix_kernel, dim3(div_up((size_t)C, 64)), dim3(64), 0, s, in, out, sout, gs, ge, rate, ref,
+                               maxg, (long long)n, C, r == AGC_EX_ROUNDS ? 1 : 0, vec);
+        hipLaunchKernelGGL(agc_serial_exact_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg, (long long)n, vec);
     }
     XR_HIP(hipGetLastError());
     cur ^= 1;

@@ -616,6 +616,8 @@ __global__ void __launch_bounds__(256) costas_verify_kernel(CostasPolicy p, long
 
 int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 {
+    if (const char *e = getenv("XRIT_CX_HIST")) { const int v = atoi(e); if (v >= 0) ex_hist = v; }
+    ex_fast = getenv("XRIT_CX_NO_FAST") == nullptr;
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;
     L = (L + COSTAS_CT - 1) / COSTAS_CT * COSTAS_CT;   // whole LDS tiles per chain
@@ -655,6 +657,8 @@ int CostasStage::reset(hipStream_t s)
 
 void CostasStage::release()
 {
+    xj.release(); xbs.release(); xcnt.release();
+    if (h_xcnt) { (void)hipHostFree(h_xcnt); h_xcnt = nullptr; }
     state.release(); S.release(); E.release(); J.release(); stat.release(); sub.release(); dlin.release();
     work.release(); flags.release(); counters.release(); wsolve.release(); rescue.release();
     if (h_counters) (void)hipHostFree(h_counters);
@@ -791,6 +795,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
     }
     XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     XR_HIP(hipGetLastError());
+    if (exact) XR_TRY(enqueue_exact(s, prof));
     return XRIT_OK;
 }
 
@@ -806,6 +811,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     max_residual = 0;
     job = Job{};
     walked = false;
+    ex_args_valid = false;
     job.in = in; job.out = out; job.n = n; job.om = om; job.om_off = om_off; job.inv_sps = inv_sps;
     job.model_accept = locked ? model_accept : 0.f;
     if (n == 0) return XRIT_OK;
@@ -946,6 +952,14 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         }
         fprintf(stderr, "[xrit] costas: %d passes, closed %u, on prediction %u, left open %u, max residual %.3e\n", passes, h_counters[0],
                 h_counters[6], h_counters[2], max_residual);
+    }
+    if (exact) {
+        XR_TRY(finish_exact(s, prof, redone));
+        ex_blocks += h_xcnt ? h_xcnt[1] : 0;
+        ex_picard += h_xcnt ? h_xcnt[2] : 0;
+        if (trace_env && h_xcnt)
+            fprintf(stderr, "[xrit] costas exact: %d walkers, %u blocks, %.2f rounds per block, %u at the round limit, %u joints open after the batch, %d more rounds\n",
+                    ex_W, h_xcnt[1], h_xcnt[1] ? (double)h_xcnt[2] / h_xcnt[1] : 0.0, h_xcnt[3], ex_open, ex_rounds);
     }
     cur ^= 1;     // the carried state now is the one the final pass left
     return XRIT_OK;

@@ -244,8 +244,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         set_error("AGC rate, reference and initial gain must be positive (Parameters.h:34-37: 0.01, 0.5, 1, 4000)");
         return XRIT_E_INVALID;
     }
-    if (cfg->front_exact < 0 || cfg->front_exact > 1) {
-        set_error("front_exact = %d: 0 (off) or 1", cfg->front_exact);
+    if (cfg->front_exact < 0 || cfg->front_exact > 2) {
+        set_error("front_exact = %d: 0 (off), 1 or 2", cfg->front_exact);
         return XRIT_E_INVALID;
     }
     if (!(cfg->sample_rate / (float)cfg->decimation / (float)cfg->symbol_rate >= 1.0f)) {
@@ -279,13 +279,16 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
+        // (cfg.front_exact = 2: both filters summed in the CPU chain's order, the AGC and the Costas loop walked literally --
+        // the front end bit for bit the CPU chain's through the Costas loop; fir.hip, agc.hip, costas_exact.hip)
+        d->dec.exact = d->rrc.exact = d->agc.exact = d->costas.exact = cfg->front_exact == 2;
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
         if ((rc = d->rtl.init(cfg->sample_rate)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
         if ((rc = d->rrc.init(rrc.data(), (int)rrc.size(), 1)) != XRIT_OK) break;
         if ((rc = d->costas.init(cfg->pll_alpha, cfg->costas_chain_len, cfg->max_passes)) != XRIT_OK) break;
         // (cfg.front_exact, the opt-in parity mode: the final pass starts every chain four chains early)
-        if (cfg->front_exact >= 1) d->costas.final_warm = 4;
+        if (cfg->front_exact == 1) d->costas.final_warm = 4;
         if ((rc = d->clock.init(d->sps, cfg->clock_gain_omega, cfg->clock_mu, cfg->clock_alpha, cfg->clock_omega_limit,
                                 cfg->clock_chain_syms, cfg->max_passes > 0 ? cfg->max_passes : 0)) != XRIT_OK) break;
         d->clock.serial = cfg->clock_serial != 0;
@@ -1171,6 +1174,14 @@ int xrit_fir_work(xrit_fir *f, const float *in, float *out, size_t n_out)
     return XRIT_OK;
 }
 
+int xrit_fir_set_exact(xrit_fir *f, int exact)
+{
+    if (!f) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(f->device));
+    XR_HIP(hipStreamSynchronize(f->stream));
+    return f->st.set_exact(exact != 0);
+}
+
 void xrit_fir_destroy(xrit_fir *f) { stage_close(f); }
 
 int xrit_agc_create(float rate, float reference, float gain, float max_gain, int device, xrit_agc **out)
@@ -1196,6 +1207,13 @@ int xrit_agc_work(xrit_agc *a, const float *in, float *out, size_t n)
     XR_TRY(a->st.run(a->in.as<float2>(), a->out.as<float2>(), n, a->stream, nullptr));
     if (n) XR_HIP(hipMemcpyAsync(out, a->out.p, n * sizeof(float2), hipMemcpyDeviceToHost, a->stream));
     XR_HIP(hipStreamSynchronize(a->stream));
+    return XRIT_OK;
+}
+
+int xrit_agc_set_exact(xrit_agc *a, int exact)
+{
+    if (!a) { set_error("null argument"); return XRIT_E_INVALID; }
+    a->st.exact = exact != 0;
     return XRIT_OK;
 }
 
@@ -1234,6 +1252,46 @@ int xrit_costas_work(xrit_costas *c, const float *in, float *out, size_t n)
     XR_TRY(c->st.run(c->in.as<float2>(), c->out.as<float2>(), n, c->stream, nullptr));
     if (n) XR_HIP(hipMemcpyAsync(out, c->out.p, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
     XR_HIP(hipStreamSynchronize(c->stream));
+    return XRIT_OK;
+}
+
+int xrit_loop_sincosf(const float *x, float *sin_out, float *cos_out, size_t n, int device)
+{
+    if (n && (!x || !sin_out || !cos_out)) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_TRY(select_device(device));
+    if (n == 0) return XRIT_OK;
+    DevBuf dx, ds, dc;
+    int rc = dx.reserve(n * sizeof(float));
+    if (rc == XRIT_OK) rc = ds.reserve(n * sizeof(float));
+    if (rc == XRIT_OK) rc = dc.reserve(n * sizeof(float));
+    if (rc == XRIT_OK && hipMemcpy(dx.p, x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); rc = XRIT_E_HIP; }
+    if (rc == XRIT_OK) rc = launch_loop_sincosf(dx.as<float>(), ds.as<float>(), dc.as<float>(), n, nullptr);
+    if (rc == XRIT_OK && (hipDeviceSynchronize() != hipSuccess ||
+                          hipMemcpy(sin_out, ds.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(cos_out, dc.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("loop_sincosf: device error");
+        rc = XRIT_E_HIP;
+    }
+    dx.release(); ds.release(); dc.release();
+    return rc;
+}
+
+int xrit_costas_set_exact(xrit_costas *c, int exact, int history)
+{
+    if (!c) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (history < 0) { set_error("history = %d", history); return XRIT_E_INVALID; }
+    c->st.exact = exact != 0;
+    if (history > 0) c->st.ex_hist = history;
+    return XRIT_OK;
+}
+
+int xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds)
+{
+    if (!c) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (blocks) *blocks = c->st.ex_blocks;
+    if (rounds) *rounds = c->st.ex_picard;
+    if (joints_open) *joints_open = c->st.ex_open;
+    if (fix_rounds) *fix_rounds = (uint32_t)c->st.ex_rounds;
     return XRIT_OK;
 }
 

@@ -585,8 +585,89 @@ fir_poly_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, fl
     }
 }
 
+
+// ---- cfg.front_exact = 2: the filter summed the way the CPU chain sums it -------------------------------------------------
+// FirFilter::Work, demodulator.cpp:138,148, as the test tier's CPU restatement (xo_fir_work) sums it: output m = sum over the time-ordered window
+// w[t] = x[m D - (T - 1) + t] of rt[t] w[t] (rt: the taps reversed) in FOUR interleaved float32 partial sums -- sum j takes
+// t = j mod 4, in order of t, every product rounded before it is added (no FMA) --, then (s0 + s1) + (s2 + s3).  Float
+// addition does not associate, so this kernel does exactly that: a lane takes one output at a time and walks its window
+// once with four accumulator pairs (v_pk_mul_f32 + v_pk_add_f32 per tap; the build has -ffp-contract=off).  Consecutive
+// lanes take consecutive outputs (windows D samples apart in the LDS tile: 2 D dwords, conflict-free for odd D; even D: the
+// tile is skewed by one sample per D); the stores are coalesced as they are.  Twice the vector work of the FMA kernels and
+// no reuse of a window read between outputs: the price of the parity mode, not the shipped default.
+template <int TYPE, bool PAD>
+__global__ void __launch_bounds__(256)
+fir_exact_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
+                 const float *__restrict__ rt, int T, int D, long long n_out, long long n_in, int tile_len, int opt,
+                 float2 *__restrict__ stat, float2 *__restrict__ hist_new)
+{
+    if (hist_new != nullptr && blockIdx.x == gridDim.x - 1) fir_leave_history<TYPE>(in, hist, hist_new, T, n_in);
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(smem_raw);
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const long long OB = (long long)nthr * opt;
+    const long long out_base = (long long)blockIdx.x * OB;
+    const long long tile_start = out_base * D - (T - 1);
+    for (int idx = tid; idx < tile_len; idx += nthr) {
+        const long long j = tile_start + idx;
+        float2 v = make_float2(0.f, 0.f);
+        if (j < 0) {
+            const long long hj = (T - 1) + j;
+            if (hj >= 0) v = hist[hj];
+        } else if (j < n_in) {
+            v = SampleLoad<TYPE>::at(in, (size_t)j);
+        }
+        tile[PAD ? idx + idx / D : idx] = v;
+    }
+    __syncthreads();
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int T4 = T & ~3;
+    for (int k = 0; k < opt; ++k) {
+        const int m = tid + k * nthr;                         // block-relative output
+        const long long o = out_base + m;
+        // window index m D + t sits at m D + t (+ (m D + t) / D = m + t / D when skewed)
+        const float2 *w = tile + (PAD ? m * (D + 1) : m * D);
+        v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, s3 = {0.f, 0.f};
+        int pos = 0, run = 0;                                 // run = t mod D (skewed tiles)
+#define XR_EX_TAP(S, TT)                                                              \
+        {                                                                             \
+            const float2 xs = w[pos];                                                 \
+            const v2f x = {xs.x, xs.y};                                               \
+            const float tp = rt[TT];                                                  \
+            const v2f pr = x * tp;                                                    \
+            S = S + pr;                                                               \
+            ++pos;                                                                    \
+            if (PAD && ++run == D) { run = 0; ++pos; }                                \
+        }
+        for (int t = 0; t < T4; t += 4) {
+            XR_EX_TAP(s0, t) XR_EX_TAP(s1, t + 1) XR_EX_TAP(s2, t + 2) XR_EX_TAP(s3, t + 3)
+        }
+        if (T4 < T) XR_EX_TAP(s0, T4)
+        if (T4 + 1 < T) XR_EX_TAP(s1, T4 + 1)
+        if (T4 + 2 < T) XR_EX_TAP(s2, T4 + 2)
+#undef XR_EX_TAP
+        const v2f r = (s0 + s1) + (s2 + s3);
+        if (o < n_out) out[o] = make_float2(r.x, r.y);
+        if (stat != nullptr) {
+            // sum z^2 per run of 8 outputs (the Costas guess's statistic, as fir_decim_kernel leaves it): eight neighbouring
+            // lanes hold a run
+            float sr = 0.f, si = 0.f;
+            if (o < n_out) { sr = r.x * r.x - r.y * r.y; si = 2.0f * r.x * r.y; }
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x111, 0xf, 0xf, true));      // row_shr:1
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x111, 0xf, 0xf, true));
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x112, 0xf, 0xf, true));      // row_shr:2
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x112, 0xf, 0xf, true));
+            sr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sr), 0x114, 0xf, 0xf, true));      // row_shr:4
+            si += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(si), 0x114, 0xf, 0xf, true));
+            if ((tid & 7) == 7 && o - 7 < n_out) stat[o >> 3] = make_float2(sr, si);
+        }
+    }
+}
+
 int FirStage::init(const float *taps, int ntaps, int decim)
 {
+    taps_host.assign(taps, taps + ntaps);
+
     // diagnostic switches are read once, here: never on the launch path (a host that calls setenv races with getenv)
     no_static_dec = getenv("XRIT_NO_STATIC_DEC") != nullptr;
     no_static_mf = getenv("XRIT_NO_STATIC_MF") != nullptr;
@@ -600,6 +681,29 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     else RC = 3;
     // large decimations whose phases map onto lanes take the polyphase kernel
     poly = (D == 16 || D == 32 || D == 64) && (T + D - 1) / D <= POLY_NQ;
+    if (exact) {
+        // (cfg.front_exact = 2: fir_exact_kernel; the reversed taps, a tile of at most 64 KiB)
+        poly = false;
+        std::vector<float> r((size_t)T);
+        for (int i = 0; i < T; ++i) r[(size_t)i] = taps[T - 1 - i];
+        XR_TRY(rt.reserve(r.size() * sizeof(float)));
+        XR_HIP(hipMemcpy(rt.p, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+        ex_pad = (D % 2) == 0;
+        ex_threads = 256;
+        ex_opt = D == 1 ? 4 : 2;
+        for (;;) {
+            const long long ob = (long long)ex_threads * ex_opt;
+            const long long tl = (ob - 1) * D + T;
+            const long long padded = ex_pad ? tl + tl / D + 2 : tl;
+            if (padded * 8 <= 64 * 1024 || (ex_threads == 64 && ex_opt == 1)) {
+                ex_tile_len = (int)tl;
+                ex_lds = (size_t)padded * 8;
+                break;
+            }
+            if (ex_opt > 1) --ex_opt; else ex_threads /= 2;
+        }
+        if (ex_lds > 160 * 1024) { set_error("FIR window of %d taps x decimation %d does not fit LDS", T, D); return XRIT_E_INVALID; }
+    }
     if (poly) {
         threads = XRIT_POLY_THREADS;
         RC = 1;
@@ -686,18 +790,29 @@ int FirStage::reset(hipStream_t s)
 
 bool FirStage::agc_supported() const
 {
-    return !poly && !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs
+    return !exact && !poly && !pad && threads % 64 == 0 && RC <= AGC_RUN_MAX_PER_LANE;      // one run per wave: 64 * RC outputs
 }
 
 bool FirStage::stat_supported(int statL) const
 {
     // runs must not straddle blocks (the sums are taken from the block's outputs staged in LDS)
+    if (exact) return statL == 8;
     if (poly) return false;
     return statL > 0 && !pad && threads % 64 == 0 && (threads * RC) % statL == 0;
 }
 
+int FirStage::set_exact(bool on)
+{
+    if (on == exact) return XRIT_OK;
+    if (taps_host.empty()) { set_error("FIR: set_exact before init"); return XRIT_E_INVALID; }
+    exact = on;
+    const std::vector<float> t = taps_host;
+    return init(t.data(), (int)t.size(), D);
+}
+
 void FirStage::release()
 {
+    rt.release();
     g.release();
     mfb.release();
     hist[0].release();
@@ -744,7 +859,7 @@ bool FirStage::agc_fill_supported(int per_lane) const
 {
     // the window must be covered by three rounds of the block's waves, one run each
     const long long runs = (tile_len + (long long)64 * per_lane - 1) / (64 * per_lane) + 1;
-    return D == 1 && !pad && threads % 64 == 0 && per_lane == 3 && RC == 5 && runs <= 3 * (threads / 64);
+    return !exact && D == 1 && !pad && threads % 64 == 0 && per_lane == 3 && RC == 5 && runs <= 3 * (threads / 64);
 }
 
 // matched filter with the AGC applied in its window fill; `in` is the fallback stream (AgcFill)
@@ -782,6 +897,32 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
         return fir_launch_agc_fill(*this, reinterpret_cast<const float2 *>(in), out, n_out, s, prof, stat, statL, *fill);
     }
     if (stat && !stat_supported(statL)) stat = nullptr;
+    if (exact) {
+        if (agc_in) { set_error("FIR: the exact-order kernel has no AGC epilogue"); return XRIT_E_INVALID; }
+        const size_t n_in = n_out * (size_t)D;
+        if (n_out > 0) {
+            ProfScope ps(prof, D > 1 ? "fir_decim" : "fir_rrc", s);
+            const unsigned blocks = div_up(n_out, (size_t)ex_threads * ex_opt);
+            const float2 *h = hist[cur].as<float2>();
+            float2 *hn = T > 1 ? hist[cur ^ 1].as<float2>() : (float2 *)nullptr;
+#define XR_EX_GO(TY, PD)                                                                                               \
+    hipLaunchKernelGGL((fir_exact_kernel<TY, PD>), dim3(blocks), dim3(ex_threads), ex_lds, s, in, h, out, rt.as<float>(), T, D, \
+                       (long long)n_out, (long long)n_in, ex_tile_len, ex_opt, stat, hn)
+#define XR_EX_TY(PD)                                                          \
+    do {                                                                      \
+        if (type == XRIT_SAMPLE_FLOATIQ) XR_EX_GO(XRIT_SAMPLE_FLOATIQ, PD);   \
+        else if (type == XRIT_SAMPLE_S16IQ) XR_EX_GO(XRIT_SAMPLE_S16IQ, PD);  \
+        else XR_EX_GO(XRIT_SAMPLE_S8IQ, PD);                                  \
+    } while (0)
+            if (ex_pad) XR_EX_TY(true);
+            else XR_EX_TY(false);
+#undef XR_EX_TY
+#undef XR_EX_GO
+            XR_HIP(hipGetLastError());
+        }
+        if (T > 1 && n_in > 0) cur ^= 1;
+        return XRIT_OK;
+    }
     AgcEpilogue agc{nullptr, nullptr, 0.f, 0.f, 0.f};
     if (agc_in) {
         if (!agc_supported()) {

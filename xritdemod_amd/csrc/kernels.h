@@ -17,6 +17,13 @@ struct FirStage {
     bool no_static_dec = false, no_static_mf = false;   // XRIT_NO_STATIC_DEC / XRIT_NO_STATIC_MF, read once in init (A/B runs)
     int prio = 0;        // 1: this launch's waves at a raised issue priority (fir_decim_kernel; set by the chain per front end)
     bool poly = false;   // polyphase kernel (lanes = phases) for decimation 16 / 32 / 64
+    // cfg.front_exact = 2: summed in the CPU chain's order, no FMA (fir_exact_kernel); set before init or through set_exact()
+    bool exact = false, ex_pad = false;
+    int ex_threads = 256, ex_opt = 2, ex_tile_len = 0;
+    size_t ex_lds = 0;
+    DevBuf rt;           // the taps reversed (exact kernel)
+    std::vector<float> taps_host;
+    int set_exact(bool on);
 #ifndef XRIT_POLY_PR
 #define XRIT_POLY_PR 16
 #endif
@@ -83,6 +90,10 @@ struct AgcStage {
     float gain0 = 1.0f;
     void release();
     int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    // cfg.front_exact = 2: chains walked literally from the scan's gains, warmed up until they ARE the serial recurrence (agc.hip)
+    bool exact = false;
+    DevBuf joints;   // per chain: gain at the start of its range / at its end
+    int run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
     // the same in two halves around the kernel that produces `in` (the decimator): fused_begin() before it
     // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
     int fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi);      // per_lane: the producer's RC
@@ -155,8 +166,25 @@ struct CostasStage {
     int stable = 0, last_passes = -1;   // calls in a row that closed inside their batch with the same count
                             // (2 on a locked signal); every surplus pass is ~4 no-op launches of ~5 us
     int get_state(float *phase, float *freq, hipStream_t s);
+    // cfg.front_exact = 2 (costas_exact.hip): behind the final pass the output is put ON the serial float32 trajectory by
+    // exactly walked, overlapping ranges; finish() closes what joints are still open
+    bool exact = false;
+    bool ex_fast = true;            // the three-instruction systolic round where neither wrap nor limiter acts (XRIT_CX_NO_FAST=1: off)
+    int ex_hist = 32768;            // samples of warm-up in front of every range (XRIT_CX_HIST)
+    DevBuf xj, xbs, xcnt;           // joints (start / end / used), block records, counters
+    unsigned *h_xcnt = nullptr;     // pinned: [0] joints open, [1] blocks, [2] Picard rounds, [3] blocks that hit the round limit
+    int ex_W = 0, ex_rounds = 0;
+    bool ex_args_valid = false;
+    unsigned ex_open = 0, ex_nonconverged = 0;
+    unsigned long long ex_blocks = 0, ex_picard = 0;    // totals over the handle's calls (statistics)
+    int exact_plan(size_t n, int *Lw, int *W) const;
+    int enqueue_exact(hipStream_t s, Profiler *prof);
+    int finish_exact(hipStream_t s, Profiler *prof, bool *redone);
     int flip_phase(hipStream_t s);      // the carried phase moves by pi: the other of the loop's two locks
 };
+
+// the exact Costas loop's sincosf (exact_sincos.h) on an array: what tests/test_gpu_exact.py holds against the oracle's
+int launch_loop_sincosf(const float *d_x, float *d_sin, float *d_cos, size_t n, hipStream_t s);
 
 // ---- ClockRecovery (demodulator.cpp:449; Work at :156) --------------------
 struct ClockStage {
