@@ -193,7 +193,7 @@ __device__ __forceinline__ void agc_step_exact(float xr, float xi, float &g, flo
 {
     yr = xr * g;
     yi = xi * g;
-    g += rate * (ref - __fsqrt_rn(yr * yr + yi * yi));
+    g += rate * (ref - ::sqrtf(yr * yr + yi * yi));      // (sqrtf: the correctly rounded expansion; __fsqrt_rn is v_sqrt_f32, 1 ulp)
     if (maxg > 0.0f && g > maxg) g = maxg;
 }
 
