@@ -350,7 +350,8 @@ int  xrit_costas_create(float loop_bw, int order, int device, xrit_costas **out)
 int  xrit_costas_work(xrit_costas *c, const float *in, float *out, size_t n);
 int  xrit_costas_state(xrit_costas *c, float *phase, float *freq);
 /* exact = 1: behind the chains' hand-off the output is put on the serial float32 trajectory by exactly walked overlapping
- * ranges (front_exact = 2; csrc/costas_exact.hip).  history: samples of warm-up in front of every range (0 = default 32768) */
+ * ranges (front_exact = 2; csrc/costas_exact.hip).  history: samples of warm-up in front of every range (0 = by plan:
+ * none on large calls, where a walker goes on into the next range until the two meet; up to 32768 on small ones) */
 int  xrit_costas_set_exact(xrit_costas *c, int exact, int history);
 /* totals over the handle's calls: 64-sample blocks walked and Picard rounds spent on them; of the last call: joints that were
  * still open after the rounds enqueued with the call, and the rounds the host added */

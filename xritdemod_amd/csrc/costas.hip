@@ -617,6 +617,12 @@ __global__ void __launch_bounds__(256) costas_verify_kernel(CostasPolicy p, long
 int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
 {
     if (const char *e = getenv("XRIT_CX_HIST")) { const int v = atoi(e); if (v >= 0) ex_hist = v; }
+    {
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            ex_walkers = 4 * cus;
+        if (const char *e = getenv("XRIT_CX_WALKERS")) { const int v = atoi(e); if (v > 0) ex_walkers = v; }
+    }
     ex_fast = getenv("XRIT_CX_NO_FAST") == nullptr;
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;
@@ -780,6 +786,7 @@ int CostasStage::enqueue_passes(int count, hipStream_t s, Profiler *prof)
 
 int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
 {
+    {
     ProfScope ps(prof, "costas_final", s);
     const double dth = -2.0 * XR_PI_D * job.inv_sps;
     float2 *st_out = state.as<float2>() + (cur ^ 1);
@@ -795,7 +802,8 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
     }
     XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     XR_HIP(hipGetLastError());
-    if (exact) XR_TRY(enqueue_exact(s, prof));
+    }
+    if (exact) XR_TRY(enqueue_exact(s, prof));      // (behind the bracket of the final pass: the profiler's scopes do not nest)
     return XRIT_OK;
 }
 

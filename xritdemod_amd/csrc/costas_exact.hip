@@ -283,25 +283,36 @@ int launch_loop_sincosf(const float *d_x, float *d_sin, float *d_cos, size_t n, 
     return XRIT_OK;
 }
 
-int CostasStage::exact_plan(size_t n, int *Lw, int *W) const
+// The plan of a call.  A walker is one wave; the chip holds one per SIMD without their sharing an issue port (ex_walkers: 4 per
+// CU), so a call is cut into that many ranges.  A range's walker must have MET the serial trajectory by the end of its range
+// (its end state is what the next joint is settled from): `span` = 32 Ki samples walked at least (the merge time's 99 %).
+//  * ranges of `span` samples and more (large calls, where the walkers' total work is what counts): NO warm-up.  Every walker
+//    starts at its own range from the approximate state, and the first round over the joints lets walker w - 1 go on into
+//    range w until it meets walker w's record (~10 k samples, median).  A warm-up is paid by every walker, going on only by
+//    the part that is missing: work n + 12 k per joint instead of n + 32 k per walker.
+//  * shorter ranges (calls below span x walkers: the chip is not full, latency is what counts): a warm-up of span - range
+//    samples, so that 99 % of the joints fit at once.
+// ex_hist >= 0 (XRIT_CX_HIST, xrit_costas_set_exact): that warm-up whatever the call's size.
+int CostasStage::exact_plan(size_t n, int *Lw, int *W, int *H) const
 {
-    // ranges of at least 8192 samples, ~2048 walkers on a large call; multiples of the chain length and of 64
     const size_t unit = (size_t)L * 64 / (size_t)(L % 64 == 0 ? 64 : 1);      // lcm(L, 64) for the chain lengths in use
-    size_t lw = n / 2048;
-    if (lw < 8192) lw = 8192;
+    const size_t span = (32768 + unit - 1) / unit * unit;
+    size_t lw = (n + (size_t)ex_walkers - 1) / (size_t)ex_walkers;
+    if (lw < 2048) lw = 2048;
     lw = (lw + unit - 1) / unit * unit;
+    size_t h = lw >= span ? 0 : span - lw;
+    if (ex_hist >= 0) h = ((size_t)ex_hist + unit - 1) / unit * unit;
     *Lw = (int)lw;
     *W = (int)((n + lw - 1) / lw);
+    *H = (int)h;
     return XRIT_OK;
 }
 
 int CostasStage::enqueue_exact(hipStream_t s, Profiler *prof)
 {
     if (job.n == 0) return XRIT_OK;
-    int Lw = 0, W = 0;
-    XR_TRY(exact_plan(job.n, &Lw, &W));
-    const size_t unit = (size_t)L * 64 / (size_t)(L % 64 == 0 ? 64 : 1);
-    const int H = (int)(((size_t)ex_hist + unit - 1) / unit * unit);
+    int Lw = 0, W = 0, H = 0;
+    XR_TRY(exact_plan(job.n, &Lw, &W, &H));
     XR_TRY(xj.reserve((size_t)3 * W * sizeof(float2)));
     XR_TRY(xbs.reserve(((job.n >> 6) + 2) * sizeof(float2)));
     XR_TRY(xcnt.reserve(8 * sizeof(unsigned)));
@@ -324,7 +335,9 @@ int CostasStage::enqueue_exact(hipStream_t s, Profiler *prof)
     }
     if (W > 1) {
         ProfScope ps(prof, "costas_exact_fix", s);
-        for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 0);
+        // (rounds enqueued with the call: without a warm-up the first one does the settling, the second catches the joints
+        // whose predecessor's end state that changed; the host looks at what is left)
+        for (int r = 0; r < (H == 0 ? 3 : 2); ++r) hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 0);
         hipLaunchKernelGGL(costas_exact_zero_kernel, dim3(1), dim3(1), 0, s, A.cnt);
         hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 1);
     }
@@ -341,15 +354,14 @@ int CostasStage::finish_exact(hipStream_t s, Profiler *prof, bool *redone)
     ex_open = h_xcnt[0];
     ex_nonconverged = h_xcnt[3];
     if (ex_W <= 1) return XRIT_OK;
-    int Lw = 0, W = 0;
-    XR_TRY(exact_plan(job.n, &Lw, &W));
-    const size_t unit = (size_t)L * 64 / (size_t)(L % 64 == 0 ? 64 : 1);
+    int Lw = 0, W = 0, H = 0;
+    XR_TRY(exact_plan(job.n, &Lw, &W, &H));
     CxArgs A{};
     A.x = job.in; A.y = job.out; A.S = S.as<float2>();
     A.st_in = state.as<float2>() + cur; A.st_out = state.as<float2>() + (cur ^ 1);
     A.js = xj.as<float2>(); A.je = A.js + W; A.used = A.je + W;
     A.bs = xbs.as<float2>(); A.cnt = xcnt.as<unsigned>();
-    A.n = (long long)job.n; A.L = L; A.Lw = Lw; A.H = (int)(((size_t)ex_hist + unit - 1) / unit * unit); A.W = W;
+    A.n = (long long)job.n; A.L = L; A.Lw = Lw; A.H = H; A.W = W;
     A.g = CxGains{gains.alpha, gains.beta};
     A.fast_ok = ex_fast ? 1 : 0;
     while (h_xcnt[0] != 0) {

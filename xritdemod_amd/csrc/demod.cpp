@@ -1281,7 +1281,7 @@ int xrit_costas_set_exact(xrit_costas *c, int exact, int history)
     if (!c) { set_error("null argument"); return XRIT_E_INVALID; }
     if (history < 0) { set_error("history = %d", history); return XRIT_E_INVALID; }
     c->st.exact = exact != 0;
-    if (history > 0) c->st.ex_hist = history;
+    c->st.ex_hist = history > 0 ? history : -1;
     return XRIT_OK;
 }
 

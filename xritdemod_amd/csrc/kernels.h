@@ -170,14 +170,15 @@ struct CostasStage {
     // exactly walked, overlapping ranges; finish() closes what joints are still open
     bool exact = false;
     bool ex_fast = true;            // the three-instruction systolic round where neither wrap nor limiter acts (XRIT_CX_NO_FAST=1: off)
-    int ex_hist = 32768;            // samples of warm-up in front of every range (XRIT_CX_HIST)
+    int ex_hist = -1;               // >= 0: samples of warm-up in front of every range whatever the call (XRIT_CX_HIST); -1: by plan
+    int ex_walkers = 1024;          // ranges per large call: one walker per SIMD (set from the device's CU count in init)
     DevBuf xj, xbs, xcnt;           // joints (start / end / used), block records, counters
     unsigned *h_xcnt = nullptr;     // pinned: [0] joints open, [1] blocks, [2] Picard rounds, [3] blocks that hit the round limit
     int ex_W = 0, ex_rounds = 0;
     bool ex_args_valid = false;
     unsigned ex_open = 0, ex_nonconverged = 0;
     unsigned long long ex_blocks = 0, ex_picard = 0;    // totals over the handle's calls (statistics)
-    int exact_plan(size_t n, int *Lw, int *W) const;
+    int exact_plan(size_t n, int *Lw, int *W, int *H) const;
     int enqueue_exact(hipStream_t s, Profiler *prof);
     int finish_exact(hipStream_t s, Profiler *prof, bool *redone);
     int flip_phase(hipStream_t s);      // the carried phase moves by pi: the other of the loop's two locks
