@@ -354,8 +354,10 @@ int  xrit_costas_state(xrit_costas *c, float *phase, float *freq);
  * none on large calls, where a walker goes on into the next range until the two meet; up to 32768 on small ones) */
 int  xrit_costas_set_exact(xrit_costas *c, int exact, int history);
 /* totals over the handle's calls: 64-sample blocks walked and Picard rounds spent on them; of the last call: joints that were
- * still open after the rounds enqueued with the call, and the rounds the host added */
-int  xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds);
+ * still open after the rounds enqueued with the call, and the rounds the host added; totals again: segments of the lattice
+ * scans and scans that fell back to the systolic one (any pointer may be null) */
+int  xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds,
+                             uint64_t *lattice_segments, uint64_t *lattice_fallbacks);
 void xrit_costas_destroy(xrit_costas *c);
 
 /* The sincosf of the exact Costas loop on an array of (host) floats, |x| < 120: the C library's sincosf as the reference's loop

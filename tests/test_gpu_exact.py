@@ -309,3 +309,27 @@ def test_front_exact_2_streamed_is_plain_word_for_word(xa, oracle_mod):
         assert len(plain[b]) == len(want)
         r = rms(plain[b] - want)
         assert r <= NORTH_STAR_RMS, (b, r)
+
+
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3])
+def test_costas_exact_scan_variants_all_give_the_oracle(xa, oracle_mod, monkeypatch, scan_mode):
+    """XRIT_CX_MODE (read when the stage is created): 0 = the general systolic scan only, 1 = the three-instruction systolic
+    round where neither wrap nor limiter acts, 2 = the lattice scan with the general one behind it, 3 (default) = lattice, fast
+    systolic, general.  Whatever the route, the words are the oracle's (the scans are certified or literal)."""
+    o = oracle_mod
+    x = synth_signal(700_000, fs_in=1.25e6)
+    cfg = o.config("lrit", 1.25e6, 1)
+    d = o.Demod(cfg)
+    d.process(x)
+    rrc = d.stage("rrc").copy()
+    monkeypatch.setenv("XRIT_CX_MODE", str(scan_mode))
+    co, cg = o.CostasLoop(cfg.pll_alpha), xa.CostasLoop(cfg.pll_alpha, exact=True)
+    for seg in (rrc[:400_000], rrc[400_000:]):
+        want, got = co.Work(seg), cg.Work(seg)
+        assert same_words(got, want), (scan_mode, first_diff(got, want))
+    st = cg.exact_stats()
+    print(f"scan mode {scan_mode}:", st)
+    if scan_mode & 2:
+        assert st["lattice_segments"] > 0
+    else:
+        assert st["lattice_segments"] == 0

@@ -89,7 +89,8 @@ _SIGNATURES = {
     "xrit_loop_sincosf": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int]),
     "xrit_agc_set_exact": (C.c_int, [_vp, C.c_int]),
     "xrit_costas_set_exact": (C.c_int, [_vp, C.c_int, C.c_int]),
-    "xrit_costas_exact_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "xrit_costas_exact_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xrit_fir_destroy": (None, [_vp]),
     "xrit_agc_create": (C.c_int, [C.c_float] * 4 + [C.c_int, C.POINTER(_vp)]),
     "xrit_agc_work": (C.c_int, [_vp, _vp, _vp, _sz]),
@@ -291,9 +292,10 @@ class CostasLoop(_Handle):
             _check(lib().xrit_costas_set_exact(self._h, 1, int(history)))
 
     def exact_stats(self):
-        b, r, o, f = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
-        _check(lib().xrit_costas_exact_stats(self._h, C.byref(b), C.byref(r), C.byref(o), C.byref(f)))
-        return {"blocks": b.value, "picard_rounds": r.value, "joints_open_after_batch": o.value, "host_rounds": f.value}
+        b, r, o, f, sg, fb = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(lib().xrit_costas_exact_stats(self._h, C.byref(b), C.byref(r), C.byref(o), C.byref(f), C.byref(sg), C.byref(fb)))
+        return {"blocks": b.value, "picard_rounds": r.value, "joints_open_after_batch": o.value, "host_rounds": f.value,
+                "lattice_segments": sg.value, "lattice_fallbacks": fb.value}
 
     def Work(self, x):
         x = _c64(x)

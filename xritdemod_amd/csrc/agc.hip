@@ -8,8 +8,11 @@
 // monotonicity: it raises a guard flag and a single-lane kernel redoes the call
 // serially (never seen with normalised SDR samples; kept for exactness).
 #include "kernels.h"
+
+#include <cstdlib>
 #include "scan.h"
 #include "agc_wave.h"
+#include "exact_walk.h"
 
 namespace xrit {
 
@@ -99,6 +102,13 @@ int AgcStage::init(float rate_, float reference, float gain0_, float max_gain)
     ref = reference;
     maxg = max_gain;
     gain0 = gain0_;
+    {
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            ex_walkers = 8 * cus;
+        if (const char *e = getenv("XRIT_CX_WALKERS")) { const int v = atoi(e); if (v > 0) ex_walkers = v; }
+        if (const char *e = getenv("XRIT_CX_MODE")) ex_mode = atoi(e) & 3;
+    }
     XR_TRY(state.reserve(4 * sizeof(float)));
     float h[4] = {gain0_, 0.0f, gain0_, 0.0f};   // two (gain, flag) slots, ping-pong
     XR_HIP(hipMemcpy(state.p, h, sizeof h, hipMemcpyHostToDevice));
@@ -173,19 +183,22 @@ int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profil
 }
 
 
-// ---- cfg.front_exact = 2: the AGC walked literally --------------------------------------------------------------------------
+// ---- cfg.front_exact = 2: the AGC walked exactly -----------------------------------------------------------------------------
 // The scan above evaluates the recurrence as composed maps: exact in real arithmetic, some ulps from the float32 recurrence
-// the CPU chain runs (AGC::Work, demodulator.cpp:143; the test tier's CPU restatement: xo_agc_work).  Bit for bit that recurrence is
-// only what it is when it is walked -- but a walk from a start gain that is a few ulps off BECOMES the true trajectory: the
-// loop is contractive and its state a single float, so the two coincide bit for bit after ~2 k samples (median; 99 %: 5.7 k,
-// tests/experiments/agc_merge_time.py) and stay together.  So: chains of AGC_EX_CHAIN samples, one lane each, every chain
-// started AGC_EX_WARM samples early from the scan's gain there (chain 0 and every chain that would start in front of the
-// call: from the carried gain, exactly), walking its warm-up quietly; a chain's gain at the start of its range must equal
-// its predecessor's gain at the end of its own -- bit for bit, which by induction from chain 0 makes every output the serial
-// recurrence's.  Joints that do not fit (one in ~1e5) are walked again from the predecessor's end state
-// (agc_exact_fix_kernel, a few rounds, no-ops otherwise); what is still open then raises the guard flag and the serial kernel
-// redoes the call.  |x| is the correctly rounded square root here (the shipped default takes v_sqrt_f32, 1 ulp).
-constexpr int AGC_EX_CHAIN = 4096;
+// the CPU chain runs (AGC::Work, demodulator.cpp:143; the test tier's CPU restatement: xo_agc_work).  Bit for bit that
+// recurrence is only what it is when it is walked -- but a walk from a start gain that is a few ulps off BECOMES the true
+// trajectory: the loop is contractive and its state a single float, so the two coincide bit for bit after ~2 k samples
+// (median; 99 %: 5.7 k, tests/experiments/agc_merge_time.py) and stay together.  The walk is exact_walk.h's: ranges, one wave
+// each, started AGC_EX_WARM samples early from the gain the map scan gives there (range 0 and every range that would start
+// in front of the call: from the carried gain, exactly), joints settled bit for bit afterwards.  One step = 64 samples:
+//   * first guess of the gain in front of every sample: the lanes' gain maps composed across the wave (agc_wave_exclusive);
+//   * Picard rounds: every lane forms its increment rate * (ref - |x g|) from its guess -- the correctly rounded square root
+//     here, the shipped default takes v_sqrt_f32 --, the additions g += d (and the clamp) are then run for all 64 samples as
+//     an integer prefix sum on the float lattice, certified lane by lane by the literal step (agx_scan, the scheme of
+//     costas_exact.hip with one state variable); gains that come out as they went in are the serial recurrence's.
+// Joints still open after the rounds enqueued with the call (never seen) raise the guard flag and the serial kernel redoes
+// the call.  (Round 6's first version walked chains of 4096 samples one LANE each: 2.1 ms per C2 burst of pure latency --
+// 16 k dependent steps of ~300 cycles; this one 0.3.)
 constexpr int AGC_EX_WARM = 12288;
 constexpr int AGC_EX_ROUNDS = 3;
 
@@ -197,79 +210,105 @@ __device__ __forceinline__ void agc_step_exact(float xr, float xi, float &g, flo
     if (maxg > 0.0f && g > maxg) g = maxg;
 }
 
-// samples [i0, i1) of the stream from gain g; WRITE: the outputs go to y.  16-byte accesses where both ends are even.
-template <bool WRITE>
-__device__ __forceinline__ float agc_exact_walk(const float2 *__restrict__ x, float2 *__restrict__ y, long long i0, long long i1,
-                                                float g, float rate, float ref, float maxg, int vec)
+// the additions of 64 samples: d = this lane's increment, g0 the gain in front of lane 0 (uniform).  Out: the gain in front
+// of this lane's sample, by the serial recurrence's own additions.
+__device__ __forceinline__ float agx_scan(float d, float g0, float maxg, int mode, unsigned *lat)
 {
-    long long i = i0;
-    // (i0 is a multiple of 1024; eight samples = four 16-byte loads in flight per round)
-    for (; vec && i + 8 <= i1; i += 8) {
-        float4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4 *>(x + i + 2 * k);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float4 o;
-            agc_step_exact(v[k].x, v[k].y, g, rate, ref, maxg, o.x, o.y);
-            agc_step_exact(v[k].z, v[k].w, g, rate, ref, maxg, o.z, o.w);
-            if (WRITE) *reinterpret_cast<float4 *>(y + i + 2 * k) = o;
+    const int lane = threadIdx.x & 63;
+    float gv = g0;
+    if (mode & 2) {
+        float gb = g0;
+        int s = 0, seg = 0;
+        bool done = false;
+        for (; seg < 4 && !done; ++seg) {
+            const bool in = lane >= s;
+            const int og = xw::ord(gb);
+            const int dG = in ? xw::ord(gb + d) - og : 0;
+            const int S = xw::prefix(dG);
+            const float gnext = xw::inv(og + S), gown = xw::inv(og + S - dG);
+            float lg = gown + d;
+            if (maxg > 0.0f && lg > maxg) lg = maxg;
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(in && __float_as_uint(lg) != __float_as_uint(gnext));
+            const int k = bad ? (int)__builtin_ctzll(bad) : 64;
+            if (in && lane <= k) gv = gown;
+            if (k >= 63) { done = true; break; }
+            gb = xw::lane_of(lg, k);
+            s = k + 1;
         }
+        if (lat) { lat[0] += (unsigned)(seg + (done ? 1 : 0)); lat[1] += done ? 0u : 1u; }
+        if (done) return gv;
     }
-    for (; i < i1; ++i) {
-        const float2 v = x[i];
-        float yr, yi;
-        agc_step_exact(v.x, v.y, g, rate, ref, maxg, yr, yi);
-        if (WRITE) y[i] = make_float2(yr, yi);
+    // systolic: every lane adds its predecessor's value, 63 times
+    const float dsh = xw::shr1(d, 0.f);
+    gv = g0;
+    for (int it = 0; it < 63; ++it) {
+        float ng = xw::shr1(gv, g0) + dsh;
+        if (maxg > 0.0f && ng > maxg) ng = maxg;
+        if (lane > 0) gv = ng;
     }
-    return g;
+    return gv;
 }
 
-__global__ void __launch_bounds__(64) agc_exact_kernel(const float2 *__restrict__ x, float2 *__restrict__ y,
-                                                       const AgcMap *__restrict__ pre, const float *__restrict__ state_in,
-                                                       float *__restrict__ state_out, float *__restrict__ gs,
-                                                       float *__restrict__ ge, float rate, float ref, float maxg, long long n,
-                                                       int C, int vec)
-{
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    const long long a = (long long)c * AGC_EX_CHAIN;
-    const long long b = min(n, a + AGC_EX_CHAIN);
-    const long long s = a > AGC_EX_WARM ? a - AGC_EX_WARM : 0;
-    // (the scan's blocks are SCAN_TILE = 1024 samples: pre[j] is the exclusive prefix map of block j)
-    float g = s == 0 ? state_in[0] : agc_apply(pre[s / SCAN_TILE], state_in[0]);
-    g = agc_exact_walk<false>(x, y, s, a, g, rate, ref, maxg, vec);
-    gs[c] = g;
-    g = agc_exact_walk<true>(x, y, a, b, g, rate, ref, maxg, vec);
-    ge[c] = g;
-    if (b == n) state_out[0] = g;
-}
+struct AgcWalk {
+    static constexpr bool GUESS = false;
+    struct Par {
+        const AgcMap *pre;          // exclusive prefix maps of the scan's blocks (SCAN_TILE samples each)
+        const float *state_in;      // [0] the gain carried into the call
+        float *state_out;           // [0] the gain carried out of it, [1] guard flag
+        float rate, ref, maxg;
+    };
+    __device__ static __forceinline__ float2 start(const Par &p, long long s)
+    {
+        const float g0 = p.state_in[0];
+        return make_float2(s == 0 ? g0 : agc_apply(p.pre[s / SCAN_TILE], g0), 0.f);
+    }
+    __device__ static __forceinline__ void carry_out(const Par &p, float2 st) { p.state_out[0] = st.x; }
+    __device__ static __forceinline__ int block(const Par &p, float2 x, float2, int cnt, float2 &st, float2 &out, int mode, unsigned *lat)
+    {
+        const int lane = threadIdx.x & 63;
+        const bool act = lane < cnt;
+        const float g0 = st.x;
+        AgcMap m = agc_identity();
+        if (act) m = agc_sample_map(x.x, x.y, p.rate, p.ref, p.maxg);
+        float gown = agc_apply(agc_wave_exclusive(m), g0);
+        float yr, yi, d;
+        int rounds = 0;
+        for (;;) {
+            ++rounds;
+            yr = x.x * gown;
+            yi = x.y * gown;
+            d = p.rate * (p.ref - ::sqrtf(yr * yr + yi * yi));
+            d = act ? d : 0.0f;
+            const float g2 = agx_scan(d, g0, p.maxg, mode, lat);
+            const bool same = __float_as_uint(g2) == __float_as_uint(gown);
+            gown = g2;
+            if (xw::all(same) || rounds >= xw::MAX_ROUNDS) break;
+        }
+        out = make_float2(yr, yi);
+        float gn = gown + d;
+        if (p.maxg > 0.0f && gn > p.maxg) gn = p.maxg;
+        st.x = xw::lane_of(gn, cnt - 1);
+        return rounds;
+    }
+};
 
-// one round: a chain whose start gain is not its predecessor's end gain is walked again from that
-__global__ void __launch_bounds__(64) agc_exact_fix_kernel(const float2 *__restrict__ x, float2 *__restrict__ y,
-                                                           float *__restrict__ state_out, float *__restrict__ gs,
-                                                           float *__restrict__ ge, float rate, float ref, float maxg,
-                                                           long long n, int C, int last, int vec)
+__global__ void agc_exact_flag_kernel(const unsigned *cnt, float *state_out)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < 1 || c >= C) return;
-    const float gp = ge[c - 1];
-    if (__float_as_uint(gp) == __float_as_uint(gs[c])) return;
-    if (last) { state_out[1] = 1.0f; return; }        // still open after the rounds: the guard flag, the serial kernel follows
-    const long long a = (long long)c * AGC_EX_CHAIN;
-    const long long b = min(n, a + AGC_EX_CHAIN);
-    const float g = agc_exact_walk<true>(x, y, a, b, gp, rate, ref, maxg, vec);
-    gs[c] = gp;
-    ge[c] = g;
-    if (b == n) state_out[0] = g;
+    if (cnt[0] != 0) state_out[1] = 1.0f;        // joints still open after the rounds: the serial kernel follows
 }
 
 __global__ void agc_serial_exact_kernel(const float2 *x, float2 *y, const float *state_in, float *state_out,
-                                        float rate, float ref, float maxg, long long n, int vec)
+                                        float rate, float ref, float maxg, long long n)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     if (state_out[1] == 0.0f) return;
-    const float g = agc_exact_walk<true>(x, y, 0, n, state_in[0], rate, ref, maxg, vec);
+    float g = state_in[0];
+    for (long long i = 0; i < n; ++i) {
+        const float2 v = x[i];
+        float yr, yi;
+        agc_step_exact(v.x, v.y, g, rate, ref, maxg, yr, yi);
+        y[i] = make_float2(yr, yi);
+    }
     state_out[0] = g;
     state_out[1] = 2.0f;  // serial path taken
 }
@@ -280,10 +319,13 @@ int AgcStage::run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, 
     float *sin_ = state.as<float>() + 2 * cur;
     float *sout = state.as<float>() + 2 * (cur ^ 1);
     const int nb = scan_blocks((long long)n);
-    const int C = (int)div_up(n, (size_t)AGC_EX_CHAIN);
+    // ranges: two walkers per SIMD on a large call, multiples of the scan's blocks (the start gains are the blocks' prefixes)
+    size_t lw = (n + (size_t)ex_walkers - 1) / (size_t)ex_walkers;
+    if (lw < 4096) lw = 4096;
+    lw = (lw + SCAN_TILE - 1) / SCAN_TILE * SCAN_TILE;
+    const int W = (int)((n + lw - 1) / lw);
     XR_TRY(aggs.reserve((size_t)(nb + scan_blocks(nb) + 4) * sizeof(AgcMap)));
-    XR_TRY(joints.reserve((size_t)2 * C * sizeof(float)));
-    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    XR_TRY(joints.reserve((size_t)3 * W * sizeof(float2) + ((n >> 6) + 2) * sizeof(float2) + xw::NCNT * sizeof(unsigned)));
     AgcScanF f{in, out, sin_, sout, rate, ref, maxg, (long long)n, 0};
     {
         ProfScope ps(prof, "agc_reduce", s);
@@ -296,13 +338,25 @@ int AgcStage::run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, 
     }
     {
         ProfScope ps(prof, "agc_exact", s);
-        float *gs = joints.as<float>(), *ge = joints.as<float>() + C;
-        hipLaunchKernelGGL(agc_exact_kernel, dim3(div_up((size_t)C, 64)), dim3(64), 0, s, in, out, aggs.as<AgcMap>(), sin_, sout,
-                           gs, ge, rate, ref, maxg, (long long)n, C, vec);
-        for (int r = 0; r <= AGC_EX_ROUNDS && C > 1; ++r)
-            hipLaunchKernelGGL(agc_exact_fix_kernel, dim3(div_up((size_t)C, 64)), dim3(64), 0, s, in, out, sout, gs, ge, rate, ref,
-                               maxg, (long long)n, C, r == AGC_EX_ROUNDS ? 1 : 0, vec);
-        hipLaunchKernelGGL(agc_serial_exact_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg, (long long)n, vec);
+        xw::KArgs<AgcWalk> K{};
+        xw::Args &A = K.a;
+        A.x = in; A.y = out;
+        A.js = joints.as<float2>(); A.je = A.js + W; A.used = A.je + W;
+        A.bs = A.used + W;
+        A.cnt = reinterpret_cast<unsigned *>(A.bs + (n >> 6) + 2);
+        A.n = (long long)n; A.Lw = (int)lw; A.H = AGC_EX_WARM; A.W = W;
+        A.mode = ex_mode; A.prio = 1;
+        K.p = AgcWalk::Par{aggs.as<AgcMap>(), sin_, sout, rate, ref, maxg};
+        hipLaunchKernelGGL(xw::zero_kernel<AgcWalk>, dim3(1), dim3(64), 0, s, A.cnt, xw::NCNT);
+        hipLaunchKernelGGL(xw::main_kernel<AgcWalk>, dim3(W), dim3(64), 0, s, K);
+        hipLaunchKernelGGL(xw::used_kernel<AgcWalk>, dim3(div_up((size_t)W, 256)), dim3(256), 0, s, A);
+        if (W > 1) {
+            for (int r = 0; r < AGC_EX_ROUNDS; ++r) hipLaunchKernelGGL(xw::fix_kernel<AgcWalk>, dim3(W - 1), dim3(64), 0, s, K, 0);
+            hipLaunchKernelGGL(xw::zero_kernel<AgcWalk>, dim3(1), dim3(64), 0, s, A.cnt, 1);
+            hipLaunchKernelGGL(xw::fix_kernel<AgcWalk>, dim3(W - 1), dim3(64), 0, s, K, 1);
+            hipLaunchKernelGGL(agc_exact_flag_kernel, dim3(1), dim3(1), 0, s, A.cnt, sout);
+        }
+        hipLaunchKernelGGL(agc_serial_exact_kernel, dim3(1), dim3(1), 0, s, in, out, sin_, sout, rate, ref, maxg, (long long)n);
     }
     XR_HIP(hipGetLastError());
     cur ^= 1;

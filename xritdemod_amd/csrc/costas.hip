@@ -620,10 +620,11 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
     {
         int cus = 0, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            ex_walkers = 4 * cus;
+            ex_walkers = 8 * cus;
         if (const char *e = getenv("XRIT_CX_WALKERS")) { const int v = atoi(e); if (v > 0) ex_walkers = v; }
     }
-    ex_fast = getenv("XRIT_CX_NO_FAST") == nullptr;
+    if (const char *e = getenv("XRIT_CX_MODE")) ex_mode = atoi(e) & 3;
+    if (const char *e = getenv("XRIT_CX_PRIO")) ex_prio = atoi(e) != 0;
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;
     L = (L + COSTAS_CT - 1) / COSTAS_CT * COSTAS_CT;   // whole LDS tiles per chain
@@ -965,9 +966,11 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         XR_TRY(finish_exact(s, prof, redone));
         ex_blocks += h_xcnt ? h_xcnt[1] : 0;
         ex_picard += h_xcnt ? h_xcnt[2] : 0;
+        ex_segs += h_xcnt ? h_xcnt[4] : 0;
+        ex_fallbacks += h_xcnt ? h_xcnt[5] : 0;
         if (trace_env && h_xcnt)
-            fprintf(stderr, "[xrit] costas exact: %d walkers, %u blocks, %.2f rounds per block, %u at the round limit, %u joints open after the batch, %d more rounds\n",
-                    ex_W, h_xcnt[1], h_xcnt[1] ? (double)h_xcnt[2] / h_xcnt[1] : 0.0, h_xcnt[3], ex_open, ex_rounds);
+            fprintf(stderr, "[xrit] costas exact: %d walkers, %u blocks, %.2f rounds per block, %u at the round limit, %u joints open after the batch, %d more rounds; lattice: %u segments, %u scans fell back\n",
+                    ex_W, h_xcnt[1], h_xcnt[1] ? (double)h_xcnt[2] / h_xcnt[1] : 0.0, h_xcnt[3], ex_open, ex_rounds, h_xcnt[4], h_xcnt[5]);
     }
     cur ^= 1;     // the carried state now is the one the final pass left
     return XRIT_OK;

@@ -30,23 +30,11 @@
 
 #include <cstdlib>
 #include "exact_sincos.h"
+#include "exact_walk.h"
 
 namespace xrit {
 
-namespace {
-
-constexpr int CX_MAX_ROUNDS = 72;       // lanes 0..j are exact after j Picard rounds: 64 always suffice
-
-__device__ __forceinline__ float cx_shr1(float v, float first)
-{
-    // lane i <- lane i - 1, lane 0 <- first
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-
-__device__ __forceinline__ float cx_lane(float v, int src)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
+namespace cx {
 
 // the loop filters of ONE sample, literally (xo_costas_work: the phase takes the unclamped frequency)
 __device__ __forceinline__ void cx_filters(float &phase, float &freq, float ae, float be)
@@ -64,11 +52,11 @@ __device__ __forceinline__ void cx_filters(float &phase, float &freq, float ae, 
 __device__ __forceinline__ void cx_scan_general(float ae, float be, float ph0, float fr0, float &pv, float &fv)
 {
     const int lane = threadIdx.x & 63;
-    const float ash = cx_shr1(ae, 0.f), bsh = cx_shr1(be, 0.f);
+    const float ash = xw::shr1(ae, 0.f), bsh = xw::shr1(be, 0.f);
     pv = ph0;
     fv = fr0;
     for (int it = 0; it < 63; ++it) {
-        float ps = cx_shr1(pv, ph0), fs = cx_shr1(fv, fr0);
+        float ps = xw::shr1(pv, ph0), fs = xw::shr1(fv, fr0);
         cx_filters(ps, fs, ash, bsh);
         if (lane > 0) { pv = ps; fv = fs; }
     }
@@ -78,7 +66,7 @@ __device__ __forceinline__ void cx_scan_general(float ae, float be, float ph0, f
 // would have acted (it does so on these very values: up to the first sample at which one acts they are the serial loop's).
 __device__ __forceinline__ void cx_scan_fast(float ae, float be, float ph0, float fr0, float &pv, float &fv)
 {
-    const float ash = cx_shr1(ae, 0.f), bsh = cx_shr1(be, 0.f);
+    const float ash = xw::shr1(ae, 0.f), bsh = xw::shr1(be, 0.f);
     float t = ph0;
     pv = ph0;
     fv = fr0;
@@ -97,23 +85,72 @@ __device__ __forceinline__ void cx_scan_fast(float ae, float be, float ph0, floa
                  : "v"(bsh), "v"(ash));
 }
 
-__device__ __forceinline__ bool cx_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
-__device__ __forceinline__ bool cx_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-__device__ __forceinline__ void cx_scan(float ae, float be, float ph0, float fr0, float &pv, float &fv, bool fast_ok)
+// ---- the scan on the float32 LATTICE, log depth ------------------------------------------------------------------------------
+// Inside one binade a float is an integer multiple of its ulp, and adding a small increment to it moves it by the increment
+// rounded to that lattice -- the same whole number of ulps whatever the running value is (ties and binade changes aside).  So
+// the two recurrences become integer prefix sums: lane n turns its increment into lattice units against the block's BASE
+// state (ord(fl(base + inc)) - ord(base): one float addition, the rounding is the hardware's), two DPP prefix sums give every
+// lane its candidate state.  The candidates are then CERTIFIED, not trusted: every lane runs the literal step (cx_filters: the
+// serial loop's own additions, wrap and limiter) from its candidate state and compares the result with its neighbour's
+// candidate bit for bit.  Up to the first lane whose step does not reproduce, the states are the serial loop's; that lane's
+// literal result is the exact state behind it and becomes the base of the next segment (a tie, a phase that crosses a power
+// of two, a wrap at +-2 pi: one more segment each; a phase that hovers around zero changes binade all the time and falls
+// back to the systolic scan).  ~60 instructions per segment against 250 for the systolic scan.
+constexpr int CX_MAX_SEG = 4;
+
+
+// true: (pv, fv) hold the exact state in front of every lane's sample.  *segs: segments used (statistics).
+__device__ __forceinline__ bool cx_scan_lattice(float ae, float be, float ph0, float fr0, float &pv, float &fv, int *segs)
 {
-    if (fast_ok) {
+    const int lane = threadIdx.x & 63;
+    float bph = ph0, bfr = fr0;           // the exact state in front of lane s
+    int s = 0;
+    pv = ph0;
+    fv = fr0;
+    for (int seg = 0; seg < CX_MAX_SEG; ++seg) {
+        const bool in = lane >= s;
+        const int of0 = xw::ord(bfr), op0 = xw::ord(bph);
+        const int dF = in ? xw::ord(bfr + be) - of0 : 0;
+        const int SF = xw::prefix(dF);
+        const float fnext = xw::inv(of0 + SF), fown = xw::inv(of0 + SF - dF);
+        const int d1 = in ? xw::ord(bph + fnext) - op0 : 0;
+        const int d2 = in ? xw::ord(bph + ae) - op0 : 0;
+        const int SP = xw::prefix(d1 + d2);
+        const float pnext = xw::inv(op0 + SP), pown = xw::inv(op0 + SP - d1 - d2);
+        float lp = pown, lf = fown;
+        cx_filters(lp, lf, ae, be);
+        const bool ok = __float_as_uint(lp) == __float_as_uint(pnext) && __float_as_uint(lf) == __float_as_uint(fnext);
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(in && !ok);
+        const int k = bad ? (int)__builtin_ctzll(bad) : 64;          // the first lane whose step the lattice did not reproduce
+        if (in && lane <= k) { pv = pown; fv = fown; }
+        if (segs) *segs = seg + 1;
+        if (k >= 63) return true;         // (k == 63: its own state is certified; the state behind it is the caller's literal step)
+        bph = xw::lane_of(lp, k);
+        bfr = xw::lane_of(lf, k);
+        s = k + 1;
+    }
+    return false;
+}
+
+
+// mode bit 0: the three-instruction systolic round where it is valid; bit 1: the lattice scan first
+__device__ __forceinline__ void cx_scan(float ae, float be, float ph0, float fr0, float &pv, float &fv, int mode, unsigned *stat)
+{
+    if (mode & 2) {
+        int segs = 0;
+        const bool ok = cx_scan_lattice(ae, be, ph0, fr0, pv, fv, &segs);
+        if (stat) { stat[0] += (unsigned)segs; stat[1] += ok ? 0u : 1u; }
+        if (ok) return;
+    }
+    if (mode & 1) {
         cx_scan_fast(ae, be, ph0, fr0, pv, fv);
         // would the wrap or the limiter have acted anywhere?  (on the state in front of every sample and on the one behind
         // the last: lane 63's own step)
-        float np = pv, nf = fv;
-        {
-            const float f1 = fv + be;
-            np = (pv + f1) + ae;
-            nf = f1;
-        }
+        const float nf = fv + be;
+        const float np = (pv + nf) + ae;
         const bool out = !(fabsf(pv) <= XR_TWOPI_F) || !(fabsf(fv) <= 1.0f) || !(fabsf(np) <= XR_TWOPI_F) || !(fabsf(nf) <= 1.0f);
-        if (!cx_any(out)) return;
+        if (!xw::any(out)) return;
     }
     cx_scan_general(ae, be, ph0, fr0, pv, fv);
 }
@@ -123,7 +160,7 @@ struct CxGains { float alpha, beta; };
 // One block of up to 64 samples from (ph, fr): lane n's sample x, the first guess ya (the approximate output), cnt valid
 // lanes.  Leaves the exact outputs in (yr, yi) and the state behind the block's last sample in (ph, fr).
 // Returns the number of Picard rounds (statistics).
-__device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph, float &fr, CxGains g, float &yr, float &yi, bool fast_ok)
+__device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph, float &fr, CxGains g, float &yr, float &yi, int mode, unsigned *stat)
 {
     const int lane = threadIdx.x & 63;
     const bool act = lane < cnt;
@@ -131,7 +168,7 @@ __device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph,
     e = (act && e == e) ? e : 0.0f;
     float ae = g.alpha * e, be = g.beta * e;
     float pv, fv;
-    cx_scan(ae, be, ph, fr, pv, fv, fast_ok);
+    cx_scan(ae, be, ph, fr, pv, fv, mode, stat);
     int rounds = 0;
     for (;;) {
         ++rounds;
@@ -144,124 +181,45 @@ __device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph,
         ae = g.alpha * e;
         be = g.beta * e;
         float p2, f2;
-        cx_scan(ae, be, ph, fr, p2, f2, fast_ok);
+        cx_scan(ae, be, ph, fr, p2, f2, mode, stat);
         const bool same = __float_as_uint(p2) == __float_as_uint(pv) && __float_as_uint(f2) == __float_as_uint(fv);
         pv = p2;
         fv = f2;
-        if (cx_all(same) || rounds >= CX_MAX_ROUNDS) break;
+        if (xw::all(same) || rounds >= xw::MAX_ROUNDS) break;
     }
     // the state behind sample cnt - 1: that lane's own step
     float np = pv, nf = fv;
     cx_filters(np, nf, ae, be);
-    ph = cx_lane(np, cnt - 1);
-    fr = cx_lane(nf, cnt - 1);
+    ph = xw::lane_of(np, cnt - 1);
+    fr = xw::lane_of(nf, cnt - 1);
     return rounds;
 }
 
-struct CxArgs {
-    const float2 *x;        // the loop's input (matched filter output)
-    float2 *y;              // in: the approximate output; out: the exact one
-    const float2 *S;        // approximate chain start states (costas.hip), chains of L samples
-    const float2 *st_in;    // the state carried into the call (exact)
-    float2 *st_out;         // the state carried out of it
-    float2 *js, *je, *used; // per walker: state at the start of its range / at its end / the start state its output belongs to
-    float2 *bs;             // per block of its range: the state behind the block
-    unsigned *cnt;          // [0] joints that did not fit (this round), [1] blocks walked, [2] Picard rounds, [3] non-converged blocks
-    long long n;
-    int L, Lw, H, W;
-    CxGains g;
-    int fast_ok;
-};
 
-// walker w over blocks [from, to) (sample indices, multiples of 64 except the call's end) starting from (ph, fr); outputs
-// are written from `write_from` on.  MEET: stop at the first block boundary where the state equals the record in bs
-// (returns true there); otherwise the records are (re)written.
-template <bool MEET>
-__device__ __forceinline__ bool cx_walk(const CxArgs &A, long long from, long long to, long long write_from, float &ph, float &fr,
-                                        float2 *js_slot, long long js_at)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned blocks = 0, rounds = 0, bad = 0;
-    bool met = false;
-    const long long last = A.n - 1;
-    auto idx_of = [&](long long blk) { const long long i = blk + lane; return i < last ? i : last; };
-    float2 xn = A.x[idx_of(from)], yn = A.y[idx_of(from)];
-    for (long long blk = from; blk < to; blk += 64) {
-        const float2 x = xn, ya = yn;
-        if (blk + 64 < to) { xn = A.x[idx_of(blk + 64)]; yn = A.y[idx_of(blk + 64)]; }
-        const int cnt = (int)min((long long)64, to - blk);
+// the walker framework's policy (exact_walk.h): state = (phase, freq)
+struct CostasWalk {
+    static constexpr bool GUESS = true;        // the approximate output is the first guess of every block
+    struct Par {
+        const float2 *S;        // approximate chain start states (costas.hip), chains of L samples
+        const float2 *st_in;    // the state carried into the call (exact)
+        float2 *st_out;         // the state carried out of it
+        int L;
+        CxGains g;
+    };
+    __device__ static __forceinline__ float2 start(const Par &p, long long s)
+    {
+        const float2 st = s == 0 ? p.st_in[0] : p.S[s / p.L];
+        return make_float2(costas_prewrap(st.x), st.y);
+    }
+    __device__ static __forceinline__ void carry_out(const Par &p, float2 st) { p.st_out[0] = st; }
+    __device__ static __forceinline__ int block(const Par &p, float2 x, float2 ya, int cnt, float2 &st, float2 &out, int mode, unsigned *lat)
+    {
         float yr, yi;
-        const int r = cx_block(x, ya, cnt, ph, fr, A.g, yr, yi, A.fast_ok != 0);
-        ++blocks;
-        rounds += (unsigned)r;
-        bad += r >= CX_MAX_ROUNDS ? 1u : 0u;
-        if (blk >= write_from && lane < cnt) A.y[blk + lane] = make_float2(yr, yi);
-        if (js_slot != nullptr && blk + 64 == js_at && lane == 0) *js_slot = make_float2(ph, fr);
-        if (blk >= write_from) {
-            float2 *rec = A.bs + (blk >> 6);
-            if (MEET) {
-                const float2 old = *rec;
-                if (__float_as_uint(old.x) == __float_as_uint(ph) && __float_as_uint(old.y) == __float_as_uint(fr)) { met = true; break; }
-            }
-            if (lane == 0) *rec = make_float2(ph, fr);
-        }
+        const int r = cx_block(x, ya, cnt, st.x, st.y, p.g, yr, yi, mode, lat);
+        out = make_float2(yr, yi);
+        return r;
     }
-    if (lane == 0) {
-        atomicAdd(A.cnt + 1, blocks);
-        atomicAdd(A.cnt + 2, rounds);
-        if (bad) atomicAdd(A.cnt + 3, bad);
-    }
-    return met;
-}
-
-__global__ void __launch_bounds__(64) costas_exact_kernel(CxArgs A)
-{
-    const int w = blockIdx.x;
-    const int lane = threadIdx.x;
-    const long long a = (long long)w * A.Lw;
-    const long long b = min(A.n, a + A.Lw);
-    const long long s = a > A.H ? a - A.H : 0;
-    float2 st = s == 0 ? A.st_in[0] : A.S[s / A.L];
-    float ph = costas_prewrap(st.x), fr = st.y;
-    if (s == a && lane == 0) A.js[w] = make_float2(ph, fr);
-    (void)cx_walk<false>(A, s, b, a, ph, fr, s < a ? A.js + w : nullptr, a);
-    if (lane == 0) {
-        A.je[w] = make_float2(ph, fr);
-        if (b == A.n) A.st_out[0] = make_float2(ph, fr);
-    }
-}
-
-// the hand-over of the joints' start states: used[w] = js[w] (a kernel of its own: every walker has finished)
-__global__ void costas_exact_used_kernel(CxArgs A)
-{
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < A.W) A.used[w] = A.js[w];
-    if (w == 0) A.cnt[0] = 0;
-}
-
-// one round over the joints.  count_only: just count the joints that do not fit.
-__global__ void __launch_bounds__(64) costas_exact_fix_kernel(CxArgs A, int count_only)
-{
-    const int w = blockIdx.x + 1;
-    const int lane = threadIdx.x;
-    const float2 prev = A.je[w - 1], mine = A.used[w];
-    if (__float_as_uint(prev.x) == __float_as_uint(mine.x) && __float_as_uint(prev.y) == __float_as_uint(mine.y)) return;
-    if (lane == 0) atomicAdd(A.cnt + 0, 1u);
-    if (count_only) return;
-    const long long a = (long long)w * A.Lw;
-    const long long b = min(A.n, a + A.Lw);
-    float ph = prev.x, fr = prev.y;
-    const bool met = cx_walk<true>(A, a, b, a, ph, fr, nullptr, 0);
-    if (lane == 0) {
-        A.used[w] = prev;
-        if (!met) {
-            A.je[w] = make_float2(ph, fr);
-            if (b == A.n) A.st_out[0] = make_float2(ph, fr);
-        }
-    }
-}
-
-__global__ void costas_exact_zero_kernel(unsigned *cnt) { if (threadIdx.x < 4) cnt[threadIdx.x] = 0; }
+};
 
 __global__ void loop_sincosf_kernel(const float *__restrict__ x, float *__restrict__ sn, float *__restrict__ cs, long long n)
 {
@@ -273,7 +231,8 @@ __global__ void loop_sincosf_kernel(const float *__restrict__ x, float *__restri
     cs[i] = c;
 }
 
-}  // namespace
+}  // namespace cx
+using namespace cx;
 
 int launch_loop_sincosf(const float *d_x, float *d_sin, float *d_cos, size_t n, hipStream_t s)
 {
@@ -308,6 +267,24 @@ int CostasStage::exact_plan(size_t n, int *Lw, int *W, int *H) const
     return XRIT_OK;
 }
 
+static xw::KArgs<CostasWalk> cx_args(CostasStage &c, int Lw, int W, int H)
+{
+    xw::KArgs<CostasWalk> K{};
+    xw::Args &A = K.a;
+    A.x = c.job.in; A.y = c.job.out;
+    A.js = c.xj.as<float2>(); A.je = A.js + W; A.used = A.je + W;
+    A.bs = c.xbs.as<float2>(); A.cnt = c.xcnt.as<unsigned>();
+    A.n = (long long)c.job.n; A.Lw = Lw; A.H = H; A.W = W;
+    A.mode = c.ex_mode;
+    A.prio = c.ex_prio;
+    K.p.S = c.S.as<float2>();
+    K.p.st_in = c.state.as<float2>() + c.cur;
+    K.p.st_out = c.state.as<float2>() + (c.cur ^ 1);
+    K.p.L = c.L;
+    K.p.g = CxGains{c.gains.alpha, c.gains.beta};
+    return K;
+}
+
 int CostasStage::enqueue_exact(hipStream_t s, Profiler *prof)
 {
     if (job.n == 0) return XRIT_OK;
@@ -315,33 +292,26 @@ int CostasStage::enqueue_exact(hipStream_t s, Profiler *prof)
     XR_TRY(exact_plan(job.n, &Lw, &W, &H));
     XR_TRY(xj.reserve((size_t)3 * W * sizeof(float2)));
     XR_TRY(xbs.reserve(((job.n >> 6) + 2) * sizeof(float2)));
-    XR_TRY(xcnt.reserve(8 * sizeof(unsigned)));
+    XR_TRY(xcnt.reserve(xw::NCNT * sizeof(unsigned)));
     if (!h_xcnt) XR_HIP(hipHostMalloc((void **)&h_xcnt, 64));
-    CxArgs A{};
-    A.x = job.in; A.y = job.out; A.S = S.as<float2>();
-    A.st_in = state.as<float2>() + cur; A.st_out = state.as<float2>() + (cur ^ 1);
-    A.js = xj.as<float2>(); A.je = A.js + W; A.used = A.je + W;
-    A.bs = xbs.as<float2>(); A.cnt = xcnt.as<unsigned>();
-    A.n = (long long)job.n; A.L = L; A.Lw = Lw; A.H = H; A.W = W;
-    A.g = CxGains{gains.alpha, gains.beta};
-    A.fast_ok = ex_fast ? 1 : 0;
+    const xw::KArgs<CostasWalk> K = cx_args(*this, Lw, W, H);
     ex_W = W;
     ex_rounds = 0;
     {
         ProfScope ps(prof, "costas_exact", s);
-        hipLaunchKernelGGL(costas_exact_zero_kernel, dim3(1), dim3(64), 0, s, A.cnt);
-        hipLaunchKernelGGL(costas_exact_kernel, dim3(W), dim3(64), 0, s, A);
-        hipLaunchKernelGGL(costas_exact_used_kernel, dim3(div_up((size_t)W, 256)), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(xw::zero_kernel<CostasWalk>, dim3(1), dim3(64), 0, s, K.a.cnt, xw::NCNT);
+        hipLaunchKernelGGL(xw::main_kernel<CostasWalk>, dim3(W), dim3(64), 0, s, K);
+        hipLaunchKernelGGL(xw::used_kernel<CostasWalk>, dim3(div_up((size_t)W, 256)), dim3(256), 0, s, K.a);
     }
     if (W > 1) {
         ProfScope ps(prof, "costas_exact_fix", s);
         // (rounds enqueued with the call: without a warm-up the first one does the settling, the second catches the joints
         // whose predecessor's end state that changed; the host looks at what is left)
-        for (int r = 0; r < (H == 0 ? 3 : 2); ++r) hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 0);
-        hipLaunchKernelGGL(costas_exact_zero_kernel, dim3(1), dim3(1), 0, s, A.cnt);
-        hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 1);
+        for (int r = 0; r < (H == 0 ? 3 : 2); ++r) hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 0);
+        hipLaunchKernelGGL(xw::zero_kernel<CostasWalk>, dim3(1), dim3(64), 0, s, K.a.cnt, 1);
+        hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 1);
     }
-    XR_HIP(hipMemcpyAsync(h_xcnt, xcnt.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(h_xcnt, xcnt.p, xw::NCNT * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     XR_HIP(hipGetLastError());
     ex_args_valid = true;
     return XRIT_OK;
@@ -356,23 +326,16 @@ int CostasStage::finish_exact(hipStream_t s, Profiler *prof, bool *redone)
     if (ex_W <= 1) return XRIT_OK;
     int Lw = 0, W = 0, H = 0;
     XR_TRY(exact_plan(job.n, &Lw, &W, &H));
-    CxArgs A{};
-    A.x = job.in; A.y = job.out; A.S = S.as<float2>();
-    A.st_in = state.as<float2>() + cur; A.st_out = state.as<float2>() + (cur ^ 1);
-    A.js = xj.as<float2>(); A.je = A.js + W; A.used = A.je + W;
-    A.bs = xbs.as<float2>(); A.cnt = xcnt.as<unsigned>();
-    A.n = (long long)job.n; A.L = L; A.Lw = Lw; A.H = H; A.W = W;
-    A.g = CxGains{gains.alpha, gains.beta};
-    A.fast_ok = ex_fast ? 1 : 0;
+    const xw::KArgs<CostasWalk> K = cx_args(*this, Lw, W, H);
     while (h_xcnt[0] != 0) {
         if (ex_rounds > W + 4) { set_error("Costas loop (exact): %u joints still open after %d rounds", h_xcnt[0], ex_rounds); return XRIT_E_NOT_CONVERGED; }
         if (redone) *redone = true;
         ++ex_rounds;
         ProfScope ps(prof, "costas_exact_fix", s);
-        hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 0);
-        hipLaunchKernelGGL(costas_exact_zero_kernel, dim3(1), dim3(1), 0, s, A.cnt);
-        hipLaunchKernelGGL(costas_exact_fix_kernel, dim3(W - 1), dim3(64), 0, s, A, 1);
-        XR_HIP(hipMemcpyAsync(h_xcnt, xcnt.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 0);
+        hipLaunchKernelGGL(xw::zero_kernel<CostasWalk>, dim3(1), dim3(64), 0, s, K.a.cnt, 1);
+        hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 1);
+        XR_HIP(hipMemcpyAsync(h_xcnt, xcnt.p, xw::NCNT * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         XR_HIP(hipStreamSynchronize(s));
     }
     return XRIT_OK;

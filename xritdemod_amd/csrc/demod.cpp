@@ -58,6 +58,7 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
+    hipStream_t stream_c = nullptr;     // cfg.front_exact = 2: the Costas loops (their exact walkers are latency, not work) beside the next front end
     // bursts whose Costas loop is a handful of small kernels (few circuit-rate samples: large decimations) run that loop on the
     // walker stream their own walkers will take, beside the next burst's decimator instead of behind it (ov_service)
     size_t costas_own_stream_below = 16u << 20;                     // circuit-rate samples per burst (XRIT_OV_CSTREAM_BELOW)
@@ -282,6 +283,7 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         // (cfg.front_exact = 2: both filters summed in the CPU chain's order, the AGC and the Costas loop walked literally --
         // the front end bit for bit the CPU chain's through the Costas loop; fir.hip, agc.hip, costas_exact.hip)
         d->dec.exact = d->rrc.exact = d->agc.exact = d->costas.exact = cfg->front_exact == 2;
+        if (cfg->front_exact == 2 && !getenv("XRIT_NO_COSTAS_STREAM") && create_own_queue_stream(&d->stream_c) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
         if ((rc = d->rtl.init(cfg->sample_rate)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
@@ -314,10 +316,12 @@ void xrit_demod_destroy(xrit_demod *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream2) (void)hipStreamSynchronize(d->stream2);     // a front end that ran ahead may still be at work
+    if (d->stream_c) (void)hipStreamSynchronize(d->stream_c);
     for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
     if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
+    if (d->stream_c) { (void)hipStreamSynchronize(d->stream_c); (void)hipStreamDestroy(d->stream_c); }
     for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
@@ -339,6 +343,7 @@ int xrit_demod_reset(xrit_demod *d, void *stream)
     XR_HIP(hipSetDevice(d->device));
     hipStream_t s = stream ? (hipStream_t)stream : d->stream;
     XR_HIP(hipStreamSynchronize(d->stream2));       // a front end that ran ahead belongs to the stream being left
+    if (d->stream_c) XR_HIP(hipStreamSynchronize(d->stream_c));
     for (auto w : d->stream3) XR_HIP(hipStreamSynchronize(w));      // ... and so do walkers
     if (d->costas.job.n && d->pf_count > 0) {
         // (a Costas loop begun ahead and never looked at: the stage's bookkeeping is brought to an end before its state is reset)
@@ -657,8 +662,11 @@ static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
             // walkers of the burst two in front are on: the loop then runs behind them instead of beside them, and its walkers
             // behind it.  That is what HIP's dealing of streams onto hardware queues had arranged by accident on the first handle
             // of a process, and measured better than a queue of its own: C5 1.08 against 1.11-1.14 ms per burst)
-            f.costas_stream = f.length < d->costas_own_stream_below ? 1 : 0;
-            hipStream_t sc = f.costas_stream ? d->stream3[(d->clock.ov_serial + 1) % XRIT_WALK_STREAMS] : d->stream2;
+            // (round 6, cfg.front_exact = 2: the exact AGC chains and the exact Costas walkers are a wave per SIMD or less for
+            // milliseconds -- latency, not work --, so the Costas loop of burst b runs on a stream of its own beside the front end
+            // of burst b + 1 instead of in front of it)
+            f.costas_stream = d->stream_c ? 2 : (f.length < d->costas_own_stream_below ? 1 : 0);
+            hipStream_t sc = f.costas_stream == 2 ? d->stream_c : f.costas_stream ? d->stream3[(d->clock.ov_serial + 1) % XRIT_WALK_STREAMS] : d->stream2;
             f.c_stream = sc;
             if (f.costas_stream) XR_HIP(hipStreamWaitEvent(sc, d->ev_fe[f.set], 0));
             int rc = costas_enqueue(d, io, sc, prof, &f.slot);
@@ -1285,13 +1293,16 @@ int xrit_costas_set_exact(xrit_costas *c, int exact, int history)
     return XRIT_OK;
 }
 
-int xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds)
+int xrit_costas_exact_stats(xrit_costas *c, uint64_t *blocks, uint64_t *rounds, uint32_t *joints_open, uint32_t *fix_rounds,
+                            uint64_t *lattice_segments, uint64_t *lattice_fallbacks)
 {
     if (!c) { set_error("null argument"); return XRIT_E_INVALID; }
     if (blocks) *blocks = c->st.ex_blocks;
     if (rounds) *rounds = c->st.ex_picard;
     if (joints_open) *joints_open = c->st.ex_open;
     if (fix_rounds) *fix_rounds = (uint32_t)c->st.ex_rounds;
+    if (lattice_segments) *lattice_segments = c->st.ex_segs;
+    if (lattice_fallbacks) *lattice_fallbacks = c->st.ex_fallbacks;
     return XRIT_OK;
 }
 

@@ -92,7 +92,8 @@ struct AgcStage {
     int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
     // cfg.front_exact = 2: chains walked literally from the scan's gains, warmed up until they ARE the serial recurrence (agc.hip)
     bool exact = false;
-    DevBuf joints;   // per chain: gain at the start of its range / at its end
+    DevBuf joints;   // exact_walk.h's joints, block records and counters
+    int ex_walkers = 2048, ex_mode = 3;     // ranges per large call (two walkers per SIMD); scan switches (XRIT_CX_MODE)
     int run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
     // the same in two halves around the kernel that produces `in` (the decimator): fused_begin() before it
     // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
@@ -169,15 +170,18 @@ struct CostasStage {
     // cfg.front_exact = 2 (costas_exact.hip): behind the final pass the output is put ON the serial float32 trajectory by
     // exactly walked, overlapping ranges; finish() closes what joints are still open
     bool exact = false;
-    bool ex_fast = true;            // the three-instruction systolic round where neither wrap nor limiter acts (XRIT_CX_NO_FAST=1: off)
+    int ex_mode = 3;                // bit 0: the three-instruction systolic round where neither wrap nor limiter acts; bit 1: the
+                                    // lattice scan in front of it (XRIT_CX_MODE: A/B runs)
     int ex_hist = -1;               // >= 0: samples of warm-up in front of every range whatever the call (XRIT_CX_HIST); -1: by plan
-    int ex_walkers = 1024;          // ranges per large call: one walker per SIMD (set from the device's CU count in init)
+    int ex_prio = 1;                // the walkers' waves at a raised issue priority (XRIT_CX_PRIO=0: off)
+    int ex_walkers = 2048;          // ranges per large call: two walkers per SIMD (set from the device's CU count in init; one wave
+                                    // issues a dependent instruction every ~7 cycles, two share a SIMD's port almost for free)
     DevBuf xj, xbs, xcnt;           // joints (start / end / used), block records, counters
     unsigned *h_xcnt = nullptr;     // pinned: [0] joints open, [1] blocks, [2] Picard rounds, [3] blocks that hit the round limit
     int ex_W = 0, ex_rounds = 0;
     bool ex_args_valid = false;
     unsigned ex_open = 0, ex_nonconverged = 0;
-    unsigned long long ex_blocks = 0, ex_picard = 0;    // totals over the handle's calls (statistics)
+    unsigned long long ex_blocks = 0, ex_picard = 0, ex_segs = 0, ex_fallbacks = 0;    // totals over the handle's calls (statistics)
     int exact_plan(size_t n, int *Lw, int *W, int *H) const;
     int enqueue_exact(hipStream_t s, Profiler *prof);
     int finish_exact(hipStream_t s, Profiler *prof, bool *redone);
