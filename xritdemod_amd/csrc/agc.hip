@@ -263,7 +263,7 @@ struct AgcWalk {
         return make_float2(s == 0 ? g0 : agc_apply(p.pre[s / SCAN_TILE], g0), 0.f);
     }
     __device__ static __forceinline__ void carry_out(const Par &p, float2 st) { p.state_out[0] = st.x; }
-    __device__ static __forceinline__ int block(const Par &p, float2 x, float2, int cnt, float2 &st, float2 &out, int mode, unsigned *lat)
+    __device__ static __forceinline__ int block(const Par &p, float2 x, float2, int cnt, float2 &st, float2 &out, int mode, unsigned *lat, float &)
     {
         const int lane = threadIdx.x & 63;
         const bool act = lane < cnt;

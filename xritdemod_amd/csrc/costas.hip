@@ -623,7 +623,7 @@ int CostasStage::init(float loop_bw, int chain_len, int max_passes_)
             ex_walkers = 8 * cus;
         if (const char *e = getenv("XRIT_CX_WALKERS")) { const int v = atoi(e); if (v > 0) ex_walkers = v; }
     }
-    if (const char *e = getenv("XRIT_CX_MODE")) ex_mode = atoi(e) & 3;
+    if (const char *e = getenv("XRIT_CX_MODE")) ex_mode = atoi(e) & 7;        // (bit 2: first guesses without the phase-offset correction)
     if (const char *e = getenv("XRIT_CX_PRIO")) ex_prio = atoi(e) != 0;
     gains = costas_gains(loop_bw);
     L = chain_len > 0 ? chain_len : 256;

@@ -160,11 +160,17 @@ struct CxGains { float alpha, beta; };
 // One block of up to 64 samples from (ph, fr): lane n's sample x, the first guess ya (the approximate output), cnt valid
 // lanes.  Leaves the exact outputs in (yr, yi) and the state behind the block's last sample in (ph, fr).
 // Returns the number of Picard rounds (statistics).
-__device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph, float &fr, CxGains g, float &yr, float &yi, int mode, unsigned *stat)
+// dphi (in / out): how far the exact phase was from the approximate one over the block before -- the approximate output is a
+// rotation of the exact one by that angle, which moves slowly (it is what the chains' hand-offs left, forgotten over ~600
+// samples): corrected for it, the first guess of the detector outputs is the serial loop's in most blocks and one Picard round
+// confirms it (1.2 rounds per block instead of 2.1).
+__device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph, float &fr, CxGains g, float &yr, float &yi, int mode, unsigned *stat,
+                                        float &dphi)
 {
     const int lane = threadIdx.x & 63;
     const bool act = lane < cnt;
-    float e = bclip(ya.x * ya.y, 1.0f);
+    // y_exact = y_approx e^{-j dphi}:  Re Im moves by dphi (Im^2 - Re^2)
+    float e = bclip((mode & 4) ? ya.x * ya.y : ya.x * ya.y + dphi * (ya.y * ya.y - ya.x * ya.x), 1.0f);
     e = (act && e == e) ? e : 0.0f;
     float ae = g.alpha * e, be = g.beta * e;
     float pv, fv;
@@ -186,6 +192,12 @@ __device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph,
         pv = p2;
         fv = f2;
         if (xw::all(same) || rounds >= xw::MAX_ROUNDS) break;
+    }
+    {
+        // the angle between the exact output and the approximate one, over this block: the next block's correction
+        const float num = xw::wave_sum(act ? yr * ya.y - yi * ya.x : 0.0f), den = xw::wave_sum(act ? ya.x * ya.x + ya.y * ya.y : 0.0f);
+        dphi = den > 0.0f ? num / den : 0.0f;
+        dphi = fabsf(dphi) < 1e-3f ? dphi : 0.0f;        // (a guess's ingredient: anything wild is dropped)
     }
     // the state behind sample cnt - 1: that lane's own step
     float np = pv, nf = fv;
@@ -212,10 +224,10 @@ struct CostasWalk {
         return make_float2(costas_prewrap(st.x), st.y);
     }
     __device__ static __forceinline__ void carry_out(const Par &p, float2 st) { p.st_out[0] = st; }
-    __device__ static __forceinline__ int block(const Par &p, float2 x, float2 ya, int cnt, float2 &st, float2 &out, int mode, unsigned *lat)
+    __device__ static __forceinline__ int block(const Par &p, float2 x, float2 ya, int cnt, float2 &st, float2 &out, int mode, unsigned *lat, float &aux)
     {
         float yr, yi;
-        const int r = cx_block(x, ya, cnt, st.x, st.y, p.g, yr, yi, mode, lat);
+        const int r = cx_block(x, ya, cnt, st.x, st.y, p.g, yr, yi, mode, lat, aux);
         out = make_float2(yr, yi);
         return r;
     }

@@ -43,6 +43,14 @@ __device__ __forceinline__ float inv(int o)
 {
     return __int_as_float(o >= 0 ? o : (int)(0x80000000u - (unsigned)o));
 }
+// sum over the 64 lanes, the same value in every lane (a guess's ingredient: the order of the additions does not matter)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define XW_ADD(CTRL, RM) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xf, false))
+    XW_ADD(0x111, 0xf); XW_ADD(0x112, 0xf); XW_ADD(0x114, 0xf); XW_ADD(0x118, 0xf); XW_ADD(0x142, 0xa); XW_ADD(0x143, 0xc);
+#undef XW_ADD
+    return lane_of(v, 63);
+}
 // inclusive prefix sum over the 64 lanes (rows of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2..3)
 __device__ __forceinline__ int prefix(int v)
 {
@@ -88,6 +96,7 @@ __device__ __forceinline__ bool walk(const KArgs<P> &K, long long from, long lon
     unsigned blocks = 0, rounds = 0, bad = 0;
     unsigned lat[2] = {0, 0};          // lattice segments, scans that fell back
     bool met = false;
+    float aux = 0.f;                   // the policy's scratch from block to block (never part of the state)
     const long long last = A.n - 1;
     auto idx_of = [&](long long blk) { const long long i = blk + lane; return i < last ? i : last; };
     float2 xn = A.x[idx_of(from)], yn = make_float2(0.f, 0.f);
@@ -100,7 +109,7 @@ __device__ __forceinline__ bool walk(const KArgs<P> &K, long long from, long lon
         }
         const int cnt = (int)min((long long)64, to - blk);
         float2 out;
-        const int r = P::block(K.p, x, ya, cnt, st, out, A.mode, lat);
+        const int r = P::block(K.p, x, ya, cnt, st, out, A.mode, lat, aux);
         ++blocks;
         rounds += (unsigned)r;
         bad += r >= MAX_ROUNDS ? 1u : 0u;

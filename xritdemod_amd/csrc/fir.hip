@@ -133,7 +133,7 @@ template <bool MF> __device__ __forceinline__ int fir_mf_pos(int q) { return MF 
 #ifndef XRIT_FE_PRIO
 #define XRIT_FE_PRIO 1
 #endif
-template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1, bool MF = false>
+template <int RC, bool PAD, int TYPE, int APL = 0, int TS = 0, int DS = 1, bool MF = false, bool EX = false>
 __global__ void __launch_bounds__(256)
 fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, float2 *__restrict__ out,
                  const float *__restrict__ g, int T, int D, int Wpad, long long n_out, long long n_in,
@@ -292,6 +292,43 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
             }
             i += run;
             off += D + 1;
+        }
+    } else if (EX) {
+        // cfg.front_exact = 2, windows that need no skew: the CPU chain's summation order with the window walk SHARED by the
+        // lane's RC outputs.  Output c takes window sample i with tap index t = i - c D; the CPU chain adds the products into
+        // four partial sums by t mod 4, each in order of t.  Here the sums are kept by i mod 4 -- the same four sets of terms in
+        // the same order, labelled (c D) mod 4 further on -- and the labels are put right in the final (s0 + s1) + (s2 + s3).
+        // Window samples outside an output's taps meet a zero tap: +0 added to a sum that started at +0 changes nothing (finite
+        // input).  Separate v_pk_mul_f32 / v_pk_add_f32 (-ffp-contract=off), an LDS read feeds RC of each.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f a[RC][4];
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[c][j] = (v2f){0.f, 0.f};
+        for (int i = 0; i < Wpad; i += 4) {
+            const float2 q0 = w[i], q1 = w[i + 1], q2 = w[i + 2], q3 = w[i + 3];
+            const v2f x0 = {q0.x, q0.y}, x1 = {q1.x, q1.y}, x2 = {q2.x, q2.y}, x3 = {q3.x, q3.y};
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const float *gc = g + c * Wpad + i;
+                const float t0 = gc[0], t1 = gc[1], t2 = gc[2], t3 = gc[3];
+                const v2f p0 = x0 * t0, p1 = x1 * t1, p2 = x2 * t2, p3 = x3 * t3;
+                a[c][0] = a[c][0] + p0;
+                a[c][1] = a[c][1] + p1;
+                a[c][2] = a[c][2] + p2;
+                a[c][3] = a[c][3] + p3;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int sh = (c * D) & 3;           // wave-uniform
+            v2f r;
+            if (sh == 0) r = (a[c][0] + a[c][1]) + (a[c][2] + a[c][3]);
+            else if (sh == 1) r = (a[c][1] + a[c][2]) + (a[c][3] + a[c][0]);
+            else if (sh == 2) r = (a[c][2] + a[c][3]) + (a[c][0] + a[c][1]);
+            else r = (a[c][3] + a[c][0]) + (a[c][1] + a[c][2]);
+            acc[c] = make_float2(r.x, r.y);
         }
     } else {
         for (int i = 0; i < Wpad; i += 4) {
@@ -914,7 +951,26 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
         else if (type == XRIT_SAMPLE_S16IQ) XR_EX_GO(XRIT_SAMPLE_S16IQ, PD);  \
         else XR_EX_GO(XRIT_SAMPLE_S8IQ, PD);                                  \
     } while (0)
-            if (ex_pad) XR_EX_TY(true);
+            if (!pad && threads % 64 == 0) {
+                // (windows that need no skew: the window walk shared by a lane's RC outputs, fir_decim_kernel<..., EX>)
+                const AgcEpilogue none{nullptr, nullptr, 0.f, 0.f, 0.f};
+                const AgcFill af{};
+                const unsigned blk = div_up(n_out, (size_t)threads * RC);
+#define XR_EXS_GO(RCV, TY)                                                                                                     \
+    hipLaunchKernelGGL((fir_decim_kernel<RCV, false, TY, 0, 0, 1, false, true>), dim3(blk), dim3(threads), lds_bytes, s, in, h, out, \
+                       g.as<float>(), T, D, Wpad, (long long)n_out, (long long)n_in, tile_len, stat, statL | (prio << 16), none, af, hn)
+#define XR_EXS_TY(RCV)                                                          \
+    do {                                                                        \
+        if (type == XRIT_SAMPLE_FLOATIQ) XR_EXS_GO(RCV, XRIT_SAMPLE_FLOATIQ);   \
+        else if (type == XRIT_SAMPLE_S16IQ) XR_EXS_GO(RCV, XRIT_SAMPLE_S16IQ);  \
+        else XR_EXS_GO(RCV, XRIT_SAMPLE_S8IQ);                                  \
+    } while (0)
+                if (RC == 5) XR_EXS_TY(5);
+                else XR_EXS_TY(3);
+#undef XR_EXS_TY
+#undef XR_EXS_GO
+            }
+            else if (ex_pad) XR_EX_TY(true);
             else XR_EX_TY(false);
 #undef XR_EX_TY
 #undef XR_EX_GO
