@@ -116,6 +116,122 @@ def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev,
         dist.destroy_process_group()
 
 
+# ---- the alternative legs: the same stream from its first burst through ANOTHER configuration, never `value`
+LEGS = {
+    "parity_mode": dict(clock_exact=0, front_exact=2, steps=None, ahead=2,
+                        what="cfg.front_exact = 2 (opt-in, round 6): the front end bit for bit the CPU chain's through the Costas loop -- "
+                             "both filters summed in the CPU chain's order without FMA, the AGC and the Costas loop walked exactly "
+                             "(csrc/exact_walk.h) --; the clock recovery is the default's, fed like `value`"),
+    "exact_mode": dict(clock_exact=1, front_exact=0, steps=5, ahead=1,
+                       what="cfg.clock_exact = 1: clock recovery relayed to closure, symbols bit-identical to the serial "
+                            "float32 recurrence on this chain's Costas output"),
+    "fast_mode": dict(clock_exact=-2, front_exact=0, steps=10, ahead=1,
+                      what="cfg.clock_exact = -2 (the default of rounds 2-3): hand-off passes only, five on this signal, "
+                           "relayed only when they stall; soft symbols 2.2e-4 .. 2.6e-4 rms from the CPU chain"),
+    "quick_mode": dict(clock_exact=-3, front_exact=0, steps=10, ahead=1,
+                       what="cfg.clock_exact = -3 (round 4): the default's relay with the passes in front of its last walked "
+                            "approximately (one guess round, then two; no verification, nothing stored); soft symbols "
+                            "1.15e-4 rms from the serial trajectory"),
+}
+
+
+def run_leg(key, xa, torch, cfg_of, bursts, nbuf, n_burst, soft, cap, stream, dev, K, prefetch, generate):
+    """One alternative leg on a handle of its own (in this process).  Returns (result dict, soft symbols of burst 0, of burst 1)."""
+    leg = LEGS[key]
+    xd = xa.Demodulator(cfg_of(clock_exact=leg["clock_exact"], front_exact=leg["front_exact"]))
+    ahead_n = max(1, min(leg["ahead"], xd.prefetch_depth(n_burst)))
+    Kx, Wx = min(K, leg["steps"] or K), 2
+    if generate is not None:
+        for b in range(min(Wx + Kx, nbuf)):
+            generate(b)
+    torch.cuda.synchronize(dev)
+    closed, rp, cp = True, [], []
+    s0 = s1 = None
+    for b in range(Wx):
+        ns = xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
+        if b == 0:
+            s0 = soft[:ns].clone()
+        if b == 1 and leg["front_exact"]:
+            s1 = soft[:ns].clone()
+    torch.cuda.synchronize(dev)
+    x0 = time.perf_counter()
+    # (streamed like the headline: inputs registered ahead of their calls)
+    if prefetch:
+        for q in range(min(ahead_n, Kx)):
+            xd.prefetch_device(bursts[(Wx + q) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+    sx = None
+    for b in range(Wx, Wx + Kx):
+        if prefetch and b + ahead_n < Wx + Kx:
+            xd.prefetch_device(bursts[(b + ahead_n) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
+        xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
+        sx = xd.stats()
+        closed = closed and bool(sx.clock_relay_closed)
+        rp.append(int(sx.clock_relay_passes))
+        cp.append(int(sx.clock_passes))
+    torch.cuda.synchronize(dev)
+    x1 = time.perf_counter()
+    res = {"what": leg["what"], "value": round(n_burst * Kx / (x1 - x0) / 1e6, 2), "unit": "Msamples/s", "steps": Kx,
+           "ms_per_step": round((x1 - x0) / Kx * 1e3, 3), "front_end_of_next_burst_overlaps_loops": bool(prefetch),
+           "hand_off_passes": cp, "relay_passes": rp,
+           "closed": closed, "relay_segments": int(sx.clock_relay_segments) if sx is not None else 0}
+    del xd
+    return res, s0, s1
+
+
+def leg_child(args):
+    """bench.py --leg KEY --leg-dir DIR: one alternative leg in a process of its own (the first handle of the process: what a
+    handle's speed is does not depend on what other legs created before).  Writes DIR/KEY.json and the soft symbols of
+    bursts 0 / 1 as DIR/KEY_soft0.npy / _soft1.npy for the parent's parity comparison."""
+    import torch
+    import xritdemod_amd as xa
+    from xritdemod_amd import _capi
+    local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n_burst, D, mode = 1 << args.burst_log2, args.decimation, args.mode
+    fs_in = (1.25e6 if mode == "lrit" else 2.5e6) * D
+    sym_rate, alpha = (293883.0, 0.5) if mode == "lrit" else (927000.0, 0.3)
+    leg = LEGS[args.leg]
+    Kx = min(args.steps, leg["steps"] or args.steps)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    nbuf = max(2, min(2 + Kx, int(free_b * 0.7) // (n_burst * 8)))
+    bursts = torch.empty((nbuf, n_burst, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = _capi.synth_params(fs_in=fs_in, symbol_rate=sym_rate, alpha=alpha, seed=0x58524954)
+
+    def generate(b):
+        _capi.synth_generate_device(sp, b * n_burst, n_burst, bursts[b % nbuf].data_ptr(), device=local_rank, stream=stream.cuda_stream)
+
+    def cfg_of(**kw):
+        return xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
+                                     clock_chain_syms=args.clock_chain, **kw)
+
+    sps = fs_in / D / sym_rate
+    cap = int(n_burst / (D * sps * 0.99)) + 64
+    soft = torch.empty((cap,), dtype=torch.float32, device=dev)
+    res, s0, s1 = run_leg(args.leg, xa, torch, cfg_of, bursts, nbuf, n_burst, soft, cap, stream, dev, args.steps, not args.no_prefetch, generate)
+    res["process"] = "a process of its own (the handle is its first)"
+    if s0 is not None:
+        np.save(os.path.join(args.leg_dir, args.leg + "_soft0.npy"), s0.cpu().numpy())
+    if s1 is not None:
+        np.save(os.path.join(args.leg_dir, args.leg + "_soft1.npy"), s1.cpu().numpy())
+    with open(os.path.join(args.leg_dir, args.leg + ".json"), "w") as f:
+        json.dump(res, f)
+
+
+def run_children(cmds, timeout):
+    """Fresh processes of this script, one after the other; returns [(returncode, stdout, stderr tail)]."""
+    import subprocess
+    outs = []
+    for cmd in cmds:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + cmd, capture_output=True, text=True, timeout=timeout)
+            outs.append((r.returncode, r.stdout, r.stderr[-600:]))
+        except subprocess.TimeoutExpired:
+            outs.append((-9, "", "timed out after %d s" % timeout))
+    return outs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,8 +258,9 @@ def main():
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
     ap.add_argument("--front-exact", type=int, default=0, choices=[0, 1, 2],
-                    help="cfg.front_exact of the measured handle (opt-in parity mode: 1 = tight Costas stop rule, 2 = and the AGC walked "
-                         "literally); the default, 0, is the configuration `value` is quoted on")
+                    help="cfg.front_exact of the measured handle (include/xritdemod_amd.h): 1 = the Costas loop's final pass warmed up over "
+                         "four chains; 2 = the front end bit for bit the CPU chain's through the Costas loop (round 6); the default, 0, "
+                         "is the configuration `value` is quoted on")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
                     help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
                          "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")
@@ -151,10 +268,21 @@ def main():
                     help="add the `contiguous` leg (second timed region, same JSON line) also at N = 1, where the RCCL communicator "
                          "has one rank; with N > 1 over RCCL the leg is always run")
     ap.add_argument("--contiguous-timeout", type=int, default=240, help="seconds the contiguous leg may take before the line is printed without it")
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)          # (internal: run ONE alternative leg in this process)
+    ap.add_argument("--leg-dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--legs-in-process", action="store_true",
+                    help="run the alternative legs (parity_mode, exact_mode, fast_mode, quick_mode) as further handles of THIS process, as "
+                         "rounds 2-5 did; the default since round 6 is a fresh process per leg: how fast a handle is depends on which "
+                         "hardware queues HIP deals its streams onto, and that depends on what the process created before")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs on BASELINE's other single-GPU configurations (C5, C1's chain at burst size, C3), each a "
+                         "fresh process of this script")
     ap.add_argument("--contiguous", action="store_true",
                     help="N ranks demodulate ONE stream cut in N slices, with RCCL edge-sample exchange "
                          "(SURVEY.md 8(e); the default is N independent segments, no data-path collective)")
     args = ap.parse_args()
+    if args.leg:
+        return leg_child(args)
 
     import torch
     import torch.distributed as dist
@@ -476,55 +604,63 @@ def main():
     # passes, three relay passes from the timing guess).
     soft0_alt, soft1_alt = {}, {}
     if rank == 0 and world == 1 and not args.no_exact:
-        def alt_leg(key, clock_exact, what, steps, front_exact=0, ahead_n=1):
-            xd = xa.Demodulator(xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
-                                                       clock_chain_syms=args.clock_chain, clock_exact=clock_exact, front_exact=front_exact))
-            ahead_n = max(1, min(ahead_n, xd.prefetch_depth(n_burst)))
-            Kx, Wx = min(K, steps), 2
-            for b in range(min(Wx + Kx, nbuf)):
-                generate(b)
-            torch.cuda.synchronize(dev)
-            closed, rp, cp = True, [], []
-            for b in range(Wx):
-                ns = xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
-                if b == 0:
-                    soft0_alt[key] = soft[:ns].clone()
-                if b == 1 and front_exact:
-                    soft1_alt[key] = soft[:ns].clone()
-            torch.cuda.synchronize(dev)
-            x0 = time.perf_counter()
-            # (streamed like the headline: the front end of burst b + 1 under the loops of burst b)
-            # (one input registered ahead: these configurations keep round 4's pipeline -- the next burst's front end and Costas
-            # loop beside this burst's relay or hand-off passes)
-            if prefetch:
-                for q in range(min(ahead_n, Kx)):
-                    xd.prefetch_device(bursts[(Wx + q) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
-            for b in range(Wx, Wx + Kx):
-                if prefetch and b + ahead_n < Wx + Kx:
-                    xd.prefetch_device(bursts[(b + ahead_n) % nbuf].data_ptr(), n_burst, stream=stream.cuda_stream)
-                xd.process_device(bursts[b % nbuf].data_ptr(), n_burst, soft.data_ptr(), cap, stream=stream.cuda_stream)
-                sx = xd.stats()
-                closed = closed and bool(sx.clock_relay_closed)
-                rp.append(int(sx.clock_relay_passes))
-                cp.append(int(sx.clock_passes))
-            torch.cuda.synchronize(dev)
-            x1 = time.perf_counter()
-            out[key] = {"what": what, "value": round(n_burst * Kx / (x1 - x0) / 1e6, 2), "unit": "Msamples/s", "steps": Kx,
-                        "ms_per_step": round((x1 - x0) / Kx * 1e3, 3), "front_end_of_next_burst_overlaps_loops": bool(prefetch),
-                        "hand_off_passes": cp, "relay_passes": rp,
-                        "closed": closed, "relay_segments": int(sx.clock_relay_segments)}
-            del xd
+        def cfg_of(**kw):
+            return xa.Demodulator.config(mode, fs_in, D, device=local_rank, costas_chain_len=args.costas_chain,
+                                         clock_chain_syms=args.clock_chain, **kw)
+        if args.legs_in_process:
+            for key in LEGS:
+                out[key], s0_, s1_ = run_leg(key, xa, torch, cfg_of, bursts, nbuf, n_burst, soft, cap, stream, dev, K, prefetch, generate)
+                out[key]["process"] = "a further handle of the bench's process"
+                if s0_ is not None:
+                    soft0_alt[key] = s0_
+                if s1_ is not None:
+                    soft1_alt[key] = s1_
+        else:
+            # a fresh process per leg (round 6): this process keeps its handle and its bursts, both idle meanwhile
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                fwd = ["--burst-log2", str(args.burst_log2), "--decimation", str(D), "--mode", mode, "--steps", str(K),
+                       "--costas-chain", str(args.costas_chain), "--clock-chain", str(args.clock_chain)] + (["--no-prefetch"] if args.no_prefetch else [])
+                res = run_children([["--leg", key, "--leg-dir", td] + fwd for key in LEGS], 300)
+                for key, (rc, _so, se) in zip(LEGS, res):
+                    try:
+                        out[key] = json.load(open(os.path.join(td, key + ".json")))
+                    except Exception:
+                        out[key] = {"error": "leg process failed (rc %d): %s" % (rc, se[-300:])}
+                        continue
+                    for nm, dst in (("_soft0.npy", soft0_alt), ("_soft1.npy", soft1_alt)):
+                        f_ = os.path.join(td, key + nm)
+                        if os.path.exists(f_):
+                            dst[key] = torch.from_numpy(np.load(f_))
 
-        alt_leg("parity_mode", 0, "cfg.front_exact = 1 (opt-in, round 5): the Costas loop's final pass warms every chain up over the "
-                                  "four chains in front of it; everything else the default configuration, fed like `value`", K,
-                front_exact=1, ahead_n=2)
-        alt_leg("exact_mode", 1, "cfg.clock_exact = 1: clock recovery relayed to closure, symbols bit-identical to the serial "
-                                 "float32 recurrence on this chain's Costas output", 5)
-        alt_leg("fast_mode", -2, "cfg.clock_exact = -2 (the default of rounds 2-3): hand-off passes only, five on this signal, "
-                                 "relayed only when they stall; soft symbols 2.2e-4 .. 2.6e-4 rms from the CPU chain", 10)
-        alt_leg("quick_mode", -3, "cfg.clock_exact = -3 (round 4): the default's relay with the passes in front of its last walked "
-                                  "approximately (one guess round, then two; no verification, nothing stored); soft symbols "
-                                  "1.15e-4 rms from the serial trajectory", 10)
+    # ---- BASELINE's other single-GPU configurations, a short leg each (round 6): a fresh process of this script per
+    # configuration -- C5 (configs[4], the "HBM-bound roofline point": 40 Msps, 963 taps, d = 32), C1's chain at burst size
+    # (configs[0]'s chain, 2^28 samples at the circuit rate), C3 (configs[2], HRIT) -- the same timed region as `value` with
+    # fewer steps; parity against the oracle on the first 2^25 samples of the cold-started burst.  Never `value`.
+    if (rank == 0 and world == 1 and not args.no_other_configs and (mode, D) == ("lrit", 5) and args.burst_log2 == 28
+            and args.front_exact == 0):
+        cfgs = {"C5": ["--decimation", "32", "--steps", "8", "--warmup", "4"],
+                "C1": ["--decimation", "1", "--steps", "5", "--warmup", "3"],
+                "C3": ["--mode", "hrit", "--decimation", "1", "--steps", "5", "--warmup", "3"]}
+        common = ["--no-exact", "--no-other-configs", "--no-serial-floor", "--no-profile", "--cpu-sample-log2", "25", "--cpu-threads", "1"]
+        res = run_children([v + common for v in cfgs.values()], 240)
+        out["other_configs"] = {}
+        for key, (rc, so_, se_) in zip(cfgs, res):
+            try:
+                d_ = json.loads(so_.strip().splitlines()[-1])
+                pv = d_.get("parity_vs_oracle") or {}
+                out["other_configs"][key] = {
+                    "workload": d_["config"]["workload"], "steps": d_["steps"], "warmup": d_["warmup"],
+                    "ms_per_step": d_["ms_per_step"], "value": d_["value"], "unit": d_["unit"],
+                    "roofline": {"bound": "hbm", "what": "whole chain: algorithmic bytes per step / ms_per_step",
+                                 "achieved": round(d_["algorithmic_bytes_per_sample"] * d_["config"]["samples_per_step_per_gpu"] / d_["ms_per_step"] / 1e6, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(d_["algorithmic_bytes_per_sample"] * d_["config"]["samples_per_step_per_gpu"] / d_["ms_per_step"] / 1e6 / HBM_PEAK_GBS, 4)},
+                    "parity_vs_oracle": {k_: pv.get(k_) for k_ in ("symbols", "rms", "max", "sign_mismatches")},
+                    "cpu_baseline": {k_: (d_.get("cpu_baseline") or {}).get(k_) for k_ in ("value", "unit", "cores", "kind")},
+                    "process": "a process of its own"}
+            except Exception:
+                out["other_configs"][key] = {"error": "rc %d: %s" % (rc, se_[-300:])}
 
     # ---- CPU baseline: the oracle (a CPU restatement; the reference binary cannot be built here) on a
     # bounded sample of the same workload, one thread like the reference's DSP thread.

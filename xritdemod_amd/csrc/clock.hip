@@ -2148,6 +2148,7 @@ int ClockStage::finish(size_t *n_out, hipStream_t s, Profiler *prof)
         relay_segments = oj.G;
         relay_seg_chains = 0;
         passes = 0;
+        unconverged = 0; max_residual = 0; large_open = 0;     // (the hand-off's figures: this plan has no hand-off)
         if (trace_env) {
             unsigned hs[8];
             XR_HIP(hipMemcpy(hs, oj.aux.p, sizeof hs, hipMemcpyDeviceToHost));
@@ -2460,6 +2461,8 @@ int ClockStage::redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_
         if (carry) hipLaunchKernelGGL(clock_negate_kernel, dim3(div_up(carry, 256)), dim3(256), 0, s, tail.as<float2>() + 1024 * cur, carry);
     }
     if (n) hipLaunchKernelGGL(clock_negate_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, data, n);
+    // (the samples kept as the NEXT call's history are negated now: walkers of an overlap job must not warm up over them)
+    hist_xb = -1; hist_len = 0; hist_job = -1;
     XR_HIP(hipGetLastError());
     xbase_fixed = data - carry;             // (carry <= 1024 <= xpad: never in front of the buffer)
     const int rc = run(n, soft_out, sym_out, cap, n_out, s, prof);

@@ -6,8 +6,10 @@
 
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <thread>
+#include <vector>
 
 namespace xrit {
 
@@ -58,6 +60,8 @@ struct xrit_demod {
     DevBuf bufA[2], bufB[2], bufC[2], bufR[2], stat[2], in_dev, soft_dev, q_in, q_out;
     int next_set = 0;
     hipStream_t stream2 = nullptr;
+    hipStream_t stream_c_pool = nullptr;    // the set's Costas stream (used by cfg.front_exact = 2 only)
+    bool pooled = false;                    // the streams go back to the process's pool when the handle is destroyed
     hipStream_t stream_c = nullptr;     // cfg.front_exact = 2: the Costas loops (their exact walkers are latency, not work) beside the next front end
     // bursts whose Costas loop is a handful of small kernels (few circuit-rate samples: large decimations) run that loop on the
     // walker stream their own walkers will take, beside the next burst's decimator instead of behind it (ov_service)
@@ -209,9 +213,10 @@ static hipError_t create_own_queue_stream(hipStream_t *s)
     for (auto &m : mask) m = 0xffffffffu;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (cus > 32 * 32) cus = 32 * 32;            // (the mask array holds 32 words)
     const uint32_t words = (uint32_t)((cus + 31) / 32);
     if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
-    const hipError_t e = hipExtStreamCreateWithCUMask(s, words <= 32 ? words : 32, mask);
+    const hipError_t e = hipExtStreamCreateWithCUMask(s, words, mask);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
     return hipStreamCreate(s);
@@ -222,6 +227,59 @@ static bool create_walker_streams(xrit_demod *d)
     for (auto &w : d->stream3) if (create_own_queue_stream(&w) != hipSuccess) return false;
     return true;
 }
+
+// The streams of a handle are kept when the handle is destroyed and given to the next handle created on that device (round 6).
+// How fast a handle runs depends on which hardware queues its streams sit on (above), and what HIP deals a NEW stream depends
+// on everything the process has created before: a handle created after others had been destroyed ran its bursts in 2.5 ms
+// instead of 1.8 (round 5, profiles/r5_handles_in_one_process.txt).  With the pool such a handle runs on the very streams --
+// the very queues -- of the one before it: create / destroy sequences are as fast as the first handle, whatever their length.
+// (Handles that are alive TOGETHER still take a set each: more queues than the hardware has slots for are time-sliced.)
+namespace {
+struct StreamSet {
+    int device = -1;
+    hipStream_t s = nullptr, s2 = nullptr, s3[XRIT_WALK_STREAMS] = {}, sc = nullptr;
+};
+std::mutex g_pool_mu;
+std::vector<StreamSet> g_pool;
+
+bool stream_set_acquire(int device, StreamSet *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == device) { *out = g_pool[i]; g_pool.erase(g_pool.begin() + (long)i); return true; }
+    }
+    StreamSet n;
+    n.device = device;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // (the second stream at the lowest priority: a hardware queue of its own -- streams of one priority share a few
+    // queues round-robin, and a front end that lands in the queue of the caller's stream does not overlap anything --
+    // and the loops of the current burst go first where the two compete)
+    bool ok = hipStreamCreate(&n.s) == hipSuccess && hipStreamCreateWithPriority(&n.s2, hipStreamDefault, prio_least) == hipSuccess;
+    for (auto &w : n.s3) ok = ok && create_own_queue_stream(&w) == hipSuccess;
+    ok = ok && create_own_queue_stream(&n.sc) == hipSuccess;
+    if (!ok) {
+        if (n.s) (void)hipStreamDestroy(n.s);
+        if (n.s2) (void)hipStreamDestroy(n.s2);
+        for (auto w : n.s3) if (w) (void)hipStreamDestroy(w);
+        if (n.sc) (void)hipStreamDestroy(n.sc);
+        return false;
+    }
+    *out = n;
+    return true;
+}
+
+void stream_set_release(const StreamSet &st)
+{
+    if (st.s) (void)hipStreamSynchronize(st.s);
+    if (st.s2) (void)hipStreamSynchronize(st.s2);
+    for (auto w : st.s3) if (w) (void)hipStreamSynchronize(w);
+    if (st.sc) (void)hipStreamSynchronize(st.sc);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(st);
+}
+}  // namespace
 
 int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
 {
@@ -263,27 +321,26 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
     d->sps = d->circuit_rate / ((float)cfg->symbol_rate);
     int rc = XRIT_OK;
     do {
-        // (the second stream at the lowest priority: a hardware queue of its own -- streams of one priority share a few
-        // queues round-robin, and a front end that lands in the queue of the caller's stream does not overlap anything --
-        // and the loops of the current burst go first where the two compete)
-        int prio_least = 0, prio_greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (hipStreamCreate(&d->stream) != hipSuccess ||
-            hipStreamCreateWithPriority(&d->stream2, hipStreamDefault, prio_least) != hipSuccess ||
-            !create_walker_streams(d) ||
-            hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
+        {
+            StreamSet st;
+            if (!stream_set_acquire(d->device, &st)) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+            d->stream = st.s; d->stream2 = st.s2; d->stream_c_pool = st.sc;
+            for (int i = 0; i < XRIT_WALK_STREAMS; ++i) d->stream3[i] = st.s3[i];
+            d->pooled = true;
+        }
+        if (hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_fe[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->ev_relay, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_costas, hipEventDisableTiming) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+            hipEventCreateWithFlags(&d->ev_costas, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); rc = XRIT_E_HIP; break; }
         std::vector<float> rrc = design_rrc(1, d->circuit_rate, cfg->symbol_rate, cfg->rrc_alpha, cfg->rrc_taps);
         std::vector<float> lp = design_lowpass(1, cfg->sample_rate, d->circuit_rate / 2, 100e3);
         d->dec_ntaps = (int)lp.size();
         // (cfg.front_exact = 2: both filters summed in the CPU chain's order, the AGC and the Costas loop walked literally --
         // the front end bit for bit the CPU chain's through the Costas loop; fir.hip, agc.hip, costas_exact.hip)
         d->dec.exact = d->rrc.exact = d->agc.exact = d->costas.exact = cfg->front_exact == 2;
-        if (cfg->front_exact == 2 && !getenv("XRIT_NO_COSTAS_STREAM") && create_own_queue_stream(&d->stream_c) != hipSuccess) { set_error("hipStreamCreate failed"); rc = XRIT_E_HIP; break; }
+        if (cfg->front_exact == 2 && !getenv("XRIT_NO_COSTAS_STREAM")) d->stream_c = d->stream_c_pool;
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
         if ((rc = d->rtl.init(cfg->sample_rate)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;
@@ -320,9 +377,7 @@ void xrit_demod_destroy(xrit_demod *d)
     for (auto w : d->stream3) if (w) (void)hipStreamSynchronize(w);     // ... or walkers
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     d->dec.release(); d->rrc.release(); d->agc.release(); d->costas.release(); d->clock.release();
-    if (d->stream2) { (void)hipStreamSynchronize(d->stream2); (void)hipStreamDestroy(d->stream2); }
-    if (d->stream_c) { (void)hipStreamSynchronize(d->stream_c); (void)hipStreamDestroy(d->stream_c); }
-    for (auto w : d->stream3) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    if (d->stream_c_pool) (void)hipStreamSynchronize(d->stream_c_pool);
     if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
     if (d->ev_relay) (void)hipEventDestroy(d->ev_relay);
@@ -333,7 +388,12 @@ void xrit_demod_destroy(xrit_demod *d)
     d->in_dev.release(); d->soft_dev.release();
     d->q_in.release(); d->q_out.release();
     for (auto &b : d->stage_buf) b.release();
-    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->pooled) {
+        StreamSet st;
+        st.device = d->device; st.s = d->stream; st.s2 = d->stream2; st.sc = d->stream_c_pool;
+        for (int i = 0; i < XRIT_WALK_STREAMS; ++i) st.s3[i] = d->stream3[i];
+        stream_set_release(st);
+    }
     delete d;
 }
 
@@ -1012,6 +1072,9 @@ int xrit_demod_read_stage(xrit_demod *d, int stage, float *out, size_t cap, size
 int xrit_demod_keep_stages(xrit_demod *d, int enable)
 {
     if (!d) return XRIT_E_INVALID;
+    // (what runs ahead of a registered input's call is chosen by these flags: a call whose Costas loop and walkers have already
+    // been started as an overlap job must not be taken by the stage-keeping path afterwards)
+    if (d->pf_count > 0) { set_error("prefetched inputs wait for their process calls: stage copies are switched between plain calls"); return XRIT_E_INVALID; }
     d->keep_stages = enable == 1;
     d->keep_symbols = enable == 2;
     return XRIT_OK;
