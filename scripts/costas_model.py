@@ -13,7 +13,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oracle                                    # noqa: E402
-from xritdemod_amd import synth                  # noqa: E402
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../tests')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 fs, D, L = 6.25e6, 5, 256

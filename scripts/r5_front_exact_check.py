@@ -4,7 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../tests')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 import oracle
 
 def rms(a): return float(np.sqrt(np.mean(np.abs(a) ** 2)))

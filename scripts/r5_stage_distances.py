@@ -2,7 +2,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../tests')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 import oracle
 def rms(a): return float(np.sqrt(np.mean(np.abs(a)**2)))
 for name,(mode,fs,D,kw,n) in {"C2":("lrit",6.25e6,5,dict(fs_in=6.25e6),8000000),"C3":("hrit",2.5e6,1,dict(fs_in=2.5e6,symbol_rate=927000.0,alpha=0.3),3000000)}.items():

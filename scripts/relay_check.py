@@ -9,7 +9,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../tests')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 
 
 def run(cfg_kw, x, calls=1, mode="lrit", fs=6.25e6, D=5):

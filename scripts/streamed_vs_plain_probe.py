@@ -5,7 +5,9 @@ import numpy as np
 sys.path.insert(0, "/root/repo")
 import torch
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../tests')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 dev = torch.device("cuda", 0)
 def compare(name, x_np, sizes, typ, fs, D, mode="lrit", **cfg):
     per = 2

@@ -50,7 +50,7 @@ _SIG_CACHE = {}
 
 def synth_signal(n, **kw):
     """Deterministic synthetic burst (numpy spec generator), cached per parameter set."""
-    from xritdemod_amd import synth
+    import synth
     key = (n, tuple(sorted(kw.items())))
     if key not in _SIG_CACHE:
         _SIG_CACHE[key] = synth.generate(synth.SynthParams(**kw), n)

@@ -151,7 +151,9 @@ def costas():
 def main():
     cmd = sys.argv[1] if len(sys.argv) > 1 else "tiled"
     if cmd == "gen":
-        from xritdemod_amd import synth
+        import os as _os, sys as _sys
+        _sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '../..')))
+        import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
         N, p = 16 << 20, synth.SynthParams()
         x = np.concatenate([synth.generate(p, N // 8, start=i * (N // 8)) for i in range(8)])
         d = oracle.Demod(oracle.config("lrit", 1.25e6, 1)); d.process(x)

@@ -1,7 +1,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 # reproduce one case of fuzz_chain.py (FUZZ_WIDE=1): python dbg_case.py <seed> <case>, stage by stage
 SEED, CASE = int(sys.argv[1]), int(sys.argv[2])
 snr_lo, snr_hi = (float(v) for v in os.environ.get("FUZZ_SNR", "8,20").split(","))

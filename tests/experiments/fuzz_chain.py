@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import oracle
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

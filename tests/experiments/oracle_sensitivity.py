@@ -4,7 +4,9 @@ fail the parity bar at low Es/N0.  python tests/experiments/oracle_sensitivity.p
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 oracle.build()
 seed0 = int(sys.argv[1]); want = set(int(v) for v in sys.argv[2].split(","))
 rng = np.random.default_rng(seed0)

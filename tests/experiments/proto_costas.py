@@ -8,7 +8,9 @@ import numpy as np
 
 sys.path.insert(0, "/root/repo")
 import oracle
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 
 f32 = np.float32
 TWOPI = f32(2 * np.pi)

@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import oracle
 import xritdemod_amd as xa
-from xritdemod_amd import synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')))
+import synth  # tests/synth.py: the NumPy specification of the synthetic burst (test infrastructure)
 
 CASE = dict(seed=798172660, mode="hrit", D=5, n=1988307, typ=2, cuts=[794154, 1968047],
             extra=dict(esn0_db=18.83, carrier_hz=-44.79, clock_ppm=99.62, timing_offset=0.41, phase0=-0.55))

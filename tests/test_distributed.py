@@ -14,7 +14,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import dist_twin as xd
-    from xritdemod_amd import synth
+    import synth
     d = xd.init("gloo")
     w, r, lr = xd.env_world()
     assert (w, r) == (world, rank)
@@ -62,7 +62,7 @@ def _split_worker(rank, world, port, q, same_lock):
                       LOCAL_RANK=str(rank))
     import oracle                       # the CPU tier plays the chain with the oracle; on GPUs it is the HIP chain
     import dist_twin as xd
-    from xritdemod_amd import synth
+    import synth
     d = xd.init("gloo")
     n = 900000
     # every rank holds only its own slice of ONE stream (the generator is counter based: any slice on its own)
@@ -77,7 +77,7 @@ def _split_worker(rank, world, port, q, same_lock):
 
 def _run_split(same_lock):
     import oracle
-    from xritdemod_amd import synth
+    import synth
     world, n = 2, 900000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

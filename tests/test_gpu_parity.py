@@ -27,7 +27,7 @@ import numpy as np
 import pytest
 
 from conftest import synth_signal, rms
-from xritdemod_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -1304,7 +1304,8 @@ def test_stats_and_strict_mode(xa):
 
 def test_device_generator_matches_numpy_spec(xa):
     import torch
-    from xritdemod_amd import synth, _capi
+    from xritdemod_amd import _capi
+    import synth
     n = 1 << 16
     for start in (0, 123456789):
         buf = torch.empty((n, 2), dtype=torch.float32, device="cuda:0")
@@ -1321,7 +1322,8 @@ def test_full_size_burst_properties(xa):
     hard bits equal the transmitted sequence (global sign / constant delay), the symbol count matches the
     symbol clock, and a second burst continues the stream without losing symbols."""
     import torch
-    from xritdemod_amd import synth, _capi
+    from xritdemod_amd import _capi
+    import synth
     n = 1 << 28
     D, fs = 5, 6.25e6
     sp = _capi.synth_params(fs_in=fs)

@@ -236,7 +236,7 @@ def test_rtl_ingest_kat(oracle_mod):
 ])
 def test_chain_recovers_transmitted_bits(oracle_mod, mode, fs, D, kw):
     """End-to-end known answer: hard decisions equal the transmitted PRBS up to a global sign and a delay."""
-    from xritdemod_amd import synth
+    import synth
     o = oracle_mod
     n = 600000 if D == 1 else 1500000
     p = synth.SynthParams(**kw)
@@ -356,7 +356,7 @@ def test_sync_correlator_kats(oracle_mod):
 def _framed_burst(n_frames, fs=1.25e6, seed=3, **kw):
     """IQ of n_frames CCSDS-style coded frames (sync marker + random payload, k=7 r=1/2) behind a short random
     lead-in, plus what was sent."""
-    from xritdemod_amd import synth
+    import synth
     p = synth.SynthParams(fs_in=fs, seed=seed, **kw)
     sym = synth.ccsds_frames(n_frames, seed=seed)
     n = int((len(sym) + 64) * p.sps_in)
@@ -392,7 +392,7 @@ def viterbi_decode_k7(soft):
 
 def frame_bits(n_frames, seed):
     """The uncoded bits synth.ccsds_frames(n_frames, seed) encodes, one row per frame."""
-    from xritdemod_amd import synth
+    import synth
     rng = np.random.default_rng(seed)
     asm = np.array([(synth.CCSDS_ASM >> (31 - i)) & 1 for i in range(32)], np.uint8)
     return np.stack([np.concatenate([asm, rng.integers(0, 2, synth.CODED_FRAME_SYMBOLS // 2 - 32).astype(np.uint8)])
@@ -429,7 +429,7 @@ def check_frame_lock(hits, first=3, min_corr=46):
 
 
 def test_coded_sync_marker_is_the_decoders_word(oracle_mod):
-    from xritdemod_amd import synth
+    import synth
     asm = np.array([(synth.CCSDS_ASM >> (31 - i)) & 1 for i in range(32)], np.uint8)
     word = 0
     for b in synth.conv_encode_k7(asm):
@@ -454,7 +454,7 @@ def test_framed_stream_locks_through_the_oracle_chain(oracle_mod):
     assert valid[3:].all()
     again = o.sync_correlate(frames[3:].reshape(-1))
     assert (again[:, 0] == 0).all() and (again[:, 1] == 0).all()
-    from xritdemod_amd import synth
+    import synth
     sent = synth.ccsds_frames(16, seed=3).reshape(16, -1) < 0          # coded bit 1 -> -1
     got = frames[3:] < 0
     errs = [min((got[i] != sent[j]).mean() for j in range(16)) for i in range(len(got))]
@@ -493,7 +493,7 @@ def test_knob_matrix_passes_the_implementation_independent_kats(oracle_mod, kn):
     upstream does, the chain must still be a BPSK demodulator: under EVERY combination the blocks pass the
     known-answer tests that do not depend on the choice, and the chain recovers the transmitted PRBS without a
     bit error."""
-    from xritdemod_amd import synth
+    import synth
     o = oracle_mod
     with o.knobs(**kn):
         # FIR: impulse response, and a decimating filter against the direct sum at the knob's phase
