@@ -343,6 +343,9 @@ int  xrit_agc_create(float rate, float reference, float gain, float max_gain, in
 int  xrit_agc_work(xrit_agc *a, const float *in, float *out, size_t n);
 /* exact = 1: the float32 recurrence walked literally in warmed-up chains whose joints are checked bit for bit (front_exact = 2) */
 int  xrit_agc_set_exact(xrit_agc *a, int exact);
+/* the last exact call's counters: [0] joints open after the rounds, [1] 64-sample blocks walked, [2] Picard rounds, [3] blocks at the
+ * round limit, [4] lattice segments, [5] scans that fell back to the systolic one, [6..7] unused */
+int  xrit_agc_exact_stats(xrit_agc *a, uint32_t *counters8);
 float xrit_agc_gain(xrit_agc *a);
 void xrit_agc_destroy(xrit_agc *a);
 

@@ -117,6 +117,10 @@ def test_agc_walked_literally_is_the_oracle_bit_for_bit(xa, oracle_mod):
         want, got = ao.Work(seg), ag.Work(seg)
         assert same_words(got, want), (m, first_diff(got, want))
         assert np.float32(ag.gain).view(np.uint32) == np.float32(ao.s.gain).view(np.uint32)
+        if m > 100000:
+            st = ag.exact_stats()
+            print("exact AGC:", m, st, "rounds per block %.2f, segments per scan %.2f" % (st["picard_rounds"] / max(st["blocks"], 1), st["lattice_segments"] / max(st["picard_rounds"], 1)))
+            assert st["joints_open"] == 0 and st["at_round_limit"] == 0
     # the clamp: a silent stretch long enough to reach max_gain
     z = np.zeros(900_000, np.complex64)
     z[:10] = 0.1
@@ -333,3 +337,48 @@ def test_costas_exact_scan_variants_all_give_the_oracle(xa, oracle_mod, monkeypa
         assert st["lattice_segments"] > 0
     else:
         assert st["lattice_segments"] == 0
+
+
+@pytest.mark.parametrize("case,seed", [("C2", 1), ("C3", 2), ("C1", 3), ("C5", 4)])
+def test_front_exact_2_randomly_cut_streams_are_the_oracle(xa, oracle_mod, case, seed):
+    """A stream cut at random into calls of 1 .. 2 M samples (empty ones too), every stage's state carried from call to call:
+    with cfg.clock_exact = 1 the soft symbols are the oracle's word for word whatever the cuts; s16 input on the decimating
+    configurations (the ingest conversion fused into the exact-order filter's window fill)."""
+    mode, fs, D, kw = CASES[case]
+    rng = np.random.default_rng(seed)
+    n = 3_000_000 * (D if D < 32 else 8)
+    x = synth_signal(n, fs_in=fs, **kw)
+    st = xa.SAMPLE_FLOATIQ
+    if D > 1:
+        q = np.empty(2 * n, np.int16)
+        q[0::2] = np.clip(np.rint(x.real * 32768.0 * 4), -32768, 32767)
+        q[1::2] = np.clip(np.rint(x.imag * 32768.0 * 4), -32768, 32767)
+        st = xa.SAMPLE_S16IQ
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=2, clock_exact=1))
+    od = oracle_mod.Demod(oracle_mod.config(mode, fs, D))
+    pos = 0
+    while pos < n:
+        m = int(rng.choice([0, 1, int(rng.integers(2, 5000)), int(rng.integers(5000, 300_000)), int(rng.integers(300_000, 2_000_000))]))
+        m = min(m, n - pos)
+        if st == xa.SAMPLE_FLOATIQ:
+            got, want = dem.process(x[pos:pos + m]), od.process(x[pos:pos + m])
+        else:
+            seg = q[2 * pos:2 * (pos + m)]
+            got, want = dem.process(seg, xa.SAMPLE_S16IQ), od.process(seg, oracle_mod.SAMPLE_S16IQ)
+        assert same_words(got, want), (case, pos, m, first_diff(got, want))
+        pos += m
+
+
+def test_front_exact_2_at_low_snr(xa, oracle_mod):
+    """Es/N0 = 4 dB: the Costas loop slips now and then, the approximate solve iterates; the exact stage does not care where its
+    start states come from -- the front end is the oracle's bit for bit, and with it (cfg.clock_exact = 1) the soft symbols."""
+    x = synth_signal(2_500_000, fs_in=1.25e6, esn0_db=4.0, seed=99)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 1.25e6, 1, front_exact=2, clock_exact=1))
+    dem.keep_stages(True)
+    od = oracle_mod.Demod(oracle_mod.config("lrit", 1.25e6, 1))
+    for a, b in ((0, 1_200_000), (1_200_000, 2_500_000)):
+        got, want = dem.process(x[a:b]), od.process(x[a:b])
+        for nm in ("agc", "rrc", "costas"):
+            g, w = dem.stage(nm), od.stage(nm)
+            assert same_words(g, w), (nm, a, first_diff(g, w))
+        assert same_words(got, want), (a, first_diff(got, want))

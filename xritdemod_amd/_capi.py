@@ -88,6 +88,7 @@ _SIGNATURES = {
     "xrit_fir_set_exact": (C.c_int, [_vp, C.c_int]),
     "xrit_loop_sincosf": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int]),
     "xrit_agc_set_exact": (C.c_int, [_vp, C.c_int]),
+    "xrit_agc_exact_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "xrit_costas_set_exact": (C.c_int, [_vp, C.c_int, C.c_int]),
     "xrit_costas_exact_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -279,6 +280,12 @@ class AGC(_Handle):
     @property
     def gain(self):
         return lib().xrit_agc_gain(self._h)
+
+    def exact_stats(self):
+        c = (C.c_uint32 * 8)()
+        _check(lib().xrit_agc_exact_stats(self._h, c))
+        return {"joints_open": c[0], "blocks": c[1], "picard_rounds": c[2], "at_round_limit": c[3], "lattice_segments": c[4],
+                "lattice_fallbacks": c[5]}
 
 
 class CostasLoop(_Handle):

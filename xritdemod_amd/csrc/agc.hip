@@ -344,6 +344,7 @@ int AgcStage::run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, 
         A.js = joints.as<float2>(); A.je = A.js + W; A.used = A.je + W;
         A.bs = A.used + W;
         A.cnt = reinterpret_cast<unsigned *>(A.bs + (n >> 6) + 2);
+        ex_cnt = A.cnt;
         A.n = (long long)n; A.Lw = (int)lw; A.H = AGC_EX_WARM; A.W = W;
         A.mode = ex_mode; A.prio = 1;
         K.p = AgcWalk::Par{aggs.as<AgcMap>(), sin_, sout, rate, ref, maxg};
@@ -535,6 +536,15 @@ int AgcStage::fused_scan(const float2 *in, float2 *fallback, size_t n, int per_l
     fill->maxg = maxg;
     fill->per_lane = per_lane;
     cur ^= 1;
+    return XRIT_OK;
+}
+
+int AgcStage::exact_counters(unsigned *out8, hipStream_t s)
+{
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!ex_cnt) return XRIT_OK;
+    XR_HIP(hipMemcpyAsync(out8, ex_cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
     return XRIT_OK;
 }
 

@@ -188,7 +188,10 @@ __device__ __forceinline__ int cx_block(float2 x, float2 ya, int cnt, float &ph,
         be = g.beta * e;
         float p2, f2;
         cx_scan(ae, be, ph, fr, p2, f2, mode, stat);
-        const bool same = __float_as_uint(p2) == __float_as_uint(pv) && __float_as_uint(f2) == __float_as_uint(fv);
+        // (the detector outputs depend on the PHASES only: phases that come out as they went in were all the serial loop's -- lane
+        // 0's is the block's start, and each one right makes the next one right --, and so is everything this scan made of
+        // them, the frequencies included, whatever the frequencies of the round before were)
+        const bool same = __float_as_uint(p2) == __float_as_uint(pv);
         pv = p2;
         fv = f2;
         if (xw::all(same) || rounds >= xw::MAX_ROUNDS) break;

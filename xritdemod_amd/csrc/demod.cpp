@@ -1288,6 +1288,13 @@ int xrit_agc_set_exact(xrit_agc *a, int exact)
     return XRIT_OK;
 }
 
+int xrit_agc_exact_stats(xrit_agc *a, uint32_t *counters8)
+{
+    if (!a || !counters8) { set_error("null argument"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(a->device));
+    return a->st.exact_counters(counters8, a->stream);
+}
+
 float xrit_agc_gain(xrit_agc *a)
 {
     float g = NAN;

@@ -95,6 +95,8 @@ struct AgcStage {
     DevBuf joints;   // exact_walk.h's joints, block records and counters
     int ex_walkers = 2048, ex_mode = 3;     // ranges per large call (two walkers per SIMD); scan switches (XRIT_CX_MODE)
     int run_exact(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    unsigned *ex_cnt = nullptr;             // the last exact call's counters (exact_walk.h: xw::NCNT words, device)
+    int exact_counters(unsigned *out8, hipStream_t s);
     // the same in two halves around the kernel that produces `in` (the decimator): fused_begin() before it
     // (hands out the epilogue descriptor), fused_finish() after it -- the stream is swept twice, not three times
     int fused_begin(size_t n, int per_lane, hipStream_t s, AgcEpilogue *epi);      // per_lane: the producer's RC

@@ -75,7 +75,7 @@ struct Options {
     bool fifo = false;             // the reference's FIFO chunking (demodulator.cpp:108-119) instead of fixed --block calls
     size_t fifo_block = 65535;     // complex samples per source callback (CFileFrontend.cpp:12 BUFFERSIZE)
     int fifo_lag = 1;              // source blocks that arrive between two looks of the DSP loop
-    bool front_exact = false;      // cfg.front_exact = 1: the opt-in parity mode (the Costas loop's final pass warmed up)
+    int front_exact = 0;           // cfg.front_exact: 1 = the Costas loop's final pass warmed up; 2 = the front end bit for bit a CPU chain's
 };
 constexpr size_t FIFO_COMPLEX = 1024 * 1024 / 2;      // FIFO_SIZE floats (Parameters.h:57)
 constexpr size_t FIFO_MIN_COMPLEX = 64 * 1024 / 2;    // "Lets wait for more samples" (demodulator.cpp:113)
@@ -89,7 +89,9 @@ void usage()
                  "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n"
                  "         [--gpus N]   (devices 0..N-1: each block of --block samples is cut in N time slices, RCCL edge exchange)\n"
                  "         [--fifo [--fifo-block SAMPLES] [--fifo-lag BLOCKS]]   (the reference's FIFO chunking, demodulator.cpp:108-119)\n"
-                 "         [--front-exact]   (cfg.front_exact = 1: closer to a CPU chain's soft symbols, ~12 %% slower on big blocks)\n");
+                 "         [--front-exact [1|2]]   (cfg.front_exact; 1: the Costas loop's final pass warmed up, ~12 %% slower on big blocks;\n"
+                 "                                  2: filters, AGC and Costas loop bit for bit a CPU chain's -- soft symbols within 1e-4 rms of it\n"
+                 "                                  on every configuration, ~3 x slower on big blocks)\n");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -117,7 +119,10 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--fifo-block") { if (!(v = need("--fifo-block"))) return false; o.fifo_block = (size_t)std::atoll(v); }
         else if (a == "--fifo-lag") { if (!(v = need("--fifo-lag"))) return false; o.fifo_lag = std::atoi(v); }
         else if (a == "--fifo") o.fifo = true;
-        else if (a == "--front-exact") o.front_exact = true;
+        else if (a == "--front-exact") {
+            o.front_exact = 1;
+            if (i + 1 < argc && (std::string(argv[i + 1]) == "1" || std::string(argv[i + 1]) == "2")) o.front_exact = atoi(argv[++i]);
+        }
         else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
         else if (a == "--stats") o.stats = true;
@@ -421,7 +426,7 @@ int main(int argc, char **argv)
     else xrit_demod_config_lrit(&cfg, (float)o.sample_rate, o.decimation);
     int rc = XRIT_OK;
     cfg.device = o.device;
-    cfg.front_exact = o.front_exact ? 1 : 0;
+    cfg.front_exact = o.front_exact;
     if (o.gpus > 1) return run_multi_gpu(o, type, bytes_per_sample, cfg);
     xrit_demod *chain = nullptr;
     if (xrit_demod_create(&cfg, &chain) != XRIT_OK) {
