@@ -641,7 +641,11 @@ def main():
             and args.front_exact == 0):
         cfgs = {"C5": ["--decimation", "32", "--steps", "8", "--warmup", "4"],
                 "C1": ["--decimation", "1", "--steps", "5", "--warmup", "3"],
-                "C3": ["--mode", "hrit", "--decimation", "1", "--steps", "5", "--warmup", "3"]}
+                "C3": ["--mode", "hrit", "--decimation", "1", "--steps", "5", "--warmup", "3"],
+                # ... and in the parity mode (cfg.front_exact = 2), the only one that holds HRIT to 1e-4
+                "C5, parity mode": ["--decimation", "32", "--steps", "5", "--warmup", "3", "--front-exact", "2"],
+                "C1, parity mode": ["--decimation", "1", "--steps", "4", "--warmup", "3", "--front-exact", "2"],
+                "C3, parity mode": ["--mode", "hrit", "--decimation", "1", "--steps", "4", "--warmup", "3", "--front-exact", "2"]}
         common = ["--no-exact", "--no-other-configs", "--no-serial-floor", "--no-profile", "--cpu-sample-log2", "25", "--cpu-threads", "1"]
         res = run_children([v + common for v in cfgs.values()], 240)
         out["other_configs"] = {}
@@ -650,7 +654,7 @@ def main():
                 d_ = json.loads(so_.strip().splitlines()[-1])
                 pv = d_.get("parity_vs_oracle") or {}
                 out["other_configs"][key] = {
-                    "workload": d_["config"]["workload"], "steps": d_["steps"], "warmup": d_["warmup"],
+                    "workload": d_["config"]["workload"], "front_exact": d_["config"].get("front_exact", 0), "steps": d_["steps"], "warmup": d_["warmup"],
                     "ms_per_step": d_["ms_per_step"], "value": d_["value"], "unit": d_["unit"],
                     "roofline": {"bound": "hbm", "what": "whole chain: algorithmic bytes per step / ms_per_step",
                                  "achieved": round(d_["algorithmic_bytes_per_sample"] * d_["config"]["samples_per_step_per_gpu"] / d_["ms_per_step"] / 1e6, 1),
