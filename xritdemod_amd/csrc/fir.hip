@@ -277,6 +277,42 @@ fir_decim_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
         }
 #pragma unroll
         for (int c = 0; c < RC; ++c) acc[c] = make_float2(a[c].x, a[c].y);
+    } else if (PAD && EX) {
+        // cfg.front_exact = 2 on a skewed window (even strides: C5's 963 taps at d = 32), D a multiple of 4 (the launcher
+        // checks): the window is walked a run of D samples at a time (the skew sits between runs), four samples per step --
+        // window index mod 4 is the position in the run mod 4, so the four partial sums keep fixed registers, and (c D) mod 4 = 0:
+        // the labels are the CPU chain's as they stand
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f a[RC][4];
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[c][j] = (v2f){0.f, 0.f};
+        int i = 0, off = 0;
+        while (i < Wpad) {
+            const int run = min(D, Wpad - i);
+            for (int k = 0; k < run; k += 4) {
+                const float2 q0 = w[off + k], q1 = w[off + k + 1], q2 = w[off + k + 2], q3 = w[off + k + 3];
+                const v2f x0 = {q0.x, q0.y}, x1 = {q1.x, q1.y}, x2 = {q2.x, q2.y}, x3 = {q3.x, q3.y};
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    const float *gc = g + c * Wpad + i + k;
+                    const float t0 = gc[0], t1 = gc[1], t2 = gc[2], t3 = gc[3];
+                    const v2f p0 = x0 * t0, p1 = x1 * t1, p2 = x2 * t2, p3 = x3 * t3;
+                    a[c][0] = a[c][0] + p0;
+                    a[c][1] = a[c][1] + p1;
+                    a[c][2] = a[c][2] + p2;
+                    a[c][3] = a[c][3] + p3;
+                }
+            }
+            i += run;
+            off += D + 1;
+        }
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const v2f r = (a[c][0] + a[c][1]) + (a[c][2] + a[c][3]);
+            acc[c] = make_float2(r.x, r.y);
+        }
     } else if (PAD) {
         int i = 0, off = 0;
         while (i < Wpad) {
@@ -716,6 +752,9 @@ int FirStage::init(const float *taps, int ntaps, int decim)
     // measured at C2: five outputs per lane halve the decimator's occupancy (52 KiB window) and lose 45 %
     if (D == 1) RC = 5;
     else RC = 3;
+    // (cfg.front_exact = 2 at large decimations: one output per lane -- a window of 64 KiB then holds 128 outputs, four workgroups
+    // per CU; with three per lane it held 192 on ONE wave per workgroup and two waves per CU: 4.0 ms per C5 burst)
+    if (exact && D >= 16) RC = 1;
     // large decimations whose phases map onto lanes take the polyphase kernel
     poly = (D == 16 || D == 32 || D == 64) && (T + D - 1) / D <= POLY_NQ;
     if (exact) {
@@ -969,6 +1008,25 @@ int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream
                 else XR_EXS_TY(3);
 #undef XR_EXS_TY
 #undef XR_EXS_GO
+            }
+            else if (pad && D % 4 == 0 && threads % 64 == 0 && (RC == 3 || RC == 1)) {
+                // (skewed windows with D a multiple of 4 -- 16, 32, 64: the shared walk too)
+                const AgcEpilogue none{nullptr, nullptr, 0.f, 0.f, 0.f};
+                const AgcFill af{};
+                const unsigned blk = div_up(n_out, (size_t)threads * RC);
+#define XR_EXP_GO(RCV, TY)                                                                                                     \
+    hipLaunchKernelGGL((fir_decim_kernel<RCV, true, TY, 0, 0, 1, false, true>), dim3(blk), dim3(threads), lds_bytes, s, in, h, out, \
+                       g.as<float>(), T, D, Wpad, (long long)n_out, (long long)n_in, tile_len, (float2 *)nullptr, 0, none, af, hn)
+#define XR_EXP_TY(RCV)                                                          \
+    do {                                                                        \
+        if (type == XRIT_SAMPLE_FLOATIQ) XR_EXP_GO(RCV, XRIT_SAMPLE_FLOATIQ);   \
+        else if (type == XRIT_SAMPLE_S16IQ) XR_EXP_GO(RCV, XRIT_SAMPLE_S16IQ);  \
+        else XR_EXP_GO(RCV, XRIT_SAMPLE_S8IQ);                                  \
+    } while (0)
+                if (RC == 1) XR_EXP_TY(1);
+                else XR_EXP_TY(3);
+#undef XR_EXP_TY
+#undef XR_EXP_GO
             }
             else if (ex_pad) XR_EX_TY(true);
             else XR_EX_TY(false);
