@@ -679,7 +679,7 @@ def main():
         out["cpu_baseline"] = {"value": round(n_cpu / (c1 - c0) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                "kind": "port",
                                "sample": "first %d samples (%.0f Mi) of burst 0, oracle/xrit_oracle.c single thread "
-                                         "(gcc -O3 -mavx2 -ffp-contract=off)" % (n_cpu, n_cpu / 2.0 ** 20),
+                                         "(gcc -O3 -mavx2 -mfma -ffp-contract=off; the FMA only where the C library's sincosf has it)" % (n_cpu, n_cpu / 2.0 ** 20),
                                "seconds": round(c1 - c0, 3)}
         if cpu_threads > 1:
             # N independent segments on N threads (the C call releases the GIL): what the node's cores do together

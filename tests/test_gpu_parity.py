@@ -1680,11 +1680,12 @@ def test_contiguous_split_on_device(xa, same_lock):
         t.join(timeout=300)
     (o0, s0), (o1, s1) = res
     got = np.concatenate([s0, s1])
-    assert o0 == 0 and o1 == len(s0) and len(got) == len(ref)
-    assert np.array_equal(np.sign(got), np.sign(ref))
-    e1 = rms(got[len(s0):] - ref[len(s0):])
-    assert rms(got[:len(s0)] - ref[:len(s0)]) < 4e-4            # rank 0: same chain, other chunking
-    assert e1 < (6e-4 if same_lock else 3e-3)
+    assert o0 == 0 and o1 == len(s0) and len(got) == len(ref), (o0, o1, len(s0), len(s1), len(ref))
+    flips = np.nonzero(np.sign(got) != np.sign(ref))[0]
+    assert len(flips) == 0, (len(flips), flips[:8].tolist(), got[flips[:8]].tolist(), ref[flips[:8]].tolist(), len(s0))
+    e0, e1 = rms(got[:len(s0)] - ref[:len(s0)]), rms(got[len(s0):] - ref[len(s0):])
+    assert e0 < 4e-4, (e0, e1)            # rank 0: same chain, other chunking
+    assert e1 < (6e-4 if same_lock else 3e-3), (e0, e1)
 
 
 def test_group_api_two_ranks_on_one_device(xa, oracle_mod):

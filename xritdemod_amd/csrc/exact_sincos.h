@@ -14,12 +14,11 @@ namespace xrit {
 
 __device__ __forceinline__ void exact_sincosf_poly(double x, double x2, bool negc, int n, float &sn, float &cs)
 {
-    // the cosine polynomial negated in quadrants 2 and 3; the sine's sign is in x
-    const double c0 = negc ? -0x1p0 : 0x1p0;
-    const double c1 = negc ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
-    const double c2 = negc ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5;
-    const double c3 = negc ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
-    const double c4 = negc ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    // In quadrants 2 and 3 the C library takes a table whose cosine coefficients are all negated (the sine's sign is in x).
+    // Negating every coefficient negates every fused multiply-add's exact result, and rounding is symmetric: the polynomial is
+    // evaluated once with the positive coefficients and its rounded value negated -- the same bits.
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
     const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
     const double x3 = x2 * x, x4 = x2 * x2;
     const double s1 = __builtin_fma(x2, s3c, s2c);
@@ -29,25 +28,29 @@ __device__ __forceinline__ void exact_sincosf_poly(double x, double x2, bool neg
     const double s = __builtin_fma(x3, s1c, x);
     const double c = __builtin_fma(x4, c2, cc1);
     const float sv = (float)__builtin_fma(x5, s1, s);
-    const float cv = (float)__builtin_fma(x6, cc2, c);
+    float cv = (float)__builtin_fma(x6, cc2, c);
+    cv = negc ? -cv : cv;
     sn = (n & 1) ? cv : sv;
     cs = (n & 1) ? sv : cv;
 }
 
 __device__ __forceinline__ void exact_sincosf(float y, float &sn, float &cs)
 {
+    // One straight line for every |y| < 120 (the lanes of a wave sit on both sides of pi/4 now and then: no divergence).  The C
+    // library's first branch (|y| < pi/4: the polynomials on y itself) is the general one with n = 0 -- there
+    // n = ((int)(y 2^24 2/pi) + 2^23) >> 24 is 0, the reduction fma(-0, pi/2, y) is y exactly, the sign 1, the table the first --;
+    // its second (|y| < 2^-12: sin = y, cos = 1) is a select behind it.
     const unsigned top = (__float_as_uint(y) >> 20) & 0x7ffu;
     const double x = (double)y;
-    if (top < 0x3f4u) {                               // |y| < pi/4
-        if (top < 0x398u) { sn = y; cs = 1.0f; return; }      // |y| < 2^-12
-        exact_sincosf_poly(x, x * x, false, 0, sn, cs);
-        return;
-    }
     const double r = x * 0x1.45F306DC9C883p+23;       // 2/pi * 2^24
     const int n = ((int)r + 0x800000) >> 24;          // (int): towards zero, like cvttsd2si
     const double xr = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
     const double sg = ((n + 1) & 2) ? -1.0 : 1.0;     // sign[n & 3] = {1, -1, -1, 1}
-    exact_sincosf_poly(xr * sg, xr * xr, (n & 2) != 0, n, sn, cs);
+    float s1, c1;
+    exact_sincosf_poly(xr * sg, xr * xr, (n & 2) != 0, n, s1, c1);
+    const bool tiny = top < 0x398u;                   // |y| < 2^-12
+    sn = tiny ? y : s1;
+    cs = tiny ? 1.0f : c1;
 }
 
 }  // namespace xrit
