@@ -94,3 +94,22 @@ def test_circuit_rate_burst_walks_overlapping_blocks():
     assert lp["clock"] == 0 and lp["clock_relay"] == 1 and lp["clock_relay_closed"] == 0 and lp["costas"] == 1 and lp["costas_unconverged"] == 0, lp
     assert 2 * 256 <= lp["clock_relay_segments"] <= 3 * 256, lp           # (2.5 walkers per CU at most: 640 on a 256-CU part)
     assert d["value"] > 0 and d["config"]["decimation"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_alternative_legs_run_in_processes_of_their_own():
+    """Round 6: parity_mode (cfg.front_exact = 2), exact_mode, fast_mode, quick_mode are each a fresh process of bench.py (--leg):
+    what a handle's bursts take depends on the hardware queues HIP deals its streams onto, which depends on what the process
+    created before.  The parent collects their results and their soft symbols for the parity comparison."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--burst-log2", "24",
+                        "--cpu-sample-log2", "22", "--cpu-threads", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    _check_line(d, 1)
+    for key in ("parity_mode", "exact_mode", "fast_mode", "quick_mode"):
+        assert "error" not in d[key], d[key]
+        assert d[key]["ms_per_step"] > 0 and "process of its own" in d[key]["process"], d[key]
+    pv = d["parity_vs_oracle"]
+    assert pv["parity_mode"]["sign_mismatches"] == 0 and pv["parity_mode"]["rms"] <= 1e-4, pv["parity_mode"]
+    assert pv["exact_mode"]["words_differing_from_serial_gpu"] == 0
+    assert "other_configs" not in d          # (only beside the headline workload: C2 at the full burst size)
