@@ -122,6 +122,9 @@ LEGS = {
                         what="cfg.front_exact = 2 (opt-in, round 6): the front end bit for bit the CPU chain's through the Costas loop -- "
                              "both filters summed in the CPU chain's order without FMA, the AGC and the Costas loop walked exactly "
                              "(csrc/exact_walk.h) --; the clock recovery is the default's, fed like `value`"),
+    "warm_mode": dict(clock_exact=0, front_exact=1, steps=None, ahead=2,
+                      what="cfg.front_exact = 1 (opt-in, round 5; `parity_mode` of round 5's bench): the Costas loop's final pass warms every "
+                           "chain up over the four chains in front of it; everything else the default configuration, fed like `value`"),
     "exact_mode": dict(clock_exact=1, front_exact=0, steps=5, ahead=1,
                        what="cfg.clock_exact = 1: clock recovery relayed to closure, symbols bit-identical to the serial "
                             "float32 recurrence on this chain's Costas output"),

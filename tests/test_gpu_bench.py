@@ -106,7 +106,7 @@ def test_bench_alternative_legs_run_in_processes_of_their_own():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     _check_line(d, 1)
-    for key in ("parity_mode", "exact_mode", "fast_mode", "quick_mode"):
+    for key in ("parity_mode", "warm_mode", "exact_mode", "fast_mode", "quick_mode"):
         assert "error" not in d[key], d[key]
         assert d[key]["ms_per_step"] > 0 and "process of its own" in d[key]["process"], d[key]
     pv = d["parity_vs_oracle"]
