@@ -113,3 +113,44 @@ def test_bench_alternative_legs_run_in_processes_of_their_own():
     assert pv["parity_mode"]["sign_mismatches"] == 0 and pv["parity_mode"]["rms"] <= 1e-4, pv["parity_mode"]
     assert pv["exact_mode"]["words_differing_from_serial_gpu"] == 0
     assert "other_configs" not in d          # (only beside the headline workload: C2 at the full burst size)
+
+
+@pytest.mark.gpu
+def test_handles_created_one_after_the_other_run_alike():
+    """Round 6 (task 2): a handle's streams come from a pool per process, so a handle created after others have
+    been destroyed runs on the very hardware queues of the first one -- round 5 measured 2.5 ms per C2 burst for such a handle
+    against 1.8.  Five handles of the default configuration, one after the other, the same streamed bursts each: none takes more
+    than 1.15 x what the first took."""
+    import time
+    import torch
+    import xritdemod_amd as xa
+    from xritdemod_amd import _capi
+    n, D, fs, nb, steps = 1 << 28, 5, 6.25e6, 4, 12
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((nb, n, 2), dtype=torch.float32, device=dev)
+    sp = _capi.synth_params(fs_in=fs)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for b in range(nb):
+        _capi.synth_generate_device(sp, b * n, n, buf[b].data_ptr(), device=0, stream=st)
+    torch.cuda.synchronize(dev)
+    cap = int(n / (D * 4.2)) + 4096
+    soft = torch.empty(cap, dtype=torch.float32, device=dev)
+    times = []
+    for h in range(5):
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+        for b in range(3):                                   # warm-up: buffers grow, the loops lock
+            dem.process_device(buf[b % nb].data_ptr(), n, soft.data_ptr(), cap, stream=st)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        dem.prefetch_device(buf[3 % nb].data_ptr(), n, stream=st)
+        dem.prefetch_device(buf[4 % nb].data_ptr(), n, stream=st)
+        for b in range(3, 3 + steps):
+            if b + 2 < 3 + steps:
+                dem.prefetch_device(buf[(b + 2) % nb].data_ptr(), n, stream=st)
+            dem.process_device(buf[b % nb].data_ptr(), n, soft.data_ptr(), cap, stream=st)
+        torch.cuda.synchronize(dev)
+        times.append((time.perf_counter() - t0) / steps * 1e3)
+        dem.close()
+        del dem
+    print("ms per burst, handle by handle:", [round(t, 3) for t in times])
+    assert max(times[1:]) <= 1.15 * times[0], times
