@@ -382,3 +382,51 @@ def test_front_exact_2_at_low_snr(xa, oracle_mod):
             g, w = dem.stage(nm), od.stage(nm)
             assert same_words(g, w), (nm, a, first_diff(g, w))
         assert same_words(got, want), (a, first_diff(got, want))
+
+
+def test_front_exact_2_host_rounds_inside_the_streaming_pipeline(xa, oracle_mod, monkeypatch):
+    """Joints left open by the rounds enqueued with a call are closed from the host when the Costas loop is finished -- which, in
+    the streaming pipeline, happens after the burst's clock-recovery walkers have been launched speculatively: they start over on
+    the rewritten output.  A warm-up of 1024 samples and few walkers (XRIT_CX_HIST / XRIT_CX_WALKERS, read at create) force that
+    path on every burst: the words are those of plain calls, and within 1e-4 of the oracle's."""
+    import torch
+    from xritdemod_amd import _capi
+    monkeypatch.setenv("XRIT_CX_HIST", "1024")
+    monkeypatch.setenv("XRIT_CX_WALKERS", "4096")
+    n, fs, nb = 1 << 23, 1.25e6, 4
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((nb, n, 2), dtype=torch.float32, device=dev)
+    sp = _capi.synth_params(fs_in=fs)
+    for b in range(nb):
+        _capi.synth_generate_device(sp, b * n, n, buf[b].data_ptr(), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    cap = int(n / 4.2) + 4096
+
+    def run(plan):
+        soft = torch.empty(cap, dtype=torch.float32, device=dev)
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, 1, front_exact=2))
+        out = []
+        for op, b in plan:
+            if op == "pf":
+                dem.prefetch_device(buf[b].data_ptr(), n)
+            else:
+                k = dem.process_device(buf[b].data_ptr(), n, soft.data_ptr(), cap)
+                out.append(soft[:k].cpu().numpy())
+        return out
+
+    plain = run([("go", b) for b in range(nb)])
+    ahead = run([("pf", 0), ("pf", 1), ("pf", 2), ("go", 0), ("pf", 3), ("go", 1), ("go", 2), ("go", 3)])
+    ref = oracle_mod.Demod(oracle_mod.config("lrit", fs, 1))
+    for b in range(nb):
+        want = ref.process(buf[b].cpu().numpy().view(np.complex64).reshape(-1))
+        assert same_words(plain[b], ahead[b]), b
+        assert len(plain[b]) == len(want)
+        assert rms(plain[b] - want) <= NORTH_STAR_RMS, (b, rms(plain[b] - want))
+    # (that the host did add rounds: the stage object with the same switches)
+    cfg = oracle_mod.config("lrit", fs, 1)
+    d = oracle_mod.Demod(cfg)
+    d.process(buf[0].cpu().numpy().view(np.complex64).reshape(-1))
+    cg = xa.CostasLoop(cfg.pll_alpha, exact=True)
+    cg.Work(d.stage("rrc"))
+    st = cg.exact_stats()
+    assert st["host_rounds"] > 0, st

@@ -1,31 +1,27 @@
 // costas_exact.hip -- cfg.front_exact = 2: the Costas loop walked exactly, 64 samples per step on one wave.
 // Replaces SatHelper::CostasLoop::Work (/root/reference/demodulator/src/demodulator.cpp:152) bit for bit as the CPU chain
-// evaluates it (the test tier's CPU restatement: xo_costas_work with xo_sincosf).  costas.hip evaluates the loop as chains corrected by a
-// Newton hand-off: within ~1e-6 rms of the serial loop, not ON it -- and the float32 Mueller & Mueller recurrence behind it
-// turns any difference into 5e-5 .. 1.1e-4 rms of its own.  This file puts the output on the serial
-// trajectory:
+// evaluates it (the test tier's CPU restatement: xo_costas_work with xo_sincosf).  costas.hip evaluates the loop as chains
+// corrected by a Newton hand-off: within ~1e-6 rms of the serial loop, not ON it -- and the float32 Mueller & Mueller
+// recurrence behind it turns any difference into 5e-5 .. 1.1e-4 rms of its own.  This file puts the
+// output on the serial trajectory; the ranges, walkers and joints are exact_walk.h's, this is the policy:
 //
-//  * One step.  Given the state (phase, freq) in front of a block of 64 samples, lane n holds a guess of the phase in front of
-//    sample n, de-rotates its sample with it (exact_sincos.h: the C library's sincosf, operation for operation in double
-//    precision) and forms its detector output e_n.  The loop filters are then two float additions per sample that do not
-//    involve the samples any more -- freq += beta e_n; phase = (phase + freq) + alpha e_n -- and are run as a SYSTOLIC scan:
-//    every lane adds its predecessor's values (v_add_f32_dpp ... wave_shr:1), 63 times, so that lane n ends up with the state
-//    in front of sample n computed by exactly the serial loop's additions in the serial loop's order.  If the phases that
-//    come out are bit for bit the guesses that went in, all 64 e_n were the serial loop's and so is everything else; if not,
-//    the new phases are the next guess (a Picard iteration: lanes 0..j are exact after j rounds whatever the guess, and the
-//    loop's gain over 64 samples is ~0.08, so a guess that is 1e-6 off is exact after one or two rounds).  The first guess
-//    costs no trigonometry: e_n is taken from the APPROXIMATE output costas.hip has left in the output buffer.
-//    Measured on the CPU (prototype of this scheme on the oracle's signal): 1.76 rounds per block on average.
-//  * Walkers.  A call is cut into ranges; the walker of a range starts `hist` samples in front of it from the approximate
-//    chain start state there (costas.hip's S) and walks those samples quietly: the loop is contractive, and a float32
-//    trajectory started a few ulps beside the true one COINCIDES with it after ~10 k samples (median; 99 %: 30 k; 250 trials
-//    per mode on the CPU) and stays on it.  Walker 0 -- and every walker that would start in front of the call -- starts
-//    from the carried state, exactly.
-//  * Joints.  Walker w's state at the start of its range must be walker w - 1's state at the end of its own, bit for bit;
-//    by induction from walker 0 every output then is the serial loop's.  Where it is not (~1 % of the joints at the default
-//    history), walker w - 1 goes on into range w from its end state, rewriting the output, until its state meets the record
-//    walker w left at every block boundary (costas_exact_fix_kernel; rounds until nothing changes: two are enqueued with
-//    the call, the host looks at the count afterwards and goes on in the rare case something is left).
+//  * One step (cx_block).  Given the state (phase, freq) in front of a block of 64 samples, lane n holds a guess of the phase
+//    in front of sample n, de-rotates its sample with it (exact_sincos.h: the C library's sincosf, operation for operation in
+//    double precision) and forms its detector output e_n.  The loop filters are then two float additions per sample that do
+//    not involve the samples any more -- freq += beta e_n; phase = (phase + freq) + alpha e_n -- and are run over the 64
+//    samples by a scan that performs exactly the serial loop's additions (below).  If the PHASES that come out are bit for bit
+//    the guesses that went in, all 64 e_n were the serial loop's and so is everything the scan made of them; if not, the new
+//    phases are the next guess (a Picard iteration: lanes 0..j are exact after j rounds whatever the guess; the loop's gain
+//    over 64 samples is ~0.08).  The first guess costs no trigonometry: e_n from the APPROXIMATE output costas.hip has left in
+//    the output buffer, corrected for the slowly moving angle between the two (measured on the block before).  1.4 rounds per
+//    block on the test signals.
+//  * The scans.  cx_scan_lattice: inside a binade a float is an integer multiple of its ulp and adding a small increment moves
+//    it by the increment rounded to that lattice, so the two recurrences are integer prefix sums (DPP) -- CERTIFIED lane by lane
+//    by the literal step, restarted behind the first lane whose step does not reproduce (a tie, a binade change, a wrap).
+//    cx_scan_fast / cx_scan_general: systolic, every lane adds its predecessor's values 63 times (v_add_f32_dpp wave_shr:1).
+//  * Start states: costas.hip's chain start states S (approximate: a trajectory started a few ulps beside the true one coincides
+//    with it after ~10 k samples, median; 99 %: 30 k), the carried state for the first range.  costas.hip still runs in this
+//    mode: it leaves S, the first guess, and the clock recovery's timing statistic.
 #include "kernels.h"
 
 #include <cstdlib>
