@@ -260,10 +260,11 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-mode, fast-mode and quick-mode legs (cfg.clock_exact = 1, -2, -3)")
     ap.add_argument("--no-serial-floor", action="store_true",
                     help="skip the serial-device run of the parity leg (cfg.clock_serial: ~0.3 us per symbol)")
-    ap.add_argument("--front-exact", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--front-exact", type=int, default=0, choices=[-1, 0, 1, 2],
                     help="cfg.front_exact of the measured handle (include/xritdemod_amd.h): 1 = the Costas loop's final pass warmed up over "
                          "four chains; 2 = the front end bit for bit the CPU chain's through the Costas loop (round 6); the default, 0, "
-                         "is the configuration `value` is quoted on")
+                         "is the configuration `value` is quoted on (the fast front end on bursts of a million symbols and more, the bit-exact "
+                         "one on smaller calls); -1 = the fast one on calls of every size")
     ap.add_argument("--mode", choices=["lrit", "hrit"], default="lrit",
                     help="lrit: 293 883 sym/s, alpha 0.5, circuit rate 1.25 Msps (C2, C5; --decimation 1 = C1's chain); "
                          "hrit: 927 000 sym/s, alpha 0.3, circuit rate 2.5 Msps (C3)")

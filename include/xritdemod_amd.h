@@ -140,7 +140,12 @@ typedef struct xrit_demod_config {
                                  *      there for their end states): 1.92 ms per streamed burst, 1.15e-4 rms from the serial
                                  *      trajectory.  Faster AND closer than -2. */
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
-    int32_t  front_exact;       /* opt-in parity mode (round 5; 0 = off).  What the soft symbols' distance from the CPU chain is made
+    int32_t  front_exact;       /* which front end a call takes (round 6).  0 (default): the bit-exact one (see 2) on calls below the
+                                 * big-burst size -- the reference's chunk sizes and everything up to a million symbols, where a call
+                                 * is launch latency, not throughput: a call of up to 74 k symbols then yields the CPU chain's soft
+                                 * symbols word for word -- and the fast one on bursts of a million symbols and more (what `value`
+                                 * is quoted on); -1: the fast one on calls of every size (round 5's default).
+                                 * The fast front end:  What the soft symbols' distance from the CPU chain is made
                                  * of is the front end's distance at the Costas loop's output (1.1e-6 rms as shipped; ANY distance
                                  * costs a float32 M&M 5.5e-5 on LRIT), and most of that is what the
                                  * hand-offs between the loop's 256-sample chains leave: a chain's start a few 1e-6 rad beside its

@@ -13,7 +13,8 @@ for fs, D in ((1.25e6, 1), (6.25e6, 5)):
         st = torch.cuda.current_stream().cuda_stream
         for b in range(40):
             _capi.synth_generate_device(sp, b * n, n, buf[b].data_ptr(), device=0, stream=st)
-        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_chain_syms=int(__import__("os").environ.get("NS", "0"))))
+        dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, clock_chain_syms=int(__import__("os").environ.get("NS", "0")),
+                                                          front_exact=int(__import__("os").environ.get("FRONT_EXACT", "0"))))
         soft = torch.empty((n,), dtype=torch.float32, device="cuda:0")
         for b in range(10):
             dem.process_device(buf[b].data_ptr(), n, soft.data_ptr(), n, stream=st)

@@ -286,16 +286,17 @@ CASES = {
 
 
 NORTH_STAR_RMS = 1.0e-4        # BASELINE.json north_star: "soft-symbol output within 1e-4 RMS of reference"
-# Where the default configuration is KNOWN to sit above it on the test burst of CASES (measured, round 5, gpurun_out r5a: C1 1.31e-4
-# with the serial float32 trajectory itself at 1.05e-4 from the oracle, C2 1.19e-4 = its serial floor, C3 1.09e-4 / 0.97e-4; C5
-# 1.2e-5): short cold-started bursts, where two float32 M&M trajectories on Costas outputs 1e-6 apart part most:
+# Round 6: the DEFAULT configuration (cfg.front_exact = 0) runs the bit-exact front end on every call below the big-burst size
+# (a million symbols), i.e. on all of CASES' test bursts: it meets the tolerance on every one of them, plainly.  Where the FAST
+# front end alone (cfg.front_exact = -1: round 5's default) is KNOWN to sit above it on these bursts (measured, round 5, gpurun_out
+# r5a: C1 1.31e-4 with the serial float32 trajectory itself at 1.05e-4 from the oracle, C2 1.19e-4 = its serial floor, C3 1.09e-4
+# / 0.97e-4; C5 1.2e-5): short cold-started bursts, where two float32 M&M trajectories on Costas outputs 1e-6 apart part most:
 NORTH_STAR_MISS = {"C1", "C2", "C3"}
 
 
 def north_star_tol(case):
-    """1e-4 where the configuration meets BASELINE.json's tolerance on its test burst; for the known miss the old bound, so that
-    the other assertions of a test still guard it (the miss itself is asserted by test_north_star_1e_4_on_the_test_bursts)."""
-    return 1.5e-4 if case in NORTH_STAR_MISS else NORTH_STAR_RMS
+    """BASELINE.json's tolerance: the default configuration meets it on every test burst (round 6)."""
+    return NORTH_STAR_RMS
 
 
 def report_parity(what, **values):
@@ -405,23 +406,40 @@ def _north_star_params(cases, miss, why, loose=()):
             for c in cases]
 
 
-@pytest.mark.parametrize("case", _north_star_params(CASES, NORTH_STAR_MISS,
-                         "known miss: on these cold-started bursts the serial float32 trajectory itself is 1.0e-4 .. 1.2e-4 from the oracle"))
+@pytest.mark.parametrize("case", list(CASES))
 def test_north_star_1e_4_on_the_test_bursts(xa, oracle_mod, case):
     """BASELINE.json's tolerance, as written: the DEFAULT configuration's soft symbols within 1e-4 rms of the oracle's, hard
-    decisions equal.  No floor clause.  C3 is a strict expected failure (if it ever passes, this list must change); the
-    measured value and the serial floor of the same samples go to the warnings summary either way."""
+    decisions equal.  No floor clause, no expected failure (round 6: calls of this size take the bit-exact front end by default;
+    what is left is the relay's distance from the serial trajectory, and on calls of up to 74 k symbols nothing at all)."""
     mode, fs, D, kw, n = CASES[case]
     x = synth_signal(n, **kw)
     want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
     got = xa.Demodulator(xa.Demodulator.config(mode, fs, D)).process(x)
-    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, clock_serial=1)).process(x)
+    assert len(got) == len(want)
+    big = np.abs(want) > 1e-3
+    assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
+    r = rms(got - want)
+    report_parity(f"north star 1e-4, test burst, default configuration, {case}", rms_vs_oracle=r, met=bool(r <= NORTH_STAR_RMS))
+    assert r <= NORTH_STAR_RMS, (case, r)
+
+
+@pytest.mark.parametrize("case", _north_star_params(CASES, NORTH_STAR_MISS,
+                         "known miss: on these cold-started bursts the serial float32 trajectory itself is 1.0e-4 .. 1.2e-4 from the oracle"))
+def test_north_star_1e_4_on_the_test_bursts_with_the_fast_front_end(xa, oracle_mod, case):
+    """The same assertion for cfg.front_exact = -1 (the fast front end on calls of every size: round 5's default): C1, C2, C3
+    are strict expected failures (if one ever passes, this list must change); the measured value and the serial floor of the same
+    samples go to the warnings summary either way."""
+    mode, fs, D, kw, n = CASES[case]
+    x = synth_signal(n, **kw)
+    want = oracle_mod.Demod(oracle_mod.config(mode, fs, D)).process(x)
+    got = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=-1)).process(x)
+    ser = xa.Demodulator(xa.Demodulator.config(mode, fs, D, front_exact=-1, clock_serial=1)).process(x)
     _must(len(got) == len(want) == len(ser), "symbol count")
     big = np.abs(want) > 1e-3
     _must(np.array_equal(np.sign(got[big]), np.sign(want[big])), "hard decisions")
     r, floor = rms(got - want), rms(ser - want)
     _must(r <= 1.5e-4, "beyond the known miss", r, floor)
-    report_parity(f"north star 1e-4, test burst, {case}", rms_vs_oracle=r, serial_floor=floor, met=bool(r <= NORTH_STAR_RMS))
+    report_parity(f"north star 1e-4, test burst, fast front end, {case}", rms_vs_oracle=r, serial_floor=floor, met=bool(r <= NORTH_STAR_RMS))
     assert r <= NORTH_STAR_RMS, (case, r, floor)
 
 
@@ -1099,7 +1117,7 @@ def test_front_exact_warms_the_final_costas_pass_up(xa, oracle_mod):
         assert r <= 1.5e-4, (b, r)
     assert not np.array_equal(plain[1].view(np.uint32), base[1].view(np.uint32))       # (the mode does something)
     with pytest.raises(xa.XritError):
-        xa.Demodulator(cfg(front_exact=3))       # (2 is round 6's bit-exact front end: tests/test_gpu_exact.py)
+        xa.Demodulator(cfg(front_exact=3))       # (2 is round 6's bit-exact front end: tests/test_gpu_exact.py; -1: never)
 
 
 @pytest.mark.parametrize("mode,fs,D,kw", [("lrit", 6.25e6, 5, dict(fs_in=6.25e6)), ("hrit", 2.5e6, 1, dict(fs_in=2.5e6, symbol_rate=927000.0, alpha=0.3))])
@@ -2199,30 +2217,42 @@ def _run_case(xa, oracle_mod, mode, D, fs, n, typ, p, cuts, keep, **cfg):
     return np.concatenate(want), np.concatenate(got)
 
 
-def test_randomised_chains(xa, oracle_mod):
+@pytest.mark.parametrize("front_exact", [0, -1])
+def test_randomised_chains(xa, oracle_mod, front_exact):
     """A fixed-seed slice of tests/experiments/fuzz_chain.py (which found every regression case above): random mode,
     decimation, length, chunking, ingest type, carrier inside the lock-in range, clock error, kept or fused stages.
-    Es/N0 6..20 dB: same symbol count, hard decisions identical, soft rms <= 6e-4 on every case (short cold-started
+    cfg.front_exact = -1 (the fast front end on calls of every size: what the fuzz was run on).  Es/N0 6..20 dB: same symbol
+    count, hard decisions identical, soft rms <= 6e-4 on every case (short cold-started
     calls: most close exactly, the worst acquisitions are 4..5e-4).  Es/N0 2..6 dB, where one symbol in ten is wrong
     anyway and far more of them sit near zero: same symbol count, at most one differing hard decision per 10^4
     symbols, rms <= 1e-3 (fuzz, 150 cases: two above 6e-4, one flipped decision in 16 413 symbols at 2.7 dB; the
-    serial-device run of those cases agrees with the oracle, i.e. this is the hand-offs' doing and is stated as such)."""
+    serial-device run of those cases agrees with the oracle, i.e. this is the hand-offs' doing and is stated as such).
+    cfg.front_exact = 0 (the default, round 6: calls of these sizes take the bit-exact front end): BASELINE's 1e-4 on every
+    case, whatever the noise -- and on most of them, whose clock recovery is one exact walk, every word is the oracle's."""
     rng = np.random.default_rng(20260929)
-    worst = 0.0
+    worst, exact_cases, cases = 0.0, 0, 0
     for c in range(48):
         low = c >= 28
         case = _random_case(rng, 2, 6) if low else _random_case(rng, 6, 20)
-        w, g = _run_case(xa, oracle_mod, *case)
+        w, g = _run_case(xa, oracle_mod, *case, front_exact=front_exact)
         if len(w):
             big = np.abs(w) > 1e-3
             flips = int(np.sum(np.sign(w[big]) != np.sign(g[big])))
             r = rms(w - g)
-            if low:
+            cases += 1
+            exact_cases += int(np.array_equal(w.view(np.uint32), g.view(np.uint32)))
+            if front_exact == 0:
+                assert flips == 0 and r <= NORTH_STAR_RMS, (c, case[:5], flips, r)
+            elif low:
                 assert flips == 0 and r <= 1e-3, (c, case[:5], flips, r)
             else:
                 assert flips == 0 and r <= 6e-4, (c, case[:5], flips, r)
             worst = max(worst, r)
-    assert worst > 0.0
+    report_parity(f"randomised chains, cfg.front_exact = {front_exact}", worst_rms=worst, cases=cases, word_for_word=exact_cases)
+    if front_exact == -1:
+        assert worst > 0.0
+    else:
+        assert exact_cases >= cases // 2, (exact_cases, cases)
 
 
 @pytest.mark.parametrize("seed,esn0,carrier,ppm,toff,ph,n", [
@@ -2278,7 +2308,9 @@ def test_pull_in_through_cycle_slips_is_walked_serially(xa, oracle_mod, monkeypa
     n = 1228445
     x = synth.generate(p, n)
     want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, 5)).process(x)
-    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    # (cfg.front_exact = -1: the case is one of the fast front end's -- on the bit-exact matched-filter output the hand-off of this
+    # very call happens to close before it runs out of passes, and there would be nothing to rescue)
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, front_exact=-1))
     got = dem.process(x)
     st = dem.stats()
     assert len(got) == len(want)
@@ -2286,6 +2318,6 @@ def test_pull_in_through_cycle_slips_is_walked_serially(xa, oracle_mod, monkeypa
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big])) and rms(got - want) <= 6e-4
     monkeypatch.setenv("XRIT_NO_SERIAL_WALK", "1")
-    dem2 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5))
+    dem2 = xa.Demodulator(xa.Demodulator.config("lrit", 6.25e6, 5, front_exact=-1))
     dem2.process(x)
     assert dem2.stats().costas_serial_walk == 0 and dem2.stats().costas_unconverged > 0

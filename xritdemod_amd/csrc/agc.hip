@@ -150,9 +150,9 @@ int AgcStage::request_flag(hipStream_t s)
     return XRIT_OK;
 }
 
-int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof)
+int AgcStage::run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool use_exact)
 {
-    if (exact) return run_exact(in, out, n, s, prof);
+    if (exact || use_exact) return run_exact(in, out, n, s, prof);
     if (n == 0) return XRIT_OK;
     float *sin_ = state.as<float>() + 2 * cur;
     float *sout = state.as<float>() + 2 * (cur ^ 1);

@@ -804,7 +804,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
     XR_HIP(hipMemcpyAsync(h_counters, counters.p, COSTAS_CTL_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     XR_HIP(hipGetLastError());
     }
-    if (exact) XR_TRY(enqueue_exact(s, prof));      // (behind the bracket of the final pass: the profiler's scopes do not nest)
+    if (job.exact) XR_TRY(enqueue_exact(s, prof));      // (behind the bracket of the final pass: the profiler's scopes do not nest)
     return XRIT_OK;
 }
 
@@ -812,7 +812,7 @@ int CostasStage::enqueue_final(hipStream_t s, Profiler *prof)
 // no-op once the device-side test has declared the hand-off closed), the final pass and the copy of the control
 // block.  finish() is called after the caller has synchronised the stream.
 int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof,
-                       const float2 *sub_ext, double2 *om, long long om_off, double inv_sps)
+                       const float2 *sub_ext, double2 *om, long long om_off, double inv_sps, bool use_exact)
 {
     const bool locked = passes > 0 && passes <= 3 && unconverged == 0;      // how the previous call went
     passes = 0;
@@ -822,6 +822,7 @@ int CostasStage::begin(const float2 *in, float2 *out, size_t n, hipStream_t s, P
     walked = false;
     ex_args_valid = false;
     job.in = in; job.out = out; job.n = n; job.om = om; job.om_off = om_off; job.inv_sps = inv_sps;
+    job.exact = exact || use_exact;
     job.model_accept = locked ? model_accept : 0.f;
     if (n == 0) return XRIT_OK;
     const int K = (int)((n + (size_t)L - 1) / (size_t)L);
@@ -962,7 +963,7 @@ int CostasStage::finish(hipStream_t s, Profiler *prof, bool *redone)
         fprintf(stderr, "[xrit] costas: %d passes, closed %u, on prediction %u, left open %u, max residual %.3e\n", passes, h_counters[0],
                 h_counters[6], h_counters[2], max_residual);
     }
-    if (exact) {
+    if (job.exact) {
         XR_TRY(finish_exact(s, prof, redone));
         ex_blocks += h_xcnt ? h_xcnt[1] : 0;
         ex_picard += h_xcnt ? h_xcnt[2] : 0;

@@ -80,6 +80,7 @@ struct xrit_demod {
     struct Prefetched {
         const void *samples = nullptr; size_t n = 0; int type = 0; int set = 0;
         size_t length = 0; const float2 *rrc = nullptr; bool stat_ready = false; const float *agc_flag = nullptr;
+        bool exact = false;             // its front end was the bit-exact one (front_exact_call)
         bool costas_begun = false;      // the Costas loop of this input has been started too (on stream2, behind its front end)
         float2 *slot = nullptr;         // ... writing here (the clock recovery's next input buffer)
         // round 5, bursts whose clock recovery walks overlapping blocks (clock_overlap.h): everything up to the walkers runs ahead
@@ -303,8 +304,8 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         set_error("AGC rate, reference and initial gain must be positive (Parameters.h:34-37: 0.01, 0.5, 1, 4000)");
         return XRIT_E_INVALID;
     }
-    if (cfg->front_exact < 0 || cfg->front_exact > 2) {
-        set_error("front_exact = %d: 0 (off), 1 or 2", cfg->front_exact);
+    if (cfg->front_exact < -1 || cfg->front_exact > 2) {
+        set_error("front_exact = %d: -1 (never), 0 (below the big-burst size), 1 or 2 (always)", cfg->front_exact);
         return XRIT_E_INVALID;
     }
     if (!(cfg->sample_rate / (float)cfg->decimation / (float)cfg->symbol_rate >= 1.0f)) {
@@ -454,11 +455,28 @@ struct SliceIO {
     bool stat_ready = false;
     int set = 0;                // which set of front-end buffers
     const float *agc_flag = nullptr;    // the AGC guard flag of THIS front end (the stage's slot moves on with the next)
+    bool exact = false;         // this call's front end is the bit-exact one (cfg.front_exact = 2, or 0 on a call below the big-burst size)
 };
+
+// Which front end a call of n input samples takes.  cfg.front_exact = 2: the bit-exact one, always; 0 (default, round 6): the
+// bit-exact one for calls below the big-burst size -- the reference's own chunk sizes (32 Ki .. 512 Ki samples) and everything
+// up to a million symbols, where a call is launch latency and not throughput: the soft symbols of a call of up to 74 k symbols
+// are then the CPU chain's word for word -- and the fast one for bursts of a million symbols and more, the ones `value` is
+// quoted on; 1: the fast one with the Costas loop's final pass warmed up; -1: the fast one, always (round 5's default).
+static bool front_exact_call(const xrit_demod *d, size_t n)
+{
+    if (d->cfg.front_exact == 2) return true;
+    if (d->cfg.front_exact != 0) return false;
+    const unsigned D = d->cfg.decimation;
+    const double length = (double)(D > 1 ? n / D : n);
+    return length / (double)d->sps < (double)d->clock.ov_min;
+}
 
 static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set, hipStream_t s, Profiler *prof, SliceIO *io)
 {
     io->set = set;
+    const bool ex = front_exact_call(d, n);
+    io->exact = ex;
     const unsigned D = d->cfg.decimation;
     if (type == XRIT_SAMPLE_U8IQ) {
         // RtlFrontend::internalCallback (RtlFrontend.cpp:102-116) hands FLOATIQ to onSamplesAvailable
@@ -476,11 +494,11 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     const float2 *cur = nullptr;
     // with a decimator in front, its epilogue leaves the AGC's composed gain maps: the AGC sweeps the stream
     // twice (scan of the maps aside) instead of three times
-    const bool agc_fused = D > 1 && length > 0 && d->dec.agc_supported();
+    const bool agc_fused = !ex && D > 1 && length > 0 && d->dec.agc_supported();
     if (D > 1) {
         AgcEpilogue epi{};
         if (agc_fused) XR_TRY(d->agc.fused_begin(length, d->dec.RC, s, &epi));
-        XR_TRY(d->dec.run(in, type, A, length, s, prof, nullptr, 0, agc_fused ? &epi : nullptr));          // :138
+        XR_TRY(d->dec.run(in, type, A, length, s, prof, nullptr, 0, agc_fused ? &epi : nullptr, nullptr, ex));          // :138
         cur = A;
     } else if (type != XRIT_SAMPLE_FLOATIQ) {
         ProfScope ps(prof, "convert", s);
@@ -495,7 +513,7 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     const bool agc_in_rrc = agc_fused && !d->keep_stages && d->rrc.agc_fill_supported(d->dec.RC);
     // no decimator (C1, C3), or one whose kernel has no such epilogue (the polyphase one, C5): the run maps come
     // from one read-only sweep, the rest is the same
-    const bool agc_in_rrc_d1 = !agc_fused && length > 0 && !d->keep_stages && d->rrc.agc_fill_supported(3);
+    const bool agc_in_rrc_d1 = !ex && !agc_fused && length > 0 && !d->keep_stages && d->rrc.agc_fill_supported(3);
     AgcFill fill{};
     float2 *Cfb = nullptr;      // where the serial fallback would put the AGC output (guard tripped)
     if (agc_in_rrc || agc_in_rrc_d1) {
@@ -505,7 +523,7 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
         XR_TRY(d->agc.fused_scan(cur, Cfb, length, agc_in_rrc ? d->dec.RC : 3, s, prof, &fill));    // :143
     }
     else if (agc_fused) XR_TRY(d->agc.fused_finish(cur, B, length, d->dec.RC, s, prof));
-    else XR_TRY(d->agc.run(cur, B, length, s, prof));
+    else XR_TRY(d->agc.run(cur, B, length, s, prof, ex));
     XR_TRY(keep_stage(d, 1, B, length, s));
     // the RRC epilogue leaves the per-chain statistic of the Costas guess, the Costas final pass the
     // timing-line statistic of the clock-recovery guess: neither stage sweeps its input once more for it
@@ -517,7 +535,7 @@ static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set,
     const bool fill_on = agc_in_rrc || agc_in_rrc_d1;
     float2 *rrc_out = fill_on ? B : A;
     XR_TRY(d->rrc.run(fill_on ? Cfb : B, XRIT_SAMPLE_FLOATIQ, rrc_out, length, s, prof, io->stat_ready ? d->stat[set].as<float2>() : nullptr, SUB,
-                      nullptr, fill_on ? &fill : nullptr)); // :148
+                      nullptr, fill_on ? &fill : nullptr, ex)); // :148
     XR_TRY(keep_stage(d, 2, rrc_out, length, s));
     io->rrc = rrc_out;
     io->agc_flag = d->agc.state.as<float>() + 2 * d->agc.cur + 1;
@@ -546,7 +564,7 @@ static int launch_prefetched(xrit_demod *d, xrit_demod::Prefetched &f, hipEvent_
     XR_HIP(hipEventRecord(d->ev_fe[set], d->stream2));
     d->last_fe_set = set;
     f.set = set;
-    f.length = io.length; f.rrc = io.rrc; f.stat_ready = io.stat_ready; f.agc_flag = io.agc_flag;
+    f.length = io.length; f.rrc = io.rrc; f.stat_ready = io.stat_ready; f.agc_flag = io.agc_flag; f.exact = io.exact;
     f.launched = true;
     return XRIT_OK;
 }
@@ -563,7 +581,7 @@ static int costas_enqueue(xrit_demod *d, const SliceIO &io, hipStream_t s, Profi
     if (length) om = d->clock.om_slot((int)((length + (size_t)L - 1) / (size_t)L), L);
     const double inv_sps = 1.0 / (double)d->sps;
     const float2 *stat = io.stat_ready ? d->stat[io.set].as<float2>() : nullptr;
-    XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, 0, inv_sps));
+    XR_TRY(d->costas.begin(io.rrc, slot, length, s, prof, stat, om, 0, inv_sps, io.exact));
     if (length) XR_TRY(d->clock.om_scan(s));     // the timing guess's count curve, behind the final pass that leaves its statistic
     if (length) XR_TRY(d->agc.request_flag_at(io.agc_flag, s));   // the AGC's guard flag rides along: no wait of its own
     *slot_out = slot;
@@ -586,7 +604,7 @@ static void set_relay_hook(xrit_demod *d, hipStream_t s)
             if (d->costas_idle) {
                 xrit_demod::Prefetched &f = d->pf[0];
                 SliceIO io;
-                io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+                io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag; io.exact = f.exact;
                 int rc = costas_enqueue(d, io, d->stream2, d->prof.enabled ? &d->prof : nullptr, &f.slot);
                 if (rc != XRIT_OK) { d->poisoned = true; return rc; }
                 XR_HIP(hipEventRecord(d->ev_costas, d->stream2));
@@ -711,7 +729,7 @@ static int ov_service(xrit_demod *d, bool *progress, int limit = 1 << 30)
         }
         if (!f.costas_begun && !costas_busy) {
             SliceIO io;
-            io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+            io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag; io.exact = f.exact;
             // (on a stream of its own behind this input's front end: the front end of the input behind it runs beside this loop)
             // (on the front ends' stream, behind this input's: measured with every stream on a hardware queue of its own
             // -- GPU_MAX_HW_QUEUES=8 -- a Costas stream beside the front ends' costs 10 %, 2.05 against 1.85 ms per C2 burst: the
@@ -878,7 +896,7 @@ int xrit_demod_process_device(xrit_demod *d, const void *d_samples, size_t n, in
         const xrit_demod::Prefetched f = d->pf[0];
         for (int i = 1; i < d->pf_count; ++i) d->pf[i - 1] = d->pf[i];
         --d->pf_count;
-        io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag;
+        io.length = f.length; io.rrc = f.rrc; io.stat_ready = f.stat_ready; io.set = f.set; io.agc_flag = f.agc_flag; io.exact = f.exact;
         if (f.costas_begun) {
             // its Costas loop ran ahead as well (under the relay of the call before): the host looks at its stop test now
             // (continuing the passes on stream2 in the rare case the batch did not close), the clock recovery follows on s.

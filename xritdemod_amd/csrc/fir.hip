@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <new>
 #include "agc_wave.h"
 
 namespace xrit {
@@ -740,6 +741,15 @@ fir_exact_kernel(const void *__restrict__ in, const float2 *__restrict__ hist, f
 int FirStage::init(const float *taps, int ntaps, int decim)
 {
     taps_host.assign(taps, taps + ntaps);
+    // the exact-order twin (the chain chooses per call; a stage that is exact itself has none)
+    if (twin) { twin->release(); delete twin; twin = nullptr; }
+    last_twin = false;
+    if (!exact) {
+        twin = new (std::nothrow) FirStage();
+        if (!twin) return XRIT_E_NOMEM;
+        twin->exact = true;
+        XR_TRY(twin->init(taps, ntaps, decim));
+    }
 
     // diagnostic switches are read once, here: never on the launch path (a host that calls setenv races with getenv)
     no_static_dec = getenv("XRIT_NO_STATIC_DEC") != nullptr;
@@ -858,6 +868,8 @@ int FirStage::init(const float *taps, int ntaps, int decim)
 
 int FirStage::reset(hipStream_t s)
 {
+    if (twin) XR_TRY(twin->reset(s));
+    last_twin = false;
     XR_HIP(hipMemsetAsync(hist[0].p, 0, hist[0].bytes, s));
     XR_HIP(hipMemsetAsync(hist[1].p, 0, hist[1].bytes, s));
     cur = 0;
@@ -888,6 +900,7 @@ int FirStage::set_exact(bool on)
 
 void FirStage::release()
 {
+    if (twin) { twin->release(); delete twin; twin = nullptr; }
     rt.release();
     g.release();
     mfb.release();
@@ -961,8 +974,18 @@ static int fir_launch_agc_fill(FirStage &f, const float2 *in, float2 *out, size_
 }
 
 int FirStage::run(const void *in, int type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof, float2 *stat,
-                  int statL, const AgcEpilogue *agc_in, const AgcFill *fill)
+                  int statL, const AgcEpilogue *agc_in, const AgcFill *fill, bool use_exact)
 {
+    if (twin && T > 1 && use_exact != last_twin) {
+        // the call changes sides: the T - 1 samples of history go along
+        FirStage &from = last_twin ? *twin : *this, &to = last_twin ? *this : *twin;
+        XR_HIP(hipMemcpyAsync(to.hist[to.cur].p, from.hist[from.cur].p, (size_t)(T - 1) * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    }
+    if (twin) last_twin = use_exact;
+    if (twin && use_exact) {
+        twin->prio = prio;
+        return twin->run(in, type, out, n_out, s, prof, stat, statL, agc_in, fill, false);
+    }
     if (fill) {
         if (!agc_fill_supported(fill->per_lane) || type != XRIT_SAMPLE_FLOATIQ || T < 2) {
             set_error("FIR: this filter cannot apply the AGC in its window fill");

@@ -40,9 +40,13 @@ struct FirStage {
     // agc (optional): the AGC's composed gain map per run of 64 * RC outputs, see AgcStage::fused_begin
     // fill (optional, D == 1): the input is the AGC's INPUT stream; the window fill applies the AGC on the fly
     // (AgcStage::fused_scan fills the descriptor) -- the AGC output is never written
+    // use_exact (the chain's per-call choice, round 6): this call through the exact-order twin (a second stage object with
+    // `exact` set, created beside every stage that is not exact itself; the T - 1 samples of history follow the call)
     int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof,
             float2 *stat = nullptr, int statL = 0, const struct AgcEpilogue *agc = nullptr,
-            const struct AgcFill *fill = nullptr);
+            const struct AgcFill *fill = nullptr, bool use_exact = false);
+    FirStage *twin = nullptr;
+    bool last_twin = false;     // the last call went through the twin: the history lives there
     bool agc_fill_supported(int per_lane) const;
     bool stat_supported(int statL) const;
     bool agc_supported() const;
@@ -89,7 +93,7 @@ struct AgcStage {
     int reset(hipStream_t s);
     float gain0 = 1.0f;
     void release();
-    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof);
+    int run(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, bool use_exact = false);
     // cfg.front_exact = 2: chains walked literally from the scan's gains, warmed up until they ARE the serial recurrence (agc.hip)
     bool exact = false;
     DevBuf joints;   // exact_walk.h's joints, block records and counters
@@ -153,7 +157,7 @@ struct CostasStage {
     // the same in two halves: begin() only enqueues (guess, a batch of passes with a device-side stop test, final
     // pass); finish() runs after the caller synchronised the stream and continues the passes if they did not close
     int begin(const float2 *in, float2 *out, size_t n, hipStream_t s, Profiler *prof, const float2 *sub_ext,
-              double2 *om, long long om_off, double inv_sps);
+              double2 *om, long long om_off, double inv_sps, bool use_exact = false);
     bool closed() const;
     int finish(hipStream_t s, Profiler *prof, bool *redone);
     int enqueue_passes(int count, hipStream_t s, Profiler *prof);
@@ -163,6 +167,7 @@ struct CostasStage {
         double2 *om = nullptr; long long om_off = 0; double inv_sps = 0;
         bool gated = false;     // this call has gone over to the gated solve
         bool rescued = false;   // the serial walk has been tried
+        bool exact = false;     // this call's output is put on the serial trajectory (costas_exact.hip)
         float model_accept = 0; // CostasPolicy::model_accept of this call: the stage's on a tracking loop, else 0
     } job;
     int batch = 4;          // passes enqueued before the host looks: what the previous call needed + a spare one
