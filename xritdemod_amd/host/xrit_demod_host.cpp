@@ -89,7 +89,8 @@ void usage()
                  "         [--diag udp://HOST:PORT] [--drop [--queue-symbols N]] [--sndbuf BYTES]\n"
                  "         [--gpus N]   (devices 0..N-1: each block of --block samples is cut in N time slices, RCCL edge exchange)\n"
                  "         [--fifo [--fifo-block SAMPLES] [--fifo-lag BLOCKS]]   (the reference's FIFO chunking, demodulator.cpp:108-119)\n"
-                 "         [--front-exact [1|2]]   (cfg.front_exact; 1: the Costas loop's final pass warmed up, ~12 %% slower on big blocks;\n"
+                 "         [--front-exact [-1|1|2]]   (cfg.front_exact; default 0: the bit-exact front end on blocks of less than a million symbols;\n"
+                 "                                  -1: the fast one always; 1: the Costas loop's final pass warmed up, ~12 %% slower on big blocks;\n"
                  "                                  2: filters, AGC and Costas loop bit for bit a CPU chain's -- soft symbols within 1e-4 rms of it\n"
                  "                                  on every configuration, ~3 x slower on big blocks)\n");
 }
@@ -121,7 +122,7 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--fifo") o.fifo = true;
         else if (a == "--front-exact") {
             o.front_exact = 1;
-            if (i + 1 < argc && (std::string(argv[i + 1]) == "1" || std::string(argv[i + 1]) == "2")) o.front_exact = atoi(argv[++i]);
+            if (i + 1 < argc && (std::string(argv[i + 1]) == "1" || std::string(argv[i + 1]) == "2" || std::string(argv[i + 1]) == "-1")) o.front_exact = atoi(argv[++i]);
         }
         else if (a == "--drop") o.drop = true;
         else if (a == "--paced") o.paced = true;
