@@ -1269,7 +1269,10 @@ def test_overlap_pipeline_survives_resets_refusals_and_abandoned_inputs(xa):
         d.prefetch_device(buf[b].data_ptr(), n)
     for b in range(2):
         k = d.process_device(buf[b].data_ptr(), n, soft.data_ptr(), cap)
-        assert np.array_equal(soft[:k].cpu().numpy().view(np.uint32), plain[b].view(np.uint32)), b
+        got_b = soft[:k].cpu().numpy()
+        same = k == len(plain[b]) and np.array_equal(got_b.view(np.uint32), plain[b].view(np.uint32))
+        assert same, (b, k, len(plain[b]), int(np.sum(got_b.view(np.uint32) != plain[b].view(np.uint32))) if k == len(plain[b]) else -1,
+                      rms(got_b - plain[b]) if k == len(plain[b]) else -1.0)
     # out of order: the handle cannot go on
     d.prefetch_device(buf[2].data_ptr(), n)
     with pytest.raises(xa.XritError):
