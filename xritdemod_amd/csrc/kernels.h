@@ -45,8 +45,11 @@ struct FirStage {
     int run(const void *in, int sample_type, float2 *out, size_t n_out, hipStream_t s, Profiler *prof,
             float2 *stat = nullptr, int statL = 0, const struct AgcEpilogue *agc = nullptr,
             const struct AgcFill *fill = nullptr, bool use_exact = false);
-    FirStage *twin = nullptr;
+    FirStage *twin = nullptr;   // (owned: released in release())
     bool last_twin = false;     // the last call went through the twin: the history lives there
+    FirStage() = default;
+    FirStage(const FirStage &) = delete;
+    FirStage &operator=(const FirStage &) = delete;
     bool agc_fill_supported(int per_lane) const;
     bool stat_supported(int statL) const;
     bool agc_supported() const;
