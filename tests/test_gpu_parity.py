@@ -1764,17 +1764,21 @@ def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     assert len(got) == len(want)
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert rms(s0 - want[:len(s0)]) < 2.5e-4
+    # (round 6: rank 0 is the stream's own chain on a slice of 42 k symbols -- the bit-exact front end by default at this size, one
+    # exact walk behind it: the oracle's words)
+    assert np.array_equal(s0.view(np.uint32), want[:len(s0)].view(np.uint32)), rms(s0 - want[:len(s0)])
     # round 3: a rank whose Costas loop locked pi away from the stream runs its clock recovery once more on the
     # sign-flipped Costas output (xrit_demod_redo_clock_flipped) -- both polarities end at the same floor
     # (round 2: 3e-3 for the flipped one, the M&M detector slices to {0, 1})
-    assert rms(s1 - want[len(s0):]) < 2.5e-4, (pol1, rms(s1 - want[len(s0):]))
+    # (rank 1 cold-starts its loops over the halo: its clock recovery has not met the stream's after 24 576 symbols -- measured
+    # 1.6e-5 .. 1.3e-4 over the four start phases of the next test, scripts/r6_group_parity.py)
+    assert rms(s1 - want[len(s0):]) < 1.5e-4, (pol1, rms(s1 - want[len(s0):]))
 
 
 def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
     """Both locks of rank 1 are exercised: the start phase of the capture is moved by a quarter turn at a time, so that
     rank 1 (cold start over its halo) falls on either side of the stream rank 0 follows; the joined output must be the
-    uninterrupted chain's to 2.5e-4 rms with identical decisions in every case."""
+    uninterrupted chain's with identical decisions in every case -- rank 0 word for word, rank 1 to 1.5e-4 rms."""
     import threading
     import torch
     n, D = 900000, 5
@@ -1813,7 +1817,10 @@ def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
         big = np.abs(want) > 1e-3
         assert np.array_equal(np.sign(sgn * got[big]), np.sign(want[big])), ph
         if sgn > 0:
-            assert rms(s1 - want[len(s0):]) < 2.5e-4, (ph, pol1)
+            # (round 6: rank 0 -- the stream's own chain, the bit-exact front end at this size -- is the oracle's words; rank 1,
+            # cold-started over its halo, 1.6e-5 .. 1.3e-4 whichever lock it fell on: scripts/r6_group_parity.py)
+            assert np.array_equal(s0.view(np.uint32), want[:len(s0)].view(np.uint32)), ph
+            assert rms(s1 - want[len(s0):]) < 1.5e-4, (ph, pol1, rms(s1 - want[len(s0):]))
     assert seen == {1, -1}, seen
 
 
