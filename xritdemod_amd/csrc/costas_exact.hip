@@ -268,6 +268,10 @@ int CostasStage::exact_plan(size_t n, int *Lw, int *W, int *H) const
     const size_t unit = (size_t)L * 64 / (size_t)(L % 64 == 0 ? 64 : 1);      // lcm(L, 64) for the chain lengths in use
     const size_t span = (32768 + unit - 1) / unit * unit;
     size_t lw = (n + (size_t)ex_walkers - 1) / (size_t)ex_walkers;
+    // (twice the walkers where their ranges still reach `span` without a warm-up -- 2^28 samples at the circuit rate: the walkers
+    // are throughput there, and four waves per SIMD issue better than two: 4.6 against 6.0 ms per C1 burst; at C2's 54 M
+    // samples the shorter ranges would have to be warmed up: 8.0 against 6.5 ms)
+    if (lw >= 2 * span) lw = (lw + 1) / 2;
     if (lw < 2048) lw = 2048;
     lw = (lw + unit - 1) / unit * unit;
     size_t h = lw >= span ? 0 : span - lw;
