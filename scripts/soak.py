@@ -12,7 +12,7 @@ def run(fs, D, log2, calls, prefetch):
     buf = torch.empty((nbuf, n, 2), dtype=torch.float32, device=dev)
     for b in range(nbuf):
         _capi.synth_generate_device(sp, b * n, n, buf[b].data_ptr(), device=0, stream=st.cuda_stream)
-    dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D))
+    dem = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, front_exact=int(os.environ.get("FRONT_EXACT", "0"))))
     cap = int(n / (D * dem.sps * 0.99)) + 64
     soft = torch.empty((cap,), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -31,6 +31,6 @@ def run(fs, D, log2, calls, prefetch):
     free2 = torch.cuda.mem_get_info(dev)[0]
     print("fs %.3g D %d 2^%d x %d: %.3f ms/call, symbols %d, worst passes costas %d relay %d, device memory after 20 calls / at the end: %d / %d MB used since start" % (
         fs, D, log2, calls, dt / calls * 1e3, tot, worst[0], worst[1], (free0 - free1) >> 20, (free0 - free2) >> 20), flush=True)
-run(6.25e6, 5, 28, 1500, True)
+run(6.25e6, 5, 28, int(os.environ.get("SOAK_BURSTS", "1500")), True)
 run(1.25e6, 1, 17, 4000, False)
 run(6.25e6, 5, 21, 3000, False)

@@ -320,9 +320,11 @@ int CostasStage::enqueue_exact(hipStream_t s, Profiler *prof)
     }
     if (W > 1) {
         ProfScope ps(prof, "costas_exact_fix", s);
-        // (rounds enqueued with the call: without a warm-up the first one does the settling, the second catches the joints
-        // whose predecessor's end state that changed; the host looks at what is left)
-        for (int r = 0; r < (H == 0 ? 3 : 2); ++r) hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 0);
+        // (rounds enqueued with the call: the first one does the settling, the next catch the joints whose predecessor's end state
+        // that changed; the host looks at what is left)
+        // (four: a round that finds nothing to do is a launch of waves that look at two words and leave, ~10 us; a joint the host has
+        // to close costs the burst its speculatively started clock-recovery walkers -- with two rounds one C2 burst in five)
+        for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 0);
         hipLaunchKernelGGL(xw::zero_kernel<CostasWalk>, dim3(1), dim3(64), 0, s, K.a.cnt, 1);
         hipLaunchKernelGGL(xw::fix_kernel<CostasWalk>, dim3(W - 1), dim3(64), 0, s, K, 1);
     }
