@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -85,7 +86,18 @@ struct Profiler {
     // An event record is a barrier in the queue: the bracketed kernel cannot overlap the tail of its
     // predecessor or the head of its successor (~10-20 us per boundary at C2).  The light mode therefore
     // brackets a single kernel per call: the decimating FIR, the one launch that moves the input bytes.
-    static bool in_light_list(const char *name) { return !strcmp(name, "fir_decim"); }
+    // (XRIT_LIGHT_LIST="name,name": other brackets for a light-mode measurement, read once)
+    static bool in_light_list(const char *name)
+    {
+        static const char *extra = getenv("XRIT_LIGHT_LIST");
+        if (extra) {
+            const size_t n = strlen(name);
+            for (const char *p = strstr(extra, name); p; p = strstr(p + 1, name))
+                if ((p == extra || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+            return false;
+        }
+        return !strcmp(name, "fir_decim");
+    }
     bool open = false;
     void begin(const char *name, hipStream_t s)
     {
