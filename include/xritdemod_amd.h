@@ -200,6 +200,30 @@ int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft_out, size_t cap, 
  * with the symbol history negated -- right to 1e-3 sample in timing, which takes 1e4..1e5 symbols to settle).
  * Refused like xrit_demod_redo_clock_flipped while a prefetched input waits. */
 int xrit_demod_prepare_flipped(xrit_demod *d, void *stream);
+/* Move the carried Costas phase by pi (a freshly reset chain: 0 -> pi).  The loop's equations do not see a half turn
+ * (the BPSK detector I*Q does not), so a chain started so pulls in along the same path into the other of its two locks:
+ * how a rank of xrit_group_* that found itself pi away from the stream starts again with the bit-exact front end, to
+ * meet the stream's own float32 trajectory instead of its negative-to-rounding.  (The reference starts at 0 and keeps
+ * whichever lock it falls into, demodulator.cpp:152.)  Refused while a prefetched input waits. */
+int xrit_demod_flip_costas_phase(xrit_demod *d, void *stream);
+/* The clock recovery's carried state as one device record of xrit_demod_clock_carry_bytes() bytes (the Mueller & Mueller
+ * loop's mu, omega, last symbols and decisions, and the <= 1024 de-rotated samples it has not consumed yet):
+ * which = 0: what the NEXT process call starts from, which = 1: what the LAST one started from.  The reference's loop
+ * objects carry ONE state across all chunks (demodulator.cpp:446-450, 136-157); across the GPUs of xrit_group_* this record
+ * is that state, handed from the rank in front to the rank behind. */
+size_t xrit_demod_clock_carry_bytes(void);
+int xrit_demod_export_clock_carry(xrit_demod *d, int which, void *d_record, void *stream);
+/* The clock recovery of the LAST process call once more from another handle's record (which = 0 of the handle that
+ * demodulated the samples in front): same input, that loop state in front of it; d_soft receives the call's symbols again.
+ * Refused (XRIT_E_INVALID, nothing changed) while a prefetched input waits, or for a record that is not one. */
+int xrit_demod_redo_clock_from(xrit_demod *d, const void *d_record, float *d_soft_out, size_t cap, size_t *n_out, void *stream);
+/* 1 if the last process call's symbols are those of ONE float32 walk from the state it started from (cfg.clock_serial,
+ * the exact closure cfg.clock_exact = 1, or a call short enough for a single exact walk -- up to 73 k symbols in the
+ * default configuration), 0 if they are relayed / overlapping walks (close to it, not it), < 0 on a null handle. */
+int xrit_demod_last_clock_exact(const xrit_demod *d);
+/* 1 if a process call of n_complex input samples on this handle takes the bit-exact front end (cfg.front_exact and the
+ * call's length decide, see xrit_demod_config), 0 if the fast one, < 0 on a null handle. */
+int xrit_demod_front_exact_for(const xrit_demod *d, size_t n_complex);
 /* Streaming at full rate: register the input of a LATER process call now, so that the library can run it ahead of
  * that call on streams of its own while the calls in between are at work:
  *     prefetch(b); prefetch(b+1);  prefetch(b+2); process_device(b);  prefetch(b+3); process_device(b+1);  ...
@@ -431,6 +455,10 @@ xrit_demod *xrit_group_chain(xrit_group *g);
 int    xrit_group_rank(const xrit_group *g);
 int    xrit_group_world(const xrit_group *g);
 size_t xrit_group_halo_samples(const xrit_group *g);
+/* What this rank did at its slice boundaries so far (see xrit_group_process_slice_device): slices started a second time
+ * from the other Costas lock; slices whose clock recovery ran again from the loop state of the rank in front; slices
+ * that had met that state bit for bit inside their halo (nothing to run again).  Any pointer may be null. */
+void xrit_group_counters(const xrit_group *g, uint64_t *relocks, uint64_t *handovers, uint64_t *joined);
 /* Ranks of the RCCL communicator the group exchanges over, as RCCL itself counts them (ncclCommCount); 0 when the
  * ranks are threads of one process (xrit_group_create_local: no communicator). */
 int    xrit_group_rccl_ranks(xrit_group *g);
@@ -439,9 +467,12 @@ int    xrit_group_rccl_ranks(xrit_group *g);
  * periods) and receives its symbols in the stream's
  * polarity with their offset in the burst's symbol sequence: rank r's symbols are
  * out[offset .. offset + n_out) of what one chain would emit for the whole burst
- * (to the clock recovery's floor: a rank whose Costas loop locked pi away from
- * rank 0's runs its clock recovery once more on the sign-flipped stream, so both
- * locks end at the same floor).  Consecutive calls are consecutive bursts of ONE
+ * (a rank whose Costas loop locked pi away from the stream's starts once more
+ * from a phase of pi where its front end is the bit-exact one -- it then meets the
+ * stream's own trajectory inside the halo, like a rank that fell on the right side
+ * at once: symbols that are the single chain's word for word wherever that chain's
+ * are the CPU chain's --, and with the fast front end runs its clock recovery once
+ * more on the sign-flipped stream, so both locks end at the same floor).  Consecutive calls are consecutive bursts of ONE
  * capture: the last rank keeps the end of its slice and hands it to rank 0 at the
  * start of the next call (the exchanges become a ring), so rank 0 warms up over a
  * halo like every other rank; xrit_group_restart() begins a new capture (as does

@@ -430,3 +430,52 @@ def test_front_exact_2_host_rounds_inside_the_streaming_pipeline(xa, oracle_mod,
     cg.Work(d.stage("rrc"))
     st = cg.exact_stats()
     assert st["host_rounds"] > 0, st
+
+
+def test_clock_state_handed_from_one_handle_to_another(xa, oracle_mod):
+    """The reference's clock recovery is ONE object that carries its state across every chunk (demodulator.cpp:446-450, :156).
+    Across handles -- the GPUs of xrit_group_* -- that state is a device record (xrit_demod_export_clock_carry): handle B, warmed up
+    from a cold start over the samples in front of a chunk, walks the chunk's clock recovery again from the record handle A left
+    where the chunk begins (xrit_demod_redo_clock_from) and emits A's symbols, which are the CPU chain's, word for word -- whether
+    or not its own warm-up had met A's trajectory.  A record that is not one is refused and changes nothing."""
+    import torch
+    fs, D = 6.25e6, 5
+    n1, n2, halo = 1500000, 1000000, 1100000
+    x = synth_signal(n1 + n2, fs_in=fs)
+    want = oracle_mod.Demod(oracle_mod.config("lrit", fs, D)).process(x)
+    A = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, front_exact=2))
+    a1 = A.process(x[:n1])
+    nbytes = xa.lib().xrit_demod_clock_carry_bytes()
+    assert nbytes == 64 + 8192
+    rec = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    junk = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    A.export_clock_carry(rec.data_ptr(), 0)
+    torch.cuda.synchronize()
+    head = rec[:8].cpu().numpy().view(np.uint32)
+    assert head[0] == 1 and head[1] <= 1024
+    a2 = A.process(x[n1:])
+    assert np.array_equal(np.concatenate([a1, a2]).view(np.uint32), want.view(np.uint32))
+    cap = n2 // D + 1024
+    soft = torch.empty(cap, dtype=torch.float32, device="cuda:0")
+    for other_lock in (False, True):
+        B = xa.Demodulator(xa.Demodulator.config("lrit", fs, D, front_exact=2))
+        if other_lock:
+            B.flip_costas_phase()
+        B.process(x[n1 - halo:n1])
+        b2 = B.process(x[n1:])
+        if np.dot(b2[:20000], a2[:20000]) > 0:
+            break
+    else:
+        pytest.fail("neither start phase of the Costas loop fell into the stream's lock")
+    assert B.last_clock_exact() and len(b2) == len(a2)
+    with pytest.raises(xa.XritError):
+        B.redo_clock_from(junk.data_ptr(), soft.data_ptr(), cap)
+    k = B.redo_clock_from(rec.data_ptr(), soft.data_ptr(), cap)
+    torch.cuda.synchronize()
+    b3 = soft[:k].cpu().numpy()
+    assert k == len(a2) and np.array_equal(b3.view(np.uint32), a2.view(np.uint32)), (k, len(a2), rms(b3 - a2), rms(b2 - a2))
+    # the record of where the last call STARTED is what was handed in
+    mine = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    B.export_clock_carry(mine.data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(mine, rec)

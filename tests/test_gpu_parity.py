@@ -1726,11 +1726,13 @@ def test_contiguous_split_on_device(xa, same_lock):
 def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     """xrit_group_* (C++) with the in-process fabric: two ranks as two threads on this GPU cut one
     burst in two slices -- halo, boundary symbols, (polarity, count) all-gather, all behind the C ABI.  The joined
-    output is the uninterrupted chain's: same symbol count, same hard decisions, rank 0's part to the chaos floor,
-    rank 1's (cold start over the halo; pi away from the stream it is a different, equally valid lock) to 3e-3."""
+    output is the uninterrupted chain's: same symbol count, same hard decisions, rank 0's part word for word (the bit-exact
+    front end and one exact walk at this size), and rank 1's too: cold start over a halo of 49 152 symbols, a second start
+    from the other Costas lock if it fell pi away from the stream, the clock recovery from the loop state rank 0 ended in
+    (rounds 2 - 5: 3e-3, 2.5e-4, 1.5e-4 rms)."""
     import threading
     import torch
-    n, D = 1200000, 5
+    n, D = 1300000, 5
     x = synth_signal(2 * n, fs_in=6.25e6)
     want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, D)).process(x)
     fabric = xa.LocalFabric(2)
@@ -1741,7 +1743,7 @@ def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     def rank_main(r):
         try:
             g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), r, fabric=fabric)
-            assert g.world == 2 and g.rank == r and g.halo_samples % D == 0 and 400000 < g.halo_samples < n
+            assert g.world == 2 and g.rank == r and g.halo_samples % D == 0 and 1000000 < g.halo_samples < n
             cap = n // D + 1024
             soft = torch.empty(cap, dtype=torch.float32, device=dev)
             sl = xt[r * n:(r + 1) * n].contiguous()
@@ -1764,27 +1766,35 @@ def test_group_api_two_ranks_on_one_device(xa, oracle_mod):
     assert len(got) == len(want)
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    # (round 6: rank 0 is the stream's own chain on a slice of 42 k symbols -- the bit-exact front end by default at this size, one
+    # (round 6: rank 0 is the stream's own chain on a slice of 61 k symbols -- the bit-exact front end by default at this size, one
     # exact walk behind it: the oracle's words)
     assert np.array_equal(s0.view(np.uint32), want[:len(s0)].view(np.uint32)), rms(s0 - want[:len(s0)])
-    # round 3: a rank whose Costas loop locked pi away from the stream runs its clock recovery once more on the
-    # sign-flipped Costas output (xrit_demod_redo_clock_flipped) -- both polarities end at the same floor
-    # (round 2: 3e-3 for the flipped one, the M&M detector slices to {0, 1})
-    # (rank 1 cold-starts its loops over the halo: its clock recovery has not met the stream's after 24 576 symbols -- measured
-    # 1.6e-5 .. 1.3e-4 over the four start phases of the next test, scripts/r6_group_parity.py)
-    assert rms(s1 - want[len(s0):]) < 1.5e-4, (pol1, rms(s1 - want[len(s0):]))
+    # rank 1: the AGC and the Costas loop have met the stream's own float32 trajectories inside the halo, whichever lock the cold
+    # start fell into -- pi away (pol1 = -1) it starts once more from a phase of pi (xrit_demod_flip_costas_phase; rounds 3 - 5:
+    # the clock recovery once more on the negated Costas output, which is still what the fast front end does) --, and the clock
+    # recovery starts from the loop state rank 0 ended in (xrit_demod_export_clock_carry / xrit_demod_redo_clock_from) unless
+    # its own warm-up had reached that very state: the CPU chain's words
+    assert np.array_equal(s1.view(np.uint32), want[len(s0):].view(np.uint32)), (pol1, rms(s1 - want[len(s0):]))
 
 
-def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
+@pytest.mark.parametrize("front_exact", [0, -1])
+def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod, front_exact):
     """Both locks of rank 1 are exercised: the start phase of the capture is moved by a quarter turn at a time, so that
     rank 1 (cold start over its halo) falls on either side of the stream rank 0 follows; the joined output must be the
-    uninterrupted chain's with identical decisions in every case -- rank 0 word for word, rank 1 to 1.5e-4 rms."""
+    uninterrupted chain's with identical decisions in every case -- both ranks word for word, in EITHER lock
+    (a rank that fell pi away starts once more from the other lock and meets the stream's trajectory like one that did not;
+    rounds 3 - 5 ran its clock recovery again on the negated Costas output: 0.5 .. 1.8e-4).  With the fast front end
+    (front_exact = -1: what slices of a million symbols and more take by default) no trajectory can be met word for word; a
+    flipped rank's clock recovery runs again on the negated Costas output as before: within 1e-4 (measured 1.8 .. 2.9e-5), a
+    flipped rank within 2e-4 (1.1 .. 1.5e-4: the clock recovery's floor with its episodes, on a slice of only 61 k symbols; at
+    the slice lengths this front end is the default for, flipped and unflipped ranks and the single chain itself sit at the same
+    0.6 .. 1.2e-4 per million symbols, profiles/r6_group_windows.txt)."""
     import threading
     import torch
-    n, D = 900000, 5
+    n, D = 1300000, 5
     dev = torch.device("cuda", 0)
     seen = set()
-    for ph in (0.7, 2.3, 3.9, 5.4):
+    for ph in (0.7, 1.5, 3.9, 4.7):
         x = synth.generate(synth.SynthParams(fs_in=6.25e6, phase0=ph, seed=4242), 2 * n)
         want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, D)).process(x)
         fabric = xa.LocalFabric(2)
@@ -1793,12 +1803,12 @@ def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
 
         def rank_main(r):
             try:
-                g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D), r, fabric=fabric)
+                g = xa.Group(xa.Demodulator.config("lrit", 6.25e6, D, front_exact=front_exact), r, fabric=fabric)
                 cap = n // D + 1024
                 soft = torch.empty(cap, dtype=torch.float32, device=dev)
                 sl = xt[r * n:(r + 1) * n].contiguous()
                 k, off, pol = g.process_slice_device(sl.data_ptr(), n, soft.data_ptr(), cap)
-                res[r] = (soft[:k].cpu().numpy(), off, pol)
+                res[r] = (soft[:k].cpu().numpy(), off, pol, g.counters())
             except Exception as e:          # noqa: BLE001
                 err.append(e)
 
@@ -1808,19 +1818,25 @@ def test_group_polarity_is_settled_before_the_clock_recovery(xa, oracle_mod):
         for t in th:
             t.join(timeout=120)
         assert not err, err
-        (s0, off0, pol0), (s1, off1, pol1) = res
+        (s0, off0, pol0, cnt0), (s1, off1, pol1, cnt1) = res
         seen.add(pol1)
+        # (pol1: the lock of rank 1's FIRST start; counters: second starts, clock hand-overs, slices that had met the state)
+        assert cnt0 == (0, 0, 0) and cnt1[0] == (1 if pol1 < 0 and front_exact == 0 else 0), (ph, pol1, cnt0, cnt1)
+        assert cnt1[1] + cnt1[2] == (1 if front_exact == 0 else 0), (ph, cnt1)
         got = np.concatenate([s0, s1])
         assert len(got) == len(want) and off1 == len(s0)
         # (the oracle's own lock may be the other one: compare up to the capture's global sign)
         sgn = 1.0 if np.dot(got[:50000], want[:50000]) > 0 else -1.0
         big = np.abs(want) > 1e-3
         assert np.array_equal(np.sign(sgn * got[big]), np.sign(want[big])), ph
-        if sgn > 0:
-            # (round 6: rank 0 -- the stream's own chain, the bit-exact front end at this size -- is the oracle's words; rank 1,
-            # cold-started over its halo, 1.6e-5 .. 1.3e-4 whichever lock it fell on: scripts/r6_group_parity.py)
-            assert np.array_equal(s0.view(np.uint32), want[:len(s0)].view(np.uint32)), ph
-            assert rms(s1 - want[len(s0):]) < 1.5e-4, (ph, pol1, rms(s1 - want[len(s0):]))
+        if sgn > 0 and front_exact < 0:
+            e0, e1 = rms(s0 - want[:len(s0)]), rms(s1 - want[len(s0):])
+            print(f"fast front end, phase0 {ph}: rank 0 {e0:.2e}, rank 1 {e1:.2e} (first lock {pol1:+d})")
+            assert e0 < 1e-4 and e1 < (2e-4 if pol1 < 0 else 1e-4), (ph, pol1, e0, e1)
+        elif sgn > 0:
+            # (round 6: rank 0 -- the stream's own chain, the bit-exact front end at this size -- is the oracle's words, and so is
+            # rank 1, whichever lock its cold start fell into: profiles/r6_group_windows.txt)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (ph, pol1, rms(s0 - want[:len(s0)]), rms(s1 - want[len(s0):]))
     assert seen == {1, -1}, seen
 
 
@@ -1828,10 +1844,12 @@ def test_group_streams_a_capture_call_after_call(xa, oracle_mod):
     """Consecutive slice calls are consecutive bursts of one capture: in every call after the first the last rank hands
     the end of its previous slice (halo samples, boundary symbols in the stream's polarity) to rank 0 -- the exchanges
     become a ring -- so rank 0 warms up over a halo like every other rank.  Three calls of two ranks = six slices; the
-    symbols joined in (call, rank) order are the uninterrupted chain's: same count, same decisions, 2.5e-4 rms."""
+    symbols joined in (call, rank) order are the uninterrupted CPU chain's word for word (rounds 2 - 5: to 2.5e-4 rms): every
+    slice meets the stream's AGC and Costas trajectories inside its halo and takes the clock recovery's state from the slice in
+    front -- the last rank's from the call before, in rank 0's case."""
     import threading
     import torch
-    n, D, calls = 700000, 5, 3
+    n, D, calls = 1300000, 5, 3
     x = synth_signal(2 * calls * n, fs_in=6.25e6)
     want = oracle_mod.Demod(oracle_mod.config("lrit", 6.25e6, D)).process(x)
     fabric = xa.LocalFabric(2)
@@ -1863,14 +1881,14 @@ def test_group_streams_a_capture_call_after_call(xa, oracle_mod):
     assert len(got) == len(want), (len(got), len(want))
     big = np.abs(want) > 1e-3
     assert np.array_equal(np.sign(got[big]), np.sign(want[big]))
-    assert rms(got - want) < 2.5e-4, rms(got - want)
     # every (call, rank) piece on its own as well
-    pos = 0
+    pos, each = 0, []
     for c in range(calls):
         for r in range(2):
             k = len(parts[(c, r)][0])
-            assert rms(parts[(c, r)][0] - want[pos:pos + k]) < 2.5e-4, (c, r, parts[(c, r)][2])
+            each.append(rms(parts[(c, r)][0] - want[pos:pos + k]))
             pos += k
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (each, rms(got - want), [parts[(c, r)][2] for c in range(calls) for r in range(2)])
 
 
 def test_group_failure_of_one_rank_reaches_every_rank(xa):
@@ -1879,7 +1897,7 @@ def test_group_failure_of_one_rank_reaches_every_rank(xa):
     error from the call."""
     import threading
     import torch
-    n, D = 900000, 5
+    n, D = 1300000, 5
     x = synth_signal(2 * n, fs_in=6.25e6)
     dev = torch.device("cuda", 0)
     xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)

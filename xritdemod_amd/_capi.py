@@ -74,6 +74,12 @@ _SIGNATURES = {
     "xrit_demod_profile_read": (C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "xrit_group_restart": (C.c_int, [_vp]),
     "xrit_demod_prepare_flipped": (C.c_int, [_vp, _vp]),
+    "xrit_demod_flip_costas_phase": (C.c_int, [_vp, _vp]),
+    "xrit_demod_front_exact_for": (C.c_int, [_vp, _sz]),
+    "xrit_demod_clock_carry_bytes": (_sz, []),
+    "xrit_demod_export_clock_carry": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "xrit_demod_redo_clock_from": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "xrit_demod_last_clock_exact": (C.c_int, [_vp]),
     "xrit_demod_prefetch_depth": (C.c_int, [_vp, _sz]),
     "xrit_demod_redo_clock_flipped": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "xrit_demod_profile_samples": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
@@ -117,6 +123,7 @@ _SIGNATURES = {
     "xrit_group_rank": (C.c_int, [_vp]),
     "xrit_group_world": (C.c_int, [_vp]),
     "xrit_group_halo_samples": (_sz, [_vp]),
+    "xrit_group_counters": (None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xrit_group_rccl_ranks": (C.c_int, [_vp]),
     "xrit_group_process_slice_device": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64),
                                                   C.POINTER(C.c_int), _vp]),
@@ -403,6 +410,30 @@ class Demodulator(_Handle):
     def prepare_flipped(self, stream=None):
         _check(lib().xrit_demod_prepare_flipped(self._h, C.c_void_p(stream) if stream else None))
 
+    def flip_costas_phase(self, stream=None):
+        """Move the carried Costas phase by pi (a freshly reset chain then pulls into its other lock)."""
+        _check(lib().xrit_demod_flip_costas_phase(self._h, C.c_void_p(stream) if stream else None))
+
+    def export_clock_carry(self, d_record_ptr, which=0, stream=None):
+        """The clock recovery's carried state into a device record of clock_carry_bytes() bytes."""
+        _check(lib().xrit_demod_export_clock_carry(self._h, int(which), C.c_void_p(d_record_ptr), C.c_void_p(stream) if stream else None))
+
+    def redo_clock_from(self, d_record_ptr, d_soft_ptr, cap, stream=None):
+        """The last call's clock recovery once more from another handle's carried state; returns the symbol count."""
+        n_out = _sz(0)
+        _check(lib().xrit_demod_redo_clock_from(self._h, C.c_void_p(d_record_ptr), C.c_void_p(d_soft_ptr), cap, C.byref(n_out),
+                                                C.c_void_p(stream) if stream else None))
+        return n_out.value
+
+    def last_clock_exact(self):
+        return lib().xrit_demod_last_clock_exact(self._h) == 1
+
+    def front_exact_for(self, n):
+        """True if a call of n input samples takes the bit-exact front end on this handle."""
+        r = lib().xrit_demod_front_exact_for(self._h, int(n))
+        _check(r if r < 0 else 0)
+        return r == 1
+
     def keep_stages(self, enable=True):
         _check(lib().xrit_demod_keep_stages(self._h, int(enable)))
 
@@ -521,6 +552,17 @@ class Group(_Handle):
     @property
     def halo_samples(self):
         return lib().xrit_group_halo_samples(self._h)
+
+    def counters(self):
+        """(relocks, handovers, joined): slices started a second time from the other Costas lock, slices whose clock recovery
+        ran again from the loop state of the rank in front, slices that had met that state inside their halo."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        lib().xrit_group_counters(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
+    @property
+    def relocks(self):
+        return self.counters()[0]
 
     @property
     def rccl_ranks(self):

@@ -2470,6 +2470,67 @@ int ClockStage::redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_
     return rc;
 }
 
+__global__ void __launch_bounds__(1024) clock_carry_pack_kernel(unsigned char *__restrict__ rec, const ClockState *__restrict__ st,
+                                                                const float2 *__restrict__ tail, int carry)
+{
+    if (threadIdx.x == 0) {
+        unsigned *h = reinterpret_cast<unsigned *>(rec);
+        h[0] = 1u; h[1] = (unsigned)carry; h[2] = 0u; h[3] = 0u;
+        *reinterpret_cast<ClockState *>(rec + 16) = *st;
+    }
+    float2 *t = reinterpret_cast<float2 *>(rec + ClockStage::CARRY_HEAD);
+    t[threadIdx.x] = (int)threadIdx.x < carry ? tail[threadIdx.x] : make_float2(0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(1024) clock_carry_unpack_kernel(const unsigned char *__restrict__ rec, ClockState *__restrict__ st,
+                                                                  float2 *__restrict__ tail, int carry)
+{
+    if (threadIdx.x == 0) *st = *reinterpret_cast<const ClockState *>(rec + 16);
+    const float2 *t = reinterpret_cast<const float2 *>(rec + ClockStage::CARRY_HEAD);
+    if ((int)threadIdx.x < carry) tail[threadIdx.x] = t[threadIdx.x];
+}
+
+static_assert(16 + sizeof(ClockState) <= ClockStage::CARRY_HEAD, "the carried record's head holds a ClockState");
+
+int ClockStage::export_carry(void *d_rec, int which, hipStream_t s)
+{
+    if (in_flight) { set_error("clock recovery: a call is in flight"); return XRIT_E_INVALID; }
+    if (which != 0 && !redo_ok) { set_error("clock recovery: no finished call whose start state is still held"); return XRIT_E_INVALID; }
+    const int slot = which == 0 ? cur : cur ^ 1;
+    const size_t c = which == 0 ? carry : prev_carry;
+    hipLaunchKernelGGL(clock_carry_pack_kernel, dim3(1), dim3(1024), 0, s, static_cast<unsigned char *>(d_rec), st.as<ClockState>() + slot,
+                       tail.as<float2>() + 1024 * slot, (int)c);
+    XR_HIP(hipGetLastError());
+    return XRIT_OK;
+}
+
+bool ClockStage::last_walk_exact() const
+{
+    if (!redo_ok || ov_cur >= 0 || job.short_input) return false;
+    return serial || (job.relay && (relay_closed || job.G == 1));
+}
+
+int ClockStage::redo_from(const void *d_rec, size_t carry_rec, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof)
+{
+    *n_out = 0;
+    if (!redo_ok) { set_error("clock recovery: no finished call to run again"); return XRIT_E_INVALID; }
+    if (carry_rec > 1024) { set_error("clock recovery: a carried record with %zu unread samples", carry_rec); return XRIT_E_INVALID; }
+    // finish() moved on to the other state / tail slot: back to the one the call started from, which takes the record
+    cur ^= 1;
+    float2 *data = xdata();     // where the call's input lies
+    const size_t n = prev_n;
+    hipLaunchKernelGGL(clock_carry_unpack_kernel, dim3(1), dim3(1024), 0, s, static_cast<const unsigned char *>(d_rec), st.as<ClockState>() + cur,
+                       tail.as<float2>() + 1024 * cur, (int)carry_rec);
+    XR_HIP(hipGetLastError());
+    carry = carry_rec;
+    alt_valid = false;
+    hist_xb = -1; hist_len = 0; hist_job = -1;      // (what lies in front of the input now is another handle's tail: no history for walkers)
+    xbase_fixed = data - carry;             // (carry <= 1024 <= xpad: never in front of the buffer)
+    const int rc = run(n, soft_out, sym_out, cap, n_out, s, prof);
+    xbase_fixed = nullptr;
+    return rc;
+}
+
 int ClockStage::make_alt(hipStream_t s, Profiler *prof)
 {
     alt_valid = false;

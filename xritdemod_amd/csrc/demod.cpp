@@ -472,6 +472,12 @@ static bool front_exact_call(const xrit_demod *d, size_t n)
     return length / (double)d->sps < (double)d->clock.ov_min;
 }
 
+int xrit_demod_front_exact_for(const xrit_demod *d, size_t n)
+{
+    if (!d) return XRIT_E_INVALID;
+    return front_exact_call(d, n) ? 1 : 0;
+}
+
 static int front_end(xrit_demod *d, const void *in, size_t n, int type, int set, hipStream_t s, Profiler *prof, SliceIO *io)
 {
     io->set = set;
@@ -977,6 +983,58 @@ int xrit_demod_prepare_flipped(xrit_demod *d, void *stream)
     int rc = d->clock.make_alt(s, d->prof.enabled ? &d->prof : nullptr);
     if (rc != XRIT_OK) d->poisoned = true;
     return rc;
+}
+
+size_t xrit_demod_clock_carry_bytes(void) { return ClockStage::CARRY_BYTES; }
+
+int xrit_demod_export_clock_carry(xrit_demod *d, int which, void *d_rec, void *stream)
+{
+    if (!d || !d_rec || which < 0 || which > 1) { set_error("null or invalid argument"); return XRIT_E_INVALID; }
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    if (d->pf_count > 0) { set_error("a prefetched input waits for its process call: the carried state is not between two calls"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    return d->clock.export_carry(d_rec, which, stream ? (hipStream_t)stream : d->stream);
+}
+
+int xrit_demod_last_clock_exact(const xrit_demod *d)
+{
+    if (!d) return XRIT_E_INVALID;
+    return d->clock.last_walk_exact() ? 1 : 0;
+}
+
+int xrit_demod_redo_clock_from(xrit_demod *d, const void *d_rec, float *d_soft, size_t cap, size_t *n_out, void *stream)
+{
+    if (!d || !d_rec || !n_out || !d_soft) { set_error("null argument"); return XRIT_E_INVALID; }
+    *n_out = 0;
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    if (d->pf_count > 0) { set_error("a prefetched input waits for its process call: the re-run belongs between plain calls"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    hipStream_t s = stream ? (hipStream_t)stream : d->stream;
+    unsigned head[4] = {0, 0, 0, 0};
+    XR_HIP(hipMemcpyAsync(head, d_rec, sizeof head, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    if (head[0] != 1u || head[1] > 1024u) { set_error("not a carried clock state (xrit_demod_export_clock_carry)"); return XRIT_E_INVALID; }
+    Profiler *prof = d->prof.enabled ? &d->prof : nullptr;
+    float2 *sym = (d->keep_stages || d->keep_symbols) ? d->stage_buf[4].as<float2>() : nullptr;
+    size_t k = 0;
+    const int rc = d->clock.redo_from(d_rec, head[1], d_soft, sym, cap, &k, s, prof);
+    if (rc != XRIT_OK) { d->poisoned = true; return rc; }
+    d->stage_n[4] = k;
+    d->stats.symbols_out = k;
+    d->stats.clock_passes = d->clock.passes;
+    d->stats.clock_relay_passes = d->clock.relay_passes;
+    d->stats.clock_relay_closed = d->clock.relay_closed ? 1 : 0;
+    *n_out = k;
+    return XRIT_OK;
+}
+
+int xrit_demod_flip_costas_phase(xrit_demod *d, void *stream)
+{
+    if (!d) { set_error("null argument"); return XRIT_E_INVALID; }
+    if (d->poisoned) { set_error("this handle's carried state is inconsistent after an earlier failed call"); return XRIT_E_INVALID; }
+    if (d->pf_count > 0) { set_error("a prefetched input waits for its process call: its Costas loop may already have started"); return XRIT_E_INVALID; }
+    XR_HIP(hipSetDevice(d->device));
+    return d->costas.flip_phase(stream ? (hipStream_t)stream : d->stream);
 }
 
 int xrit_demod_redo_clock_flipped(xrit_demod *d, float *d_soft, size_t cap, size_t *n_out, void *stream)

@@ -4,7 +4,9 @@
 // time slices, one per GPU.  What crosses GPUs (point to point over xGMI, RCCL ncclSend / ncclRecv, plus ONE
 // all-gather of two integers per rank):
 //   1. the halo: the last H input samples of rank g-1 go to rank g, which demodulates them first, from a cold
-//      start, so that its filter histories are primed and its loops locked when its slice begins;
+//      start, so that its filter histories are primed and its loops locked when its slice begins -- with the bit-exact
+//      front end, ON the stream's own float32 trajectories (a rank that fell into the other Costas lock starts again
+//      from a phase of pi, step 3b);
 //   2. the last TAIL soft symbols of rank g-1, against which rank g settles the Costas pi ambiguity (sign of the
 //      correlation) and the symbol that straddles the slice boundary (lag of the correlation peak);
 //   3. (relative polarity, symbol count) of every rank: prefix product / prefix sum = absolute polarity and
@@ -275,7 +277,12 @@ struct xrit_group {
     // the exchanges become a ring -- so that rank 0 warms up over a halo like every other rank instead of starting cold
     // in the middle of the stream.
     unsigned long long calls = 0;       // slice calls of this capture that succeeded
-    DevBuf keep_halo, keep_tail;
+    DevBuf keep_halo, keep_tail, keep_carry;
+    DevBuf carry_out, carry_in, carry_mine;     // the clock recovery's carried state: mine at the end of the slice, the previous rank's, mine at its start
+    std::vector<unsigned char> h_carry_in, h_carry_mine;
+    unsigned long long relocks = 0;      // slices started a second time, from the other Costas lock
+    unsigned long long handovers = 0;    // slices whose clock recovery ran again from the previous rank's loop state
+    unsigned long long joined = 0;       // slices that had met the previous rank's loop state bit for bit inside their halo
 };
 
 namespace {
@@ -322,7 +329,12 @@ int group_finish_create(xrit_group *g, const xrit_demod_config *cfg)
     XR_TRY(xrit_demod_create(&c, &g->chain));
     g->device = c.device;
     g->decimation = c.decimation;
-    g->halo = g->world > 1 ? group_halo_samples(c, xrit_demod_sps(g->chain), xrit_demod_decimator_ntaps(g->chain), 24576) : 0;
+    // warm-up in front of a slice: what the walkers of overlapping blocks inside a GPU take (clock_overlap.h), 49 152 symbols --
+    // with 24 576 (rounds 2 - 5) the clock recovery was still 2e-4 from the stream's over a slice's first 10 - 20 k symbols,
+    // with 49 152 it has met it (bit for bit behind the bit-exact front end: profiles/r6_group_windows.txt)
+    int warm = 49152;
+    if (const char *e = getenv("XRIT_GROUP_WARM")) { const int v = atoi(e); if (v >= 1024) warm = v; }    // (measurement switch, scripts/r6_group_windows.py)
+    g->halo = g->world > 1 ? group_halo_samples(c, xrit_demod_sps(g->chain), xrit_demod_decimator_ntaps(g->chain), warm) : 0;
     return XRIT_OK;
 }
 
@@ -443,7 +455,7 @@ void xrit_group_destroy(xrit_group *g)
     (void)hipSetDevice(g->device);
     delete g->tr;
     if (g->chain) xrit_demod_destroy(g->chain);
-    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release(); g->zeros.release(); g->pre_dev.release(); g->keep_halo.release(); g->keep_tail.release();
+    g->halo_in.release(); g->halo_syms.release(); g->soft_int.release(); g->tail_out.release(); g->tail_in.release(); g->host_in.release(); g->host_out.release(); g->zeros.release(); g->pre_dev.release(); g->keep_halo.release(); g->keep_tail.release(); g->keep_carry.release(); g->carry_out.release(); g->carry_in.release(); g->carry_mine.release();
     delete g;
 }
 
@@ -451,6 +463,12 @@ xrit_demod *xrit_group_chain(xrit_group *g) { return g ? g->chain : nullptr; }
 int xrit_group_rank(const xrit_group *g) { return g ? g->rank : -1; }
 int xrit_group_world(const xrit_group *g) { return g ? g->world : 0; }
 size_t xrit_group_halo_samples(const xrit_group *g) { return g ? g->halo : 0; }
+void xrit_group_counters(const xrit_group *g, uint64_t *relocks, uint64_t *handovers, uint64_t *joined)
+{
+    if (relocks) *relocks = g ? g->relocks : 0;
+    if (handovers) *handovers = g ? g->handovers : 0;
+    if (joined) *joined = g ? g->joined : 0;
+}
 int xrit_group_rccl_ranks(xrit_group *g) { return g && g->tr ? g->tr->comm_ranks() : 0; }
 
 int xrit_group_restart(xrit_group *g)
@@ -524,7 +542,7 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     // 1b. the halo through the chain (cold start); its last symbols are looked at on the host
     const size_t keep = GROUP_TAIL + GROUP_KEEP;
     g->h_halo_syms.clear();
-    if (has_prev && rc == XRIT_OK) {
+    auto run_halo = [&]() {
         const size_t hcap = H + 64;
         GR_STEP(g->halo_syms.reserve(hcap * sizeof(float)));
         size_t hk = 0;
@@ -533,7 +551,8 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
         const size_t take = hk < keep ? hk : keep;
         if (rc == XRIT_OK) g->h_halo_syms.resize(take);
         if (take) GR_HIP(hipMemcpyAsync(g->h_halo_syms.data(), g->halo_syms.as<float>() + (hk - take), take * sizeof(float), hipMemcpyDeviceToHost, s));
-    }
+    };
+    if (has_prev && rc == XRIT_OK) run_halo();
     // 2. the slice
     const size_t icap = cap + 64;
     GR_STEP(g->soft_int.reserve(icap * sizeof(float)));
@@ -593,17 +612,106 @@ int xrit_group_process_slice_device(xrit_group *g, const void *d_samples, size_t
     }
     int pol = 1;
     for (int r = 0; r <= rank; ++r) pol *= (int)all[(size_t)2 * r];      // (rank 0: +1 on a capture's first call)
-    // 3b. a rank that locked pi away from the stream: the Mueller & Mueller detector slices to {0, 1}, so the loop on
-    // -y is another loop than minus the loop on y (3e-3 rms in the symbols).  Its clock recovery runs once more, on
-    // the sign-flipped Costas output, from the state it had at the start of the slice: the symbols then come out in
-    // the stream's polarity, to the same floor as any other rank's.
-    if (pol < 0) {
+    // 3b. a rank that locked pi away from the stream.
+    // With the bit-exact front end (cfg.front_exact: every call of parity mode, calls below a million symbols by default) the
+    // rank starts once more, from a Costas phase of pi instead of 0: the loop's equations do not see a half turn, so it pulls
+    // in along the same path into the OTHER lock, the stream's; there its float32 trajectory meets the stream's own bit for
+    // bit within the halo, as a rank that fell on the right side at once does (merge lengths: DESIGN.md section 4b), and the
+    // clock recovery behind it starts on the stream's own words.  (profiles/r6_group_windows.txt: flipped ranks, whose Costas
+    // output is the stream's to rounding only, sat at the clock recovery's floor -- 0.6 .. 1.8e-4 over 141 k symbols -- next
+    // to 0.8 .. 3e-5 for unflipped ones.)
+    bool relocked = false;
+    if (pol < 0 && has_prev && rc == XRIT_OK && xrit_demod_front_exact_for(g->chain, n) == 1 && xrit_demod_front_exact_for(g->chain, H) == 1) {
+        GR_STEP(xrit_demod_reset(g->chain, s));
+        GR_STEP(xrit_demod_flip_costas_phase(g->chain, s));
+        run_halo();
+        k = 0;
+        GR_STEP(xrit_demod_process_device(g->chain, d_samples, n, type, g->soft_int.as<float>(), cap, &k, s));
+        fetch_head();
+        int p2 = 1, lag2 = 0;
+        if (rc == XRIT_OK) group_align(g->h_prev_tail, g->h_halo_syms, g->h_head, &p2, &lag2);
+        // (p2 is this run against rank - 1's boundary symbols, which are in rank - 1's FIRST polarity: the stream's lock is
+        // the one that changed sign against them)
+        if (rc == XRIT_OK && p2 == -pol_rel) { relocked = true; lag = lag2; }
+        g->relocks += 1;
+    }
+    // Otherwise (the fast front end, or a second start that fell on the same side): the Mueller & Mueller detector slices to
+    // {0, 1}, so the loop on -y is another loop than minus the loop on y (3e-3 rms in the symbols).  Its clock recovery runs
+    // once more, on the sign-flipped Costas output, from the state it had at the start of the slice: the symbols then come
+    // out in the stream's polarity, to the same floor as any other rank's.
+    if (pol < 0 && !relocked) {
         GR_STEP(xrit_demod_redo_clock_flipped(g->chain, g->soft_int.as<float>(), cap, &k, s));
         for (auto &v : g->h_halo_syms) v = -v;
         fetch_head();
         int p2 = 1;
         if (rc == XRIT_OK) group_align(g->h_prev_tail, g->h_halo_syms, g->h_head, &p2, &lag);
     }
+    // 3c. ONE loop state across the slices.  The reference's clock recovery is one object that carries its state across every
+    // chunk (demodulator.cpp:446-450, :156): here the state at the end of a slice -- mu, omega, the last symbols and decisions,
+    // the samples not consumed yet, one record of 8 KB -- travels from every rank to the rank behind it (the last rank keeps its
+    // own for rank 0's next call).  A rank compares it with the state its own warm-up over the halo reached at the slice's
+    // start: bit for bit the same (the float32 loops do meet: `joined`) and its symbols continue the stream's as they are;
+    // otherwise, where the slice's recovery was ONE exact walk behind the bit-exact front end, it is walked again from the
+    // handed-over state (`handovers`) -- the symbols are then the single chain's, word for word where that chain's are the CPU
+    // chain's -- and the record it hands on is the corrected one, so such ranks receive first and send afterwards.  Slices long
+    // enough for overlapping walkers do not walk again: a rank boundary is to them what the 256 joints inside every GPU are
+    // (DESIGN.md section 10); they send and receive at once.
+    bool seamless = false;
+    if (world > 1) {
+        const size_t RB = xrit_demod_clock_carry_bytes();
+        if (g->carry_out.reserve(RB) != XRIT_OK || g->carry_in.reserve(RB) != XRIT_OK || g->carry_mine.reserve(RB) != XRIT_OK ||
+            g->keep_carry.reserve(RB) != XRIT_OK) {
+            g->tr->abort(); set_error("group: out of device memory inside a collective call"); return XRIT_E_NOMEM;
+        }
+        auto pack_end = [&](void *dst) {        // what the next slice starts from (a rank that failed: no record)
+            if (rc != XRIT_OK || xrit_demod_export_clock_carry(g->chain, 0, dst, s) != XRIT_OK) (void)hipMemsetAsync(dst, 0, RB, s);
+        };
+        const bool onward = rank + 1 < world;
+        const bool exact_here = rc == XRIT_OK && has_prev && xrit_demod_front_exact_for(g->chain, n) == 1 &&
+                                xrit_demod_front_exact_for(g->chain, H) == 1 && xrit_demod_last_clock_exact(g->chain) == 1;
+        if (wrap_send) {
+            int xr = g->tr->exchange(g->keep_carry.p, RB, to, nullptr, 0, -1, s);
+            if (xr != XRIT_OK) fail(xr);
+        }
+        bool sent = false;
+        if (has_prev) {
+            int xr;
+            if (!exact_here && onward) {
+                pack_end(g->carry_out.p);
+                xr = g->tr->exchange(g->carry_out.p, RB, to, g->carry_in.p, RB, from, s);
+                sent = true;
+            } else {
+                xr = g->tr->exchange(nullptr, 0, -1, g->carry_in.p, RB, from, s);
+            }
+            if (xr != XRIT_OK) fail(xr);
+        }
+        if (has_prev && rc == XRIT_OK && xrit_demod_export_clock_carry(g->chain, 1, g->carry_mine.p, s) == XRIT_OK) {
+            g->h_carry_in.resize(RB); g->h_carry_mine.resize(RB);
+            GR_HIP(hipMemcpyAsync(g->h_carry_in.data(), g->carry_in.p, RB, hipMemcpyDeviceToHost, s));
+            GR_HIP(hipMemcpyAsync(g->h_carry_mine.data(), g->carry_mine.p, RB, hipMemcpyDeviceToHost, s));
+            GR_HIP(hipStreamSynchronize(s));
+            unsigned head[2] = {0, 0};
+            if (rc == XRIT_OK) memcpy(head, g->h_carry_in.data(), sizeof head);
+            if (rc == XRIT_OK && head[0] == 1u && head[1] <= 1024u) {
+                if (memcmp(g->h_carry_in.data(), g->h_carry_mine.data(), RB) == 0) {
+                    seamless = true;
+                    g->joined += 1;
+                } else if (exact_here) {
+                    GR_STEP(xrit_demod_redo_clock_from(g->chain, g->carry_in.p, g->soft_int.as<float>(), cap, &k, s));
+                    fetch_head();
+                    if (rc == XRIT_OK) { seamless = true; g->handovers += 1; }
+                }
+            }
+        }
+        if (onward && !sent) {
+            pack_end(g->carry_out.p);
+            int xr = g->tr->exchange(g->carry_out.p, RB, to, nullptr, 0, -1, s);
+            if (xr != XRIT_OK) fail(xr);
+        }
+        if (!onward) pack_end(g->keep_carry.p);      // the last rank: for rank 0, should the capture go on
+    }
+    // (a slice that continues from the very state the rank in front ended in has no straddling symbol to settle)
+    if (seamless) lag = 0;
     // lag > 0: rank - 1 already emitted my first `lag` symbols; lag < 0: the -lag symbols before my slice were
     // only emitted here, over the halo
     size_t count = k;

@@ -269,6 +269,18 @@ struct ClockStage {
     int redo_flipped(float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
     size_t prev_carry = 0, prev_n = 0;      // of the last call
     bool redo_ok = false;                   // ... which ended normally (its input is still in xbuf)
+    // What the loop carries from one call to the next as ONE device record (one capture across GPUs, csrc/group.hip: the rank
+    // in front hands it on, so that the stream has one loop state across all slices as the reference has across all chunks,
+    // demodulator.cpp:446-450): [valid, carry, -, -], the ClockState, then the unread tail (1024 samples, zero padded).
+    static constexpr size_t CARRY_HEAD = 64, CARRY_BYTES = 64 + 1024 * sizeof(float2);
+    // which = 0: what the NEXT call starts from; 1: what the last call started from (untouched since, as redo_flipped relies on)
+    int export_carry(void *d_rec, int which, hipStream_t s);
+    // The last call once more from the record of another handle (`carry_rec` samples of unread tail in it, read by the caller):
+    // the same input, the given loop state in front of it.
+    int redo_from(const void *d_rec, size_t carry_rec, float *soft_out, float2 *sym_out, size_t cap, size_t *n_out, hipStream_t s, Profiler *prof);
+    // the last call's symbols are those of ONE float32 walk from its start state (cfg.clock_serial, the exact closure, or a call
+    // short enough for a single exact walk): what a hand-over of the exact start state turns into the stream's own words
+    bool last_walk_exact() const;
     // What the recovery would carry had it run on the sign-flipped stream so far (make_alt(): the last call -- the
     // halo of a time slice, from a cold start -- is run again on its negated input and the outcome kept aside); a
     // later redo_flipped() starts from it instead of from the other sign's state with its history negated, whose

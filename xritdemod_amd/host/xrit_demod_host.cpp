@@ -341,7 +341,7 @@ struct Diag {
 // --gpus N: one process drives N GPUs (ncclCommInitAll).  A block of the capture is cut in N time slices, one per
 // GPU; the ranks exchange the halo and the boundary symbols over RCCL (xrit_group_process_slice_device) and the
 // symbols are sent on in rank order.  Every block starts from cold chains (a rank's previous slice ended somewhere
-// else in the stream), so blocks should be long: the halo is ~0.5 M input samples per rank at LRIT, decimation 5.
+// else in the stream), so blocks should be long: the halo is ~1 M input samples per rank at LRIT, decimation 5.
 static int run_multi_gpu(const Options &o, int type, size_t bytes_per_sample, const xrit_demod_config &cfg0)
 {
     const int W = o.gpus;
