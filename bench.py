@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 
 def run_contiguous(torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in, K, W, slices=None):
     """ONE stream per step, cut in `world` time slices of n_burst samples (BASELINE config 4): the C++ group API
-    (xrit_group_*: ncclSend / ncclRecv of the halo and of 256 boundary symbols, two ncclAllGather of (polarity, status) and
-    (count, status)).  The handles persist across steps, the slices of every step are generated and resident before the
+    (xrit_group_*: ncclSend / ncclRecv of the halo, of 256 boundary symbols and of the clock recovery's carried state, two
+    ncclAllGather of (polarity, status) and (count, status)).  The handles persist across steps, the slices of every step are generated and resident before the
     clock starts; torch.distributed only hands out the ncclUniqueId and brackets the timing.  `slices`: an existing
     (nbuf, n_burst, 2) float32 device tensor to generate into (the default leg reuses the headline's bursts).
     Returns the measurement as a dict (every rank; the reductions are collective)."""
@@ -86,13 +86,16 @@ def run_contiguous(torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst
         elapsed, nsym_all, flips_all = float(tmax[0].item()), float(t[1].item()), int(t[2].item())
     else:
         nsym_all, flips_all = float(nsym), flips
+    relocks, handovers, joined = grp.counters()      # this rank's (rank 0 prints: its own boundaries)
     del grp
     return {"value": round(n_burst * world * K / elapsed / 1e6, 2), "unit": "Msamples/s", "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 3), "symbols_per_s": round(nsym_all / elapsed, 1),
             "samples_per_step_per_gpu": n_burst, "halo_samples": int(halo), "halo_bytes_per_boundary": int(halo) * 8,
             "rccl_ranks": int(rccl_ranks), "polarity_flips": flips_all, "slices_reused": bool(W + K > nbuf),
-            "what": "one LRIT stream per step cut in n_gpus time slices: ncclSend / ncclRecv of the halo and of 256 boundary "
-                    "symbols, two ncclAllGather of two words per rank (xrit_group_process_slice_device)"}
+            "rank0_boundaries": {"second_starts": relocks, "clock_handovers": handovers, "joined": joined},
+            "what": "one LRIT stream per step cut in n_gpus time slices: ncclSend / ncclRecv of the halo (49 152 symbols), of 256 "
+                    "boundary symbols and of the clock recovery's carried state (8 KB), two ncclAllGather of two words per rank "
+                    "(xrit_group_process_slice_device)"}
 
 
 def bench_contiguous(args, torch, dist, xa, _capi, world, rank, local_rank, dev, n_burst, D, fs_in):
