@@ -98,6 +98,8 @@ def lib():
         L.xo_mm_work_trace.restype = C.c_int
         L.xo_mm_work_trace.argtypes = [vp, vp, C.c_int, vp, vp, vp]
         L.xo_mm_get_state.argtypes = [vp, C.POINTER(MMState)]
+        L.xo_mm_export.argtypes = [vp, C.POINTER(MMState), vp]
+        L.xo_mm_import.argtypes = [vp, C.POINTER(MMState), vp]
         L.xo_config_lrit.argtypes = [C.POINTER(Config), C.c_float, C.c_uint32]
         L.xo_config_hrit.argtypes = [C.POINTER(Config), C.c_float, C.c_uint32]
         L.xo_demod_create.restype = vp
@@ -115,6 +117,10 @@ def lib():
         L.xo_demod_rrc_taps.argtypes = [vp]
         L.xo_demod_sps.restype = C.c_float
         L.xo_demod_sps.argtypes = [vp]
+        L.xo_demod_costas.restype = C.POINTER(Costas)
+        L.xo_demod_costas.argtypes = [vp]
+        L.xo_demod_mm.restype = vp
+        L.xo_demod_mm.argtypes = [vp]
         L.xo_quantize_i8.argtypes = [vp, vp, C.c_size_t]
         L.xo_sync_correlate.argtypes = [vp, C.c_uint32, vp, C.c_int, vp, vp, vp]
         L.xo_sync_correlate.restype = None
@@ -278,6 +284,37 @@ class ClockRecovery:
         lib().xo_mm_get_state(self._h, C.byref(s))
         return s
 
+    # what the object carries from one Work call to the next, as one array of float32 words (tests/dist_twin.py hands it from
+    # rank to rank): the MMState, then the samples not consumed yet
+    CARRY_WORDS = C.sizeof(MMState) // 4 + 2 * 2048
+
+    def export_carry(self):
+        s = MMState()
+        tail = np.zeros(2048, np.complex64)
+        lib().xo_mm_export(self._h, C.byref(s), _p(tail))
+        out = np.zeros(self.CARRY_WORDS, np.float32)
+        out[:C.sizeof(MMState) // 4] = np.frombuffer(bytes(s), np.float32)
+        out[C.sizeof(MMState) // 4:] = tail.view(np.float32)
+        return out
+
+    def import_carry(self, words):
+        words = np.ascontiguousarray(words, np.float32)
+        assert len(words) == self.CARRY_WORDS
+        s = MMState.from_buffer_copy(words[:C.sizeof(MMState) // 4].tobytes())
+        tail = words[C.sizeof(MMState) // 4:].copy()
+        lib().xo_mm_import(self._h, C.byref(s), _p(tail))
+
+
+class _BorrowedClock(ClockRecovery):
+    """The clock recovery INSIDE a Demod (not owned: no destroy)."""
+
+    def __init__(self, handle, owner):
+        self._h = handle
+        self._owner = owner
+
+    def __del__(self):
+        self._h = None
+
 
 def config(mode="lrit", sample_rate=1.25e6, decimation=1):
     c = Config()
@@ -306,6 +343,16 @@ class Demod:
     @property
     def sps(self):
         return lib().xo_demod_sps(self._h)
+
+    @property
+    def costas(self):
+        """The chain's own Costas loop (ctypes view: .phase / .freq may be read and set between calls)."""
+        return lib().xo_demod_costas(self._h).contents
+
+    @property
+    def clock(self):
+        """The chain's own clock recovery (export_carry / import_carry between calls)."""
+        return _BorrowedClock(lib().xo_demod_mm(self._h), self)
 
     def decimator_taps(self):
         n = lib().xo_demod_decimator_ntaps(self._h)

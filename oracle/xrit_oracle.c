@@ -465,6 +465,29 @@ void xo_mm_get_state(const xo_mm *m, xo_mm_state *s)
     s->carry = m->carry;
 }
 
+/* Test infrastructure for the multi-rank tests (tests/dist_twin.py): the state ClockRecovery carries from one Work call to
+ * the next -- the reference holds ONE such object for the whole stream (demodulator.cpp:449) -- taken out of one object and
+ * put into another, so that a CPU twin of a stream cut across ranks can hand it on as the product does across GPUs. */
+void xo_mm_export(const xo_mm *m, xo_mm_state *s, xo_cf *carry /* [s->carry] after the call; at least 2048 */)
+{
+    xo_mm_get_state(m, s);
+    if (m->carry > 0) memcpy(carry, m->buf, sizeof(xo_cf) * (size_t)m->carry);
+}
+
+void xo_mm_import(xo_mm *m, const xo_mm_state *s, const xo_cf *carry)
+{
+    m->mu = s->mu; m->omega = s->omega;
+    m->p_2t = s->p_2t; m->p_1t = s->p_1t; m->p_0t = s->p_0t;
+    m->c_2t = s->c_2t; m->c_1t = s->c_1t; m->c_0t = s->c_0t;
+    if ((size_t)s->carry > m->cap) {
+        free(m->buf);
+        m->buf = (xo_cf *)malloc(sizeof(xo_cf) * ((size_t)s->carry + 64));
+        m->cap = (size_t)s->carry + 64;
+    }
+    if (s->carry > 0) memcpy(m->buf, carry, sizeof(xo_cf) * (size_t)s->carry);
+    m->carry = s->carry;
+}
+
 /* ClockRecovery::Work(in, out, n) -> symbols, demodulator.cpp:156.  GNU Radio
  * digital::clock_recovery_mm_cc::general_work.  A symbol is produced while the
  * read index ii satisfies ii < available - NTAPS - FUDGE (the upstream `ni`);
@@ -723,6 +746,9 @@ int xo_demod_decimator_ntaps(const xo_demod *d) { return d->dec_ntaps; }
 const float *xo_demod_decimator_taps(const xo_demod *d) { return d->dec_taps; }
 const float *xo_demod_rrc_taps(const xo_demod *d) { return d->rrc_taps; }
 float xo_demod_sps(const xo_demod *d) { return d->sps; }
+/* the chain's own loop objects (tests: a Costas loop started at a phase of pi, the clock recovery's carried state) */
+xo_costas *xo_demod_costas(xo_demod *d) { return &d->costas; }
+xo_mm *xo_demod_mm(xo_demod *d) { return d->mm; }
 
 /* SymbolManager::process, SymbolManager.cpp:43-46 */
 void xo_quantize_i8(const float *in, int8_t *out, size_t n)

@@ -109,6 +109,9 @@ void   xo_mm_destroy(xo_mm *m);
 /* returns symbols written; out must hold at least n/ (omega*(1-lim)) + 2 */
 int    xo_mm_work(xo_mm *m, const xo_cf *in, int n, xo_cf *out);
 void   xo_mm_get_state(const xo_mm *m, xo_mm_state *s);
+/* the carried state out of one object and into another (tests/dist_twin.py: one loop state across the ranks of a cut stream) */
+void   xo_mm_export(const xo_mm *m, xo_mm_state *s, xo_cf *carry /* [>= 2048] */);
+void   xo_mm_import(xo_mm *m, const xo_mm_state *s, const xo_cf *carry);
 /* per-symbol trace for diagnostics (tests only): arm index of the last call */
 int    xo_mm_work_trace(xo_mm *m, const xo_cf *in, int n, xo_cf *out, int *arm, float *mu_trace);
 
@@ -143,6 +146,8 @@ int       xo_demod_decimator_ntaps(const xo_demod *d);
 const float *xo_demod_decimator_taps(const xo_demod *d);
 const float *xo_demod_rrc_taps(const xo_demod *d);
 float     xo_demod_sps(const xo_demod *d);
+xo_costas *xo_demod_costas(xo_demod *d);   /* the chain's own loop objects (tests) */
+xo_mm     *xo_demod_mm(xo_demod *d);
 
 /* SymbolManager::process quantiser, SymbolManager.cpp:43-46 */
 void xo_quantize_i8(const float *in, int8_t *out, size_t n);

@@ -186,6 +186,154 @@ def demodulate_contiguous(make_process, body, dist, rank, world, halo_len, same_
     return out.astype(np.float32), int(sum(counts[:rank]))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Round 6: ONE loop state across the slices -- the twin of csrc/group.hip steps 3b / 3c.  The reference's five objects carry one
+# state across every chunk (demodulator.cpp:446-450); a stream cut across ranks keeps that true in two moves:
+#   * a rank whose cold start fell into the OTHER Costas lock starts once more from a phase of pi (the detector I*Q does not see
+#     a half turn: same pull-in, other lock) and there meets the stream's own float32 trajectory inside its halo;
+#   * the clock recovery's carried state (mu, omega, last symbols and decisions, unread samples) travels from every rank to the
+#     rank behind it, which walks its slice's clock recovery again from it unless its own warm-up had reached the very same one.
+# `make_chain()` returns an object with process(x) -> soft symbols, flip_costas_phase(), clock_start() / clock_carry() (float32
+# words: the state the last call started from / the next starts from) and redo_clock_from(words) -> soft symbols of the last
+# call again.  On GPUs that object is the product's chain handle (xrit_demod_flip_costas_phase, xrit_demod_export_clock_carry,
+# xrit_demod_redo_clock_from -- and the whole exchange is xrit_group_process_slice_device); here the CPU oracle plays it.
+
+class OracleChain:
+    """The chain interface of demodulate_contiguous_one_state played by the CPU oracle (tests only)."""
+
+    def __init__(self, mode="lrit", sample_rate=1.25e6, decimation=1):
+        import oracle
+        self.d = oracle.Demod(oracle.config(mode, sample_rate, decimation))
+        self._start = None
+
+    def flip_costas_phase(self):
+        import numpy as np
+        c = self.d.costas
+        c.phase = float(np.float32(c.phase) - np.float32(np.pi)) if c.phase > 0 else float(np.float32(c.phase) + np.float32(np.pi))
+
+    def process(self, x):
+        self._start = self.d.clock.export_carry()
+        return self.d.process(x)
+
+    def clock_start(self):
+        return self._start
+
+    def clock_carry(self):
+        return self.d.clock.export_carry()
+
+    def redo_clock_from(self, words):
+        import numpy as np
+        mm = self.d.clock
+        mm.import_carry(words)
+        self._start = np.array(words, np.float32)
+        return np.ascontiguousarray(mm.Work(self.d.stage("costas")).real, np.float32)
+
+
+def _align_lag(prev_tail, halo_syms, syms):
+    """split_align's search on its own: (relative polarity, lag)."""
+    import numpy as np
+    seq = np.concatenate([halo_syms, syms[:KEEP]])
+    nh, m = len(halo_syms), len(prev_tail)
+    best = (0.0, 0, 1)
+    for lag in range(-KEEP + 1, KEEP):
+        end = nh + lag
+        if end - m < 0 or end > len(seq):
+            continue
+        c = float(np.dot(prev_tail, seq[end - m:end]))
+        if abs(c) > best[0]:
+            best = (abs(c), lag, 1 if c >= 0 else -1)
+    return best[2], best[1]
+
+
+def demodulate_contiguous_one_state(make_chain, body, dist, rank, world, halo_len):
+    """The exchange of csrc/group.hip (round 6) under torch.distributed, host arrays.  Returns (soft symbols of this rank in the
+    stream's polarity, offset of the first one in the stream's output, what happened at this rank's boundary: a dict with
+    first_lock (+-1), second_start, handed, joined)."""
+    import numpy as np
+    import torch
+    body = np.ascontiguousarray(body, np.complex64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    halo = None
+    reqs = []
+    if rank + 1 < world:
+        reqs.append(dist.isend(t(body[-halo_len:].view(np.float32)), dst=rank + 1))
+    if rank > 0:
+        buf = torch.zeros(2 * halo_len, dtype=torch.float32)
+        dist.recv(buf, src=rank - 1)
+        halo = buf.numpy().view(np.complex64).copy()
+    for r in reqs:
+        r.wait()
+
+    def run(chain):
+        h = chain.process(halo)[-(TAIL + KEEP):].copy() if halo is not None else np.zeros(0, np.float32)
+        return h, chain.process(body)
+
+    chain = make_chain()
+    h_syms, syms = run(chain)
+    # 2b. boundary symbols, in each rank's FIRST polarity
+    tail = np.zeros(TAIL, np.float32)
+    k = min(TAIL, len(syms))
+    if k:
+        tail[TAIL - k:] = syms[-k:]
+    reqs = []
+    if rank + 1 < world:
+        reqs.append(dist.isend(t(tail), dst=rank + 1))
+    prev_tail = np.zeros(0, np.float32)
+    if rank > 0:
+        buf = torch.zeros(TAIL, dtype=torch.float32)
+        dist.recv(buf, src=rank - 1)
+        prev_tail = buf.numpy().copy()
+    for r in reqs:
+        r.wait()
+    pol_rel, lag = _align_lag(prev_tail, h_syms, syms) if rank > 0 else (1, 0)
+
+    def gather(a, b):
+        if world == 1:
+            return [a], [b]
+        got = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([a, b], dtype=torch.int64))
+        return [int(g[0]) for g in got], [int(g[1]) for g in got]
+
+    pols, _ = gather(pol_rel, 0)
+    pol = 1
+    for p in pols[:rank + 1]:
+        pol *= p
+    info = {"first_lock": pol, "second_start": False, "handed": False, "joined": False}
+    # 3b. the other lock: once more, from a Costas phase of pi
+    if pol < 0 and rank > 0:
+        chain = make_chain()
+        chain.flip_costas_phase()
+        h_syms, syms = run(chain)
+        p2, lag2 = _align_lag(prev_tail, h_syms, syms)
+        info["second_start"] = True
+        if p2 == -pol_rel:
+            lag = lag2
+        else:                   # (fell on the same side again: the symbols negated, as before round 6)
+            syms, h_syms = -syms, -h_syms
+    # 3c. the clock recovery's carried state, from rank to rank: receive, settle, then send what THIS slice ended in
+    words = len(chain.clock_carry())
+    if rank > 0:
+        buf = torch.zeros(words, dtype=torch.float32)
+        dist.recv(buf, src=rank - 1)
+        theirs = buf.numpy().copy()
+        if np.array_equal(theirs.view(np.uint32), chain.clock_start().view(np.uint32)):
+            info["joined"] = True
+        else:
+            syms = chain.redo_clock_from(theirs)
+            info["handed"] = True
+        lag = 0                 # (a slice that continues from the very state the slice in front ended in has no straddling symbol)
+    if rank + 1 < world:
+        dist.send(t(chain.clock_carry()), dst=rank + 1)
+    if lag < 0:
+        out = np.concatenate([h_syms[len(h_syms) + lag:], syms])
+    elif lag > 0:
+        out = syms[lag:]
+    else:
+        out = syms
+    _, counts = gather(1, len(out))
+    return out.astype(np.float32), int(sum(counts[:rank])), info
+
+
 def demodulate_contiguous_device(make_demod, body_t, dist, rank, world, halo_len, same_lock=False, stream=None):
     """Device-resident form of demodulate_contiguous (what bench.py --contiguous runs, one process per GPU, nccl =
     RCCL): body_t is this rank's slice as a float32 cuda tensor of shape (n, 2); the halo travels GPU to GPU with

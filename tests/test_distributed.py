@@ -110,3 +110,56 @@ def test_contiguous_split_two_ranks_same_lock():
     assert np.array_equal(np.sign(got), np.sign(ref))
     # rank 1 ran again on the other lock: it now follows the uninterrupted trajectory to the chaos level
     assert float(np.sqrt(np.mean((got[n0:] - ref[n0:]) ** 2))) < 3e-4
+
+
+# ---- round 6: ONE loop state across the slices (the twin of csrc/group.hip steps 3b / 3c) ----------------------------------------
+def _one_state_worker(rank, world, port, q, phases):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import dist_twin as xd
+    import synth
+    d = xd.init("gloo")
+    n = 600000
+    halo_len = xd.halo_samples(1, 4.2534, 0, warm_symbols=49152)
+    for ph in phases:
+        body = synth.generate(synth.SynthParams(phase0=ph, seed=4242), n, start=rank * n)
+        soft, offset, info = xd.demodulate_contiguous_one_state(lambda: xd.OracleChain("lrit", 1.25e6, 1), body, d, rank, world, halo_len)
+        q.put((ph, rank, offset, soft, info))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_contiguous_split_carries_one_loop_state_across_ranks():
+    """World of two over gloo, the CPU oracle as the chain: whichever Costas lock rank 1's cold start falls into (the capture's
+    start phase is moved until both have been seen), the joined symbols are the uninterrupted chain's WORD FOR WORD -- a rank pi
+    away starts once more from a phase of pi, the clock recovery starts from the state rank 0 ended in (or had reached it).
+    The same protocol as xrit_group_process_slice_device (tests/test_gpu_parity.py runs that one on the GPU)."""
+    import oracle
+    import synth
+    world, n = 2, 600000
+    phases = (0.7, 1.5, 2.3, 3.9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_one_state_worker, args=(r, world, port, q, phases)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world * len(phases)):
+        ph, rank, offset, soft, info = q.get(timeout=600)
+        res[(ph, rank)] = (offset, soft, info)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    locks = set()
+    for ph in phases:
+        ref = oracle.Demod(oracle.config("lrit", 1.25e6, 1)).process(synth.generate(synth.SynthParams(phase0=ph, seed=4242), world * n))
+        (o0, s0, i0), (o1, s1, i1) = res[(ph, 0)], res[(ph, 1)]
+        got = np.concatenate([s0, s1])
+        assert o0 == 0 and o1 == len(s0) and len(got) == len(ref), (ph, o0, o1, len(s0), len(s1), len(ref))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (ph, i1, float(np.sqrt(np.mean((got - ref) ** 2))))
+        assert not i0["second_start"] and not i0["handed"] and not i0["joined"]
+        assert i1["second_start"] == (i1["first_lock"] < 0) and (i1["handed"] or i1["joined"]), (ph, i1)
+        locks.add(i1["first_lock"])
+    assert locks == {1, -1}, locks
