@@ -162,7 +162,12 @@ typedef struct xrit_demod_config {
                                  *      literally in warmed-up chains (agc.hip), the Costas loop walked exactly 64 samples per
                                  *      step with the C library's sincosf evaluated in double precision (costas_exact.hip).
                                  *      What is left of the soft symbols' distance is the clock recovery's own (its distance
-                                 *      from the serial trajectory, 5-6e-5 LRIT). */
+                                 *      from the serial trajectory, 5-6e-5 LRIT) -- and on calls of up to 200 k symbols nothing: in
+                                 *      this mode such a call's clock recovery is ONE exact walk from the carried state (the default
+                                 *      configuration walks so up to 74 k), so every chunk the reference hands its blocks --
+                                 *      32 Ki .. 512 Ki samples, at most 123 k symbols LRIT / 194 k HRIT, demodulator.cpp:108-119 --
+                                 *      comes out as the CPU chain's soft symbols word for word (a 512 Ki-sample call: 5.0 ms
+                                 *      instead of 3.2). */
     int32_t  reserved[2];
 } xrit_demod_config;
 
@@ -219,7 +224,7 @@ int xrit_demod_export_clock_carry(xrit_demod *d, int which, void *d_record, void
 int xrit_demod_redo_clock_from(xrit_demod *d, const void *d_record, float *d_soft_out, size_t cap, size_t *n_out, void *stream);
 /* 1 if the last process call's symbols are those of ONE float32 walk from the state it started from (cfg.clock_serial,
  * the exact closure cfg.clock_exact = 1, or a call short enough for a single exact walk -- up to 73 k symbols in the
- * default configuration), 0 if they are relayed / overlapping walks (close to it, not it), < 0 on a null handle. */
+ * default configuration, 200 k with cfg.front_exact = 2), 0 if they are relayed / overlapping walks (close to it, not it), < 0 on a null handle. */
 int xrit_demod_last_clock_exact(const xrit_demod *d);
 /* 1 if a process call of n_complex input samples on this handle takes the bit-exact front end (cfg.front_exact and the
  * call's length decide, see xrit_demod_config), 0 if the fast one, < 0 on a null handle. */

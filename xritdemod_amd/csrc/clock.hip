@@ -1405,7 +1405,7 @@ int ClockStage::relay_plan()
     int min_syms = j.relay_budget > 0 ? 16384 : 2048;
     if (j.no_handoff && exact == 0 && !relay_per_cu_set) {
         const long long all = (long long)j.K * NS;
-        min_syms = all <= 3LL * (auto_long_seg / 2) ? (int)all : auto_long_seg / 2;
+        min_syms = all <= one_walk_limit() ? (int)all : auto_long_seg / 2;
     }
     if (relay_window <= 0 && cps * NS < min_syms) cps = (min_syms + NS - 1) / NS;
     if (cps < 1) cps = 1;
@@ -2038,7 +2038,7 @@ int ClockStage::begin(size_t n, float *soft_out, float2 *sym_out, size_t cap, hi
     // cost such a call 0.1 ms, start them close enough for three passes over segments of 16 k symbols)
     const long long all_syms = (long long)K * NS;
     j.no_handoff = j.relay && (relay_no_handoff >= 0 ? relay_no_handoff != 0
-                                                     : exact == 0 && (all_syms <= 3LL * (auto_long_seg / 2) || all_syms >= auto_guess_min));
+                                                     : exact == 0 && (all_syms <= one_walk_limit() || all_syms >= auto_guess_min));
     if (j.relay) XR_TRY(relay_plan());
     if (j.no_handoff && exact == 0) {
         // passes for the default's parity by segment length (measured, same file: 16.5 k symbols per segment: 3 passes 9.6e-5,

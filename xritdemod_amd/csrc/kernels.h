@@ -336,6 +336,12 @@ struct ClockStage {
     int auto_passes = 3;
     long long auto_guess_min = 6000000;   // symbols from which the default configuration relays straight from the timing guess
     int auto_long_seg = 49152;  // symbols per segment from which two relay passes are the default's budget (ClockStage::begin)
+    // A call of up to this many symbols is ONE exact walk from the carried state (0: three of the default's shortest segments,
+    // 73.7 k symbols -- no slower than three passes over a third of it).  Parity mode (cfg.front_exact = 2) sets 200 k: every
+    // chunk the reference hands its blocks (up to 512 Ki samples: 123 k symbols LRIT, 194 k HRIT) then comes out as the CPU
+    // chain's words, at 56 symbols per microsecond on the one walking wave.
+    int one_walk_max = 0;
+    long long one_walk_limit() const { return one_walk_max > 0 ? (long long)one_walk_max : 3LL * (auto_long_seg / 2); }
     float auto_shift = 6e-4f;
     float auto_snr = 10.0f;     // ... and to closure outright when the first pass's soft symbols show 2 Es/N0 below this (7 dB)
     float auto_snr_floor = 2.0f;  // ... but not below this: no signal (noise alone shows 1.75)
