@@ -28,7 +28,7 @@ for case in range(cases):
     n = int(rng.integers(halo + 1000 * D, max(halo + 2000 * D, min(hi, 2 * halo))))
     n -= n % D
     p = synth.SynthParams(fs_in=fs, symbol_rate=sr, alpha=al, carrier_hz=float(rng.uniform(-800, 800)), phase0=float(rng.uniform(0, 6.28)),
-                          timing_offset=float(rng.uniform(0, 1)), clock_ppm=float(rng.uniform(-40, 40)), esn0_db=float(rng.uniform(7, 20)),
+                          timing_offset=float(rng.uniform(0, 1)), clock_ppm=float(rng.uniform(-40, 40)), esn0_db=float(rng.uniform(float(os.environ.get("ESN0_LO", "7")), float(os.environ.get("ESN0_HI", "20")))),
                           seed=int(rng.integers(1, 1 << 30)))
     x = synth.generate(p, world * calls * n)
     want = oracle.Demod(oracle.config(mode, fs, D)).process(x)
