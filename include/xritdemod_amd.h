@@ -117,7 +117,7 @@ typedef struct xrit_demod_config {
                                  * knows of its past by one segment (no shorter than 16 384 symbols unless the relay
                                  * runs to closure); a pass that changes nothing has reproduced the serial trajectory
                                  * (clock_serial = 1) bit for bit.
-                                 *   0 (default), by call size (round 4): up to 74 k symbols ONE exact walk from the carried
+                                 *   0 (default), by call size (round 4): up to 74 k symbols (200 k where the call takes the bit-exact front end: cfg.front_exact 0 / 2) ONE exact walk from the carried
                                  *      state (the serial trajectory itself); from 6 M symbols -- every BASELINE burst -- no hand-off
                                  *      passes at all: two walkers per CU, the first relay pass from the timing guess, three passes at
                                  *      24.8 k symbols per segment, two from 49 k (soft symbols 5.6e-5 rms from the serial
@@ -142,7 +142,8 @@ typedef struct xrit_demod_config {
     int32_t  clock_exact_window;/* chains per relay segment; 0 = chosen per call (~4 segments per CU) */
     int32_t  front_exact;       /* which front end a call takes (round 6).  0 (default): the bit-exact one (see 2) on calls below the
                                  * big-burst size -- the reference's chunk sizes and everything up to a million symbols, where a call
-                                 * is launch latency, not throughput: a call of up to 74 k symbols then yields the CPU chain's soft
+                                 * is launch latency, not throughput: a call of up to 200 k symbols (every chunk the reference hands its blocks, 512 Ki
+                                 * samples = 123 k symbols LRIT / 194 k HRIT included) is ONE exact walk of the clock recovery and yields the CPU chain's soft
                                  * symbols word for word -- and the fast one on bursts of a million symbols and more (what `value`
                                  * is quoted on); -1: the fast one on calls of every size (round 5's default).
                                  * The fast front end:  What the soft symbols' distance from the CPU chain is made
@@ -163,8 +164,8 @@ typedef struct xrit_demod_config {
                                  *      step with the C library's sincosf evaluated in double precision (costas_exact.hip).
                                  *      What is left of the soft symbols' distance is the clock recovery's own (its distance
                                  *      from the serial trajectory, 5-6e-5 LRIT) -- and on calls of up to 200 k symbols nothing: in
-                                 *      this mode such a call's clock recovery is ONE exact walk from the carried state (the default
-                                 *      configuration walks so up to 74 k), so every chunk the reference hands its blocks --
+                                 *      this mode, as in the default, such a call's clock recovery is ONE exact walk from the carried state
+                                 *      (with the fast front end on calls of every size, -1 / 1: up to 74 k), so every chunk the reference hands its blocks --
                                  *      32 Ki .. 512 Ki samples, at most 123 k symbols LRIT / 194 k HRIT, demodulator.cpp:108-119 --
                                  *      comes out as the CPU chain's soft symbols word for word (a 512 Ki-sample call: 5.0 ms
                                  *      instead of 3.2). */
@@ -223,8 +224,8 @@ int xrit_demod_export_clock_carry(xrit_demod *d, int which, void *d_record, void
  * Refused (XRIT_E_INVALID, nothing changed) while a prefetched input waits, or for a record that is not one. */
 int xrit_demod_redo_clock_from(xrit_demod *d, const void *d_record, float *d_soft_out, size_t cap, size_t *n_out, void *stream);
 /* 1 if the last process call's symbols are those of ONE float32 walk from the state it started from (cfg.clock_serial,
- * the exact closure cfg.clock_exact = 1, or a call short enough for a single exact walk -- up to 73 k symbols in the
- * default configuration, 200 k with cfg.front_exact = 2), 0 if they are relayed / overlapping walks (close to it, not it), < 0 on a null handle. */
+ * the exact closure cfg.clock_exact = 1, or a call short enough for a single exact walk -- up to 200 k symbols in the
+ * default configuration and with cfg.front_exact = 2, 73 k with the fast front end on calls of every size), 0 if they are relayed / overlapping walks (close to it, not it), < 0 on a null handle. */
 int xrit_demod_last_clock_exact(const xrit_demod *d);
 /* 1 if a process call of n_complex input samples on this handle takes the bit-exact front end (cfg.front_exact and the
  * call's length decide, see xrit_demod_config), 0 if the fast one, < 0 on a null handle. */

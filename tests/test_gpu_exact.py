@@ -481,18 +481,20 @@ def test_clock_state_handed_from_one_handle_to_another(xa, oracle_mod):
     assert torch.equal(mine, rec)
 
 
+@pytest.mark.parametrize("front_exact", [0, 2])
 @pytest.mark.parametrize("mode, fs, kw", [("lrit", 1.25e6, dict(fs_in=1.25e6)),
                                           ("hrit", 2.5e6, dict(fs_in=2.5e6, symbol_rate=927000.0, alpha=0.3))])
-def test_parity_mode_at_the_references_largest_chunk_is_the_cpu_chains_words(xa, oracle_mod, mode, fs, kw):
+def test_parity_mode_at_the_references_largest_chunk_is_the_cpu_chains_words(xa, oracle_mod, mode, fs, kw, front_exact):
     """The reference hands its blocks between 32 Ki and 512 Ki complex samples per call (demodulator.cpp:108-119, the FIFO's
-    threshold and capacity): 123 k symbols at LRIT, 194 k at HRIT at most.  In parity mode (cfg.front_exact = 2) a call of up to
+    threshold and capacity): 123 k symbols at LRIT, 194 k at HRIT at most.  In the default configuration (cfg.front_exact = 0: the
+    bit-exact front end on calls below a million symbols) and in parity mode (cfg.front_exact = 2) a call of up to
     200 k symbols is ONE exact walk of the clock recovery behind the bit-exact front end: three consecutive chunks of the largest
     size come out as the CPU chain's words -- no relay, no floor -- and so does a stream of the file frontend's 65 535-sample blocks
     (CFileFrontend.cpp:48); a call beyond 200 k symbols is relayed again (close to the serial trajectory, not it)."""
     n = 512 * 1024
     x = synth_signal(3 * n + 700000, **kw)
     ref = oracle_mod.Demod(oracle_mod.config(mode, fs, 1))
-    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, 1, front_exact=2))
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, 1, front_exact=front_exact))
     for c in range(3):
         want = ref.process(x[c * n:(c + 1) * n])
         got = dem.process(x[c * n:(c + 1) * n])
@@ -508,7 +510,7 @@ def test_parity_mode_at_the_references_largest_chunk_is_the_cpu_chains_words(xa,
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # the file frontend's blocks
     ref = oracle_mod.Demod(oracle_mod.config(mode, fs, 1))
-    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, 1, front_exact=2))
+    dem = xa.Demodulator(xa.Demodulator.config(mode, fs, 1, front_exact=front_exact))
     for c in range(6):
         blk = x[c * 65535:(c + 1) * 65535]
         assert np.array_equal(dem.process(blk).view(np.uint32), ref.process(blk).view(np.uint32)), c

@@ -342,8 +342,11 @@ int xrit_demod_create(const xrit_demod_config *cfg, xrit_demod **out)
         // the front end bit for bit the CPU chain's through the Costas loop; fir.hip, agc.hip, costas_exact.hip)
         d->dec.exact = d->rrc.exact = d->agc.exact = d->costas.exact = cfg->front_exact == 2;
         if (cfg->front_exact == 2 && !getenv("XRIT_NO_COSTAS_STREAM")) d->stream_c = d->stream_c_pool;
-        // (parity mode: calls of up to 200 k symbols -- every chunk size of the reference -- are one exact walk: the CPU chain's words)
-        if (cfg->front_exact == 2) d->clock.one_walk_max = 200000;
+        // (wherever such a call takes the bit-exact front end -- the default and parity mode --, a call of up to 200 k symbols, i.e.
+        // every chunk size of the reference, is ONE exact walk of the clock recovery: the CPU chain's words.  With the fast
+        // front end on calls of every size, cfg.front_exact = -1 / 1, the limit stays where one walk costs no more than the
+        // relay, 73.7 k symbols: there is no word to keep.)
+        if (cfg->front_exact == 2 || cfg->front_exact == 0) d->clock.one_walk_max = 200000;
         if ((rc = d->dec.init(lp.data(), (int)lp.size(), (int)cfg->decimation)) != XRIT_OK) break;
         if ((rc = d->rtl.init(cfg->sample_rate)) != XRIT_OK) break;
         if ((rc = d->agc.init(cfg->agc_rate, cfg->agc_reference, cfg->agc_gain, cfg->agc_max_gain)) != XRIT_OK) break;

@@ -337,7 +337,7 @@ struct ClockStage {
     long long auto_guess_min = 6000000;   // symbols from which the default configuration relays straight from the timing guess
     int auto_long_seg = 49152;  // symbols per segment from which two relay passes are the default's budget (ClockStage::begin)
     // A call of up to this many symbols is ONE exact walk from the carried state (0: three of the default's shortest segments,
-    // 73.7 k symbols -- no slower than three passes over a third of it).  Parity mode (cfg.front_exact = 2) sets 200 k: every
+    // 73.7 k symbols -- no slower than three passes over a third of it).  Handles whose calls of this size take the bit-exact front end (cfg.front_exact 0 / 2) set 200 k: every
     // chunk the reference hands its blocks (up to 512 Ki samples: 123 k symbols LRIT, 194 k HRIT) then comes out as the CPU
     // chain's words, at 56 symbols per microsecond on the one walking wave.
     int one_walk_max = 0;
