@@ -24,9 +24,9 @@ for case in range(cases):
     halo = probe.halo_samples
     del probe
     sps = fs / D / sr
-    hi = int((200000 if fe == 2 else 72000) * sps * D)
+    hi = int(195000 * sps * D)      # (the single-walk limit, 200 k symbols, in both modes)
     relay = os.environ.get("GROUP_FUZZ_REGIME", "walk") == "relay"     # slices of 1 .. 4 times the single-walk limit: relayed, no hand-over
-    n = int(rng.integers(hi + 1000 * D, 4 * hi)) if relay else int(rng.integers(halo + 1000 * D, max(halo + 2000 * D, min(hi, 2 * halo))))
+    n = int(rng.integers(hi + 6000 * D, 4 * hi)) if relay else int(rng.integers(halo + 1000 * D, max(halo + 2000 * D, min(hi, 4 * halo))))
     n -= n % D
     p = synth.SynthParams(fs_in=fs, symbol_rate=sr, alpha=al, carrier_hz=float(rng.uniform(-800, 800)), phase0=float(rng.uniform(0, 6.28)),
                           timing_offset=float(rng.uniform(0, 1)), clock_ppm=float(rng.uniform(-40, 40)), esn0_db=float(rng.uniform(float(os.environ.get("ESN0_LO", "7")), float(os.environ.get("ESN0_HI", "20")))),
