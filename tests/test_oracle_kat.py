@@ -669,3 +669,31 @@ def test_sincosf_restatement_is_the_c_library(oracle_mod):
     # and it is a sincos: within 1 ulp of the double-precision value
     assert np.max(np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64)))) < 1.2e-7
     assert np.max(np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64)))) < 1.2e-7
+
+
+def test_clock_recovery_state_moves_between_objects(oracle_mod):
+    """xo_mm_export / xo_mm_import (test infrastructure of the multi-rank twin): the state one ClockRecovery object carries
+    between Work calls, put into another object, continues the stream word for word -- the reference holds ONE such object for
+    the whole stream (demodulator.cpp:449), so a stream cut across objects must behave as if it were not."""
+    import synth
+    o = oracle_mod
+    x = synth.generate(synth.SynthParams(), 400000)
+    whole = o.Demod(o.config("lrit", 1.25e6, 1))
+    ref = whole.process(x)
+    a = o.Demod(o.config("lrit", 1.25e6, 1))
+    a1 = a.process(x[:150000])
+    words = a.clock.export_carry()
+    assert len(words) == o.ClockRecovery.CARRY_WORDS and 0 <= a.clock.state().carry <= 64
+    a2 = a.process(x[150000:])
+    assert np.array_equal(np.concatenate([a1, a2]), ref)
+    costas_2 = a.stage("costas")                    # the second call's de-rotated samples
+    b = o.Demod(o.config("lrit", 1.25e6, 1)).clock  # a cold object ...
+    b.import_carry(words)                           # ... given a's state where the second call begins
+    out = b.Work(costas_2)
+    assert np.array_equal(np.ascontiguousarray(out.real, np.float32), a2)
+    # and the chain's own Costas loop can be started half a turn away (the other lock: every symbol negated to rounding)
+    c = o.Demod(o.config("lrit", 1.25e6, 1))
+    c.costas.phase = float(np.float32(np.pi))
+    neg = c.process(x)
+    big = np.abs(ref) > 0.05
+    assert len(neg) == len(ref) and np.mean(np.sign(neg[big][20000:]) == -np.sign(ref[big][20000:])) > 0.9999
